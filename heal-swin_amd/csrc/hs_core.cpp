@@ -1,0 +1,43 @@
+// Status / error plumbing of libhealswin.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+
+#include "hs_common.h"
+
+namespace hs {
+char* error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int fail(int status, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return status;
+}
+}  // namespace hs
+
+extern "C" {
+const char* hs_version(void) { return "healswin 0.1 (gfx950)"; }
+const char* hs_last_error(void) { return hs::error_buffer(); }
+const char* hs_status_string(int status) {
+    switch (status) {
+        case HS_OK: return "ok";
+        case HS_ERR_INVALID_ARG: return "invalid argument";
+        case HS_ERR_UNSUPPORTED: return "unsupported shape or dtype";
+        case HS_ERR_HIP: return "HIP runtime error";
+        case HS_ERR_NOT_PERMUTATION: return "shift is not a permutation";
+        default: return "unknown status";
+    }
+}
+int hs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+}

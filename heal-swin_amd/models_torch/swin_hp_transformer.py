@@ -1,0 +1,534 @@
+"""HEAL-SWIN-UNet on the MI355X-native hot path.
+
+Keeps the public surface of the reference module `heal_swin/models_torch/swin_hp_transformer.py`
+(class names, constructor signatures, attribute paths and therefore state-dict keys, `forward`
+contracts) so that it can stand in for it under the reference's Lightning modules, while the
+computation is organised differently:
+
+  * per block there is ONE attention kernel call: shift -> window partition -> attention -> window reverse
+    -> shift back are fused into `hs_window_attn_fwd/bwd`, which gathers rows of the un-shifted qkv tensor
+    through the shifter's int32 table and scatters its output rows back through the same table
+    (row permutations commute with the row-wise LayerNorm / Linear layers around it);
+  * masks are per-pixel uint8 region labels, not [nW, Ws, Ws] tensors; the reference's `attn_mask` buffer
+    only exists in `state_dict()` / is accepted by `load_state_dict()`;
+  * all LayerNorms (block norms, PatchMerging's LN(4C) over 4 sibling pixels, PatchExpand's LN over each
+    child row) run in the HIP row-LayerNorm kernel, with the v2-placement residual add fused in;
+  * activations run in `compute_dtype` (fp32 or bf16; fp32 statistics/softmax/accumulation either way),
+    parameters stay fp32.
+
+Reference line numbers in comments refer to heal_swin/models_torch/swin_hp_transformer.py.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Literal, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from .. import _lib, ops
+from ..data_spec import DataSpec
+from . import hp_shifting
+
+EMIT_REFERENCE_BUFFERS = True  # state_dict() carries the reference's `attn_mask` buffers (ref :306-308)
+
+
+# ----------------------------------------------------------------------------- leaf layers
+class HSLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameters, HIP kernel arithmetic (`hs_layernorm_fwd/bwd`)."""
+
+    def forward(self, x, residual=None):
+        assert self.elementwise_affine and len(self.normalized_shape) == 1 and abs(self.eps - 1e-5) < 1e-12
+        return ops.layer_norm(x, self.weight, self.bias, residual)
+
+
+def _make_norm(norm_layer, dim):
+    return HSLayerNorm(dim) if norm_layer is nn.LayerNorm else norm_layer(dim)
+
+
+def _norm_plus(norm, x, residual):
+    """residual + norm(x): one fused kernel for the HIP LayerNorm, two steps for foreign norm layers."""
+    if isinstance(norm, HSLayerNorm):
+        return norm(x, residual=residual)
+    return residual + norm(x)
+
+
+class HSLinear(nn.Linear):
+    """fp32 master weights, GEMM in the activation dtype (library GEMM)."""
+
+    def forward(self, x):
+        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
+        b = self.bias
+        if b is not None and b.dtype != x.dtype:
+            b = b.to(x.dtype)
+        return F.linear(x, w, b)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (the reference imports timm's; identity when p == 0 or in eval)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
+        return x * (mask / keep)
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU(erf) -> drop -> fc2 -> drop (ref :21-44)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = HSLinear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = HSLinear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+# ----------------------------------------------------------------------------- attention
+def _labels_from_dense_mask(mask):
+    """Recover per-position region labels from a {0, x} [nW, Ws, Ws] mask built by get_attn_mask_from_mask."""
+    m = mask.detach().cpu()
+    nW, Ws, _ = m.shape
+    same = m == 0
+    labels = same.to(torch.uint8).argmax(dim=2).to(torch.uint8)  # first position in the same region
+    rebuilt = (labels[:, :, None] != labels[:, None, :]).to(m.dtype) * (-100)
+    if not torch.equal(rebuilt.to(torch.float32), m.to(torch.float32)):
+        raise NotImplementedError("WindowAttention mask is not a {0,-100} region mask; dense masks are not supported")
+    return labels.reshape(-1).contiguous()
+
+
+class WindowAttention(nn.Module):
+    """Window multi-head self-attention with relative position bias (ref :47-174)."""
+
+    def __init__(self, dim, window_size, num_heads, rel_pos_bias=None, qkv_bias=True, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, use_cos_attn=False):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        self.use_cos_attn = use_cos_attn
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.rel_pos_bias = rel_pos_bias
+        if use_cos_attn:  # ref :84-87
+            self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((num_heads, 1, 1))), requires_grad=True)
+        if rel_pos_bias == "flat":  # ref :89-114; the table starts at zero (:92-96, :121)
+            side = int(round(window_size ** 0.5))
+            self.relative_position_bias_table = nn.Parameter(torch.zeros(((2 * side - 1) ** 2, num_heads)))
+            rel = _lib.rel_pos_index(window_size)
+            self.register_buffer("relative_position_index", torch.from_numpy(rel))
+            self.register_buffer("_rel_idx32", torch.from_numpy(rel.astype(np.int32).reshape(-1)), persistent=False)
+        self.qkv = HSLinear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = HSLinear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def extra_repr(self):
+        return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
+
+    def head_scale(self):
+        """Per-head multiplier of the raw scores: exp(min(logit_scale, ln 100)) (ref :144-147) or the qk scale."""
+        if self.use_cos_attn:
+            return torch.exp(torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01))).reshape(-1)
+        return torch.full((self.num_heads,), float(self.scale), dtype=torch.float32, device=self.qkv.weight.device)
+
+    def bias(self):
+        if self.rel_pos_bias is None:
+            return None
+        return ops.RelPosBiasFn.apply(self.relative_position_bias_table, self._rel_idx32, self.window_size)
+
+    def attend(self, x, window_size, idx, roll, labels):
+        """x: [B, N, C] in natural order -> attention branch output [B, N, C] in natural order."""
+        if self.training and self.attn_drop.p > 0.0:
+            raise NotImplementedError("attn_drop_rate > 0 in training mode is not implemented in the fused attention kernel")
+        if self.rel_pos_bias is not None and window_size != self.window_size:
+            raise AssertionError("relative position bias needs input_resolution >= window_size")  # ref quirk :243-251
+        qkv = self.qkv(x)
+        o = ops.window_attn_core(qkv, self.bias(), self.head_scale(), idx, roll, labels, self.num_heads, window_size,
+                                 self.use_cos_attn)
+        return self.proj_drop(self.proj(o))
+
+    def forward(self, x, mask=None):
+        """Reference-compatible entry: x [num_windows*B, Ws, C], mask [nW, Ws, Ws] in {0,-100} or None."""
+        B_, Ws, C = x.shape
+        if mask is None:
+            return self.attend(x.reshape(1, B_ * Ws, C), Ws, None, 0, None).reshape(B_, Ws, C)
+        nW = mask.shape[0]
+        labels = _labels_from_dense_mask(mask).to(x.device)
+        return self.attend(x.reshape(B_ // nW, nW * Ws, C), Ws, None, 0, labels).reshape(B_, Ws, C)
+
+
+class SwinTransformerBlock(nn.Module):
+    """One (shifted-)window block (ref :193-340)."""
+
+    def __init__(self, dim, input_resolution, base_pix, num_heads, window_size=4, shift_size=0, shift_strategy="nest_roll",
+                 rel_pos_bias=None, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, use_v2_norm_placement=False, use_cos_attn=False):
+        super().__init__()
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size, self.mlp_ratio = window_size, shift_size, mlp_ratio
+        self.use_v2_norm_placement = use_v2_norm_placement
+        if input_resolution <= window_size:  # a single window: no partition, no shift (ref :243-246)
+            self.shift_size, self.window_size = 0, input_resolution
+
+        self.norm1 = _make_norm(norm_layer, dim)
+        # as in the reference the attention module is built with the UNclamped window_size (ref :249-251)
+        self.attn = WindowAttention(dim, window_size=window_size, num_heads=num_heads, rel_pos_bias=rel_pos_bias,
+                                    qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop,
+                                    use_cos_attn=use_cos_attn)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = _make_norm(norm_layer, dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+        nside = math.sqrt(input_resolution // base_pix)
+        assert nside % 1 == 0, "nside has to be an integer in every layer"
+        nside = int(nside)
+        if self.shift_size > 0:
+            if shift_strategy == "nest_roll":
+                self.shifter = hp_shifting.NestRollShift(self.shift_size, self.input_resolution, self.window_size)
+            elif shift_strategy == "nest_grid_shift":
+                self.shifter = hp_shifting.NestGridShift(nside, base_pix, self.window_size)
+            elif shift_strategy == "ring_shift":
+                self.shifter = hp_shifting.RingShift(nside, base_pix, self.window_size, self.shift_size)
+            else:
+                raise KeyError(shift_strategy)
+        else:
+            self.shifter = hp_shifting.NoShift()
+        self._is_roll = isinstance(self.shifter, hp_shifting.NestRollShift)
+        self._shifted = self.shift_size > 0
+
+        # reference keeps a dense [nW, Ws, Ws] `attn_mask` buffer in the state dict (:306-308); here it is
+        # virtual: emitted by state_dict(), accepted (and dropped) by load_state_dict().
+        self.register_buffer("attn_mask", None)
+        self._register_state_dict_hook(SwinTransformerBlock._emit_attn_mask)
+        self._register_load_state_dict_pre_hook(self._accept_attn_mask, with_module=False)
+
+    @staticmethod
+    def _emit_attn_mask(module, state_dict, prefix, local_metadata):
+        if EMIT_REFERENCE_BUFFERS and module._shifted:
+            state_dict[prefix + "attn_mask"] = module.shifter.get_mask()
+
+    def _accept_attn_mask(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        state_dict.pop(prefix + "attn_mask", None)
+
+    def extra_repr(self):
+        return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "
+                f"window_size={self.window_size}, shift_size={self.shift_size}, mlp_ratio={self.mlp_ratio}")
+
+    def _attention_branch(self, x):
+        if not self._shifted:
+            return self.attn.attend(x, self.window_size, None, 0, None)
+        idx, _, labels = self.shifter.tables(x.device)
+        if self._is_roll:  # modular offset instead of a table
+            return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels)
+        return self.attn.attend(x, self.window_size, idx, 0, labels)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        assert N == self.input_resolution, f"expected {self.input_resolution} tokens, got {N}"
+        plain_path = isinstance(self.drop_path, nn.Identity) or not self.training
+        if self.use_v2_norm_placement:  # ref :334-335
+            a = self._attention_branch(x)
+            x = _norm_plus(self.norm1, a, x) if plain_path else x + self.drop_path(self.norm1(a))
+            m = self.mlp(x)
+            return _norm_plus(self.norm2, m, x) if plain_path else x + self.drop_path(self.norm2(m))
+        # ref :315-316, :337-338
+        x = x + self.drop_path(self._attention_branch(self.norm1(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+# ----------------------------------------------------------------------------- resolution changes
+class PatchMerging(nn.Module):
+    """4 sibling pixels (consecutive in nested order) -> one token: view [B, N/4, 4C] -> LN(4C) -> Linear(4C -> 2C)
+    (ref :364-395; the strided slices + cat there are exactly this view)."""
+
+    def __init__(self, dim, dim_scale=2, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = HSLinear(4 * dim, dim_scale * dim, bias=False)
+        self.norm = _make_norm(norm_layer, 4 * dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        assert N % 4 == 0, f"x size {N} is not divisible by 4 as necessary for patching."
+        return self.reduction(self.norm(x.reshape(B, N // 4, 4 * C)))
+
+
+class PatchExpand(nn.Module):
+    """Linear(C -> 2C) then every token becomes 4 children of C/2 channels, LN over each child (ref :407-430)."""
+
+    def __init__(self, dim, dim_scale=2, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.expand = HSLinear(dim, dim_scale * dim, bias=False) if dim_scale != 1 else nn.Identity()
+        self.norm = _make_norm(norm_layer, dim * dim_scale // 4)
+
+    def forward(self, x):
+        x = self.expand(x)
+        B, N, C = x.shape
+        return self.norm(x.reshape(B, N * 4, C // 4))  # 'b n (p c) -> b (n p) c' is a view in nested order
+
+
+class FinalPatchExpand_X4(nn.Module):
+    """Linear(C -> p*C), p children per token, LN(C) (ref :433-452)."""
+
+    def __init__(self, patch_size, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim, self.patch_size, self.output_dim = dim, patch_size, dim
+        self.expand = HSLinear(dim, patch_size * dim, bias=False)
+        self.norm = _make_norm(norm_layer, dim)
+
+    def forward(self, x):
+        x = self.expand(x)
+        B, N, C = x.shape
+        return self.norm(x.reshape(B, N * self.patch_size, C // self.patch_size))
+
+
+# ----------------------------------------------------------------------------- stages
+def _build_blocks(dim, input_resolution, depth, num_heads, window_size, base_pix, shift_size, shift_strategy, rel_pos_bias,
+                  mlp_ratio, qkv_bias, qk_scale, drop, attn_drop, drop_path, norm_layer, use_v2_norm_placement, use_cos_attn):
+    return nn.ModuleList([
+        SwinTransformerBlock(dim=dim, input_resolution=input_resolution, base_pix=base_pix, num_heads=num_heads,
+                             window_size=window_size, shift_size=shift_size if i % 2 else 0,  # odd blocks shifted (ref :516)
+                             shift_strategy=shift_strategy, rel_pos_bias=rel_pos_bias, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                             qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                             drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path, norm_layer=norm_layer,
+                             use_v2_norm_placement=use_v2_norm_placement, use_cos_attn=use_cos_attn)
+        for i in range(depth)
+    ])
+
+
+class _Stage(nn.Module):
+    def _run_blocks(self, x):
+        for blk in self.blocks:
+            x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
+        return x
+
+    def extra_repr(self):
+        return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"
+
+
+class BasicLayer(_Stage):
+    """Encoder stage: blocks + optional PatchMerging (ref :455-547)."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, base_pix, shift_size, shift_strategy, rel_pos_bias,
+                 mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm,
+                 downsample=None, use_checkpoint=False, use_v2_norm_placement=False, use_cos_attn=False):
+        super().__init__()
+        self.dim, self.input_resolution, self.depth, self.use_checkpoint = dim, input_resolution, depth, use_checkpoint
+        self.blocks = _build_blocks(dim, input_resolution, depth, num_heads, window_size, base_pix, shift_size, shift_strategy,
+                                    rel_pos_bias, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop, drop_path, norm_layer,
+                                    use_v2_norm_placement, use_cos_attn)
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        x = self._run_blocks(x)
+        return x if self.downsample is None else self.downsample(x)
+
+
+class BasicLayer_up(_Stage):
+    """Decoder stage: blocks + optional PatchExpand (ref :561-653)."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, base_pix, shift_size, shift_strategy, rel_pos_bias,
+                 mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm,
+                 upsample=None, use_checkpoint=False, use_v2_norm_placement=False, use_cos_attn=False):
+        super().__init__()
+        self.dim, self.input_resolution, self.depth, self.use_checkpoint = dim, input_resolution, depth, use_checkpoint
+        self.blocks = _build_blocks(dim, input_resolution, depth, num_heads, window_size, base_pix, shift_size, shift_strategy,
+                                    rel_pos_bias, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop, drop_path, norm_layer,
+                                    use_v2_norm_placement, use_cos_attn)
+        self.upsample = PatchExpand(dim=dim, dim_scale=2, norm_layer=norm_layer) if upsample is not None else None
+
+    def forward(self, x):
+        x = self._run_blocks(x)
+        return x if self.upsample is None else self.upsample(x)
+
+
+class PatchEmbed(nn.Module):
+    """`patch_size` consecutive nested pixels -> one token (ref :656-694).  The Conv1d(k = s = patch) parameters are kept
+    (state-dict layout [C, f_in, patch]); the arithmetic is a per-patch linear map."""
+
+    def __init__(self, config, data_spec):
+        super().__init__()
+        assert config.patch_size % 4 == 0, "required for valid nside in deeper layers"
+        self.config, self.data_spec = config, data_spec
+        self.num_patches = data_spec.dim_in // config.patch_size
+        self.proj = nn.Conv1d(data_spec.f_in, config.embed_dim, kernel_size=config.patch_size, stride=config.patch_size)
+        # reference quirk (:681-684): the config VALUE is stored, not an instance; only None is usable
+        self.norm = config.patch_embed_norm_layer if config.patch_embed_norm_layer is not None else None
+
+    def forward(self, x):
+        B, C, N = x.shape
+        assert N == self.data_spec.dim_in, f"Input image size ({N}) doesn't match model ({self.data_spec.dim_in})."
+        P = self.config.patch_size
+        patches = x.reshape(B, C, N // P, P).permute(0, 2, 1, 3).reshape(B, N // P, C * P)
+        w = self.proj.weight.reshape(self.proj.weight.shape[0], C * P)
+        x = F.linear(patches, w.to(x.dtype), self.proj.bias.to(x.dtype))
+        return x if self.norm is None else self.norm(x)
+
+
+class UnetDecoder(nn.Module):
+    """Expanding path with skip connections (ref :704-791)."""
+
+    def __init__(self, config, data_spec, dpr):
+        super().__init__()
+        self.config = config
+        L = self.num_layers = len(config.depths)
+        self.num_features = int(config.embed_dim * 2 ** (L - 1))
+        num_patches = data_spec.dim_in // config.patch_size
+        self.layers_up = nn.ModuleList()
+        self.concat_back_dim = nn.ModuleList()
+        for i_layer in range(L):
+            down = L - 1 - i_layer
+            width = int(config.embed_dim * 2 ** down)
+            if i_layer == 0:
+                self.concat_back_dim.append(nn.Identity())
+                self.layers_up.append(PatchExpand(dim=width, dim_scale=2, norm_layer=config.norm_layer))
+                continue
+            self.concat_back_dim.append(HSLinear(2 * width, width))
+            lo = sum(config.depths[:down])
+            self.layers_up.append(BasicLayer_up(
+                dim=width, input_resolution=num_patches // (4 ** down), depth=config.depths[down],
+                num_heads=config.num_heads[down], window_size=config.window_size, base_pix=data_spec.base_pix,
+                shift_size=config.shift_size, shift_strategy=config.shift_strategy, rel_pos_bias=config.rel_pos_bias,
+                mlp_ratio=config.mlp_ratio, qkv_bias=config.qkv_bias, qk_scale=config.qk_scale,
+                use_cos_attn=config.use_cos_attn, drop=config.drop_rate, attn_drop=config.attn_drop_rate,
+                drop_path=dpr[lo:lo + config.depths[down]], norm_layer=config.norm_layer,
+                use_v2_norm_placement=config.use_v2_norm_placement, upsample=PatchExpand if down > 0 else None,
+                use_checkpoint=config.use_checkpoint))
+        self.up = FinalPatchExpand_X4(patch_size=config.patch_size, dim=config.embed_dim)
+        self.output = nn.Conv1d(in_channels=config.embed_dim, out_channels=data_spec.f_out, kernel_size=1, bias=False)
+        self.norm_up = _make_norm(config.norm_layer, config.embed_dim)
+
+    def forward(self, x, x_downsample):
+        dbg = self.config.dev_mode
+        for inx, layer_up in enumerate(self.layers_up):
+            if inx > 0:
+                x = torch.cat([x, x_downsample[self.num_layers - 1 - inx]], -1)
+                x = self.concat_back_dim[inx](x)
+            x = layer_up(x)
+            if dbg:
+                print(f"feature shape after decoder layer {inx}: {x.size()}")
+        x = self.up(self.norm_up(x))  # B, Npix, C
+        w = self.output.weight[:, :, 0]
+        x = F.linear(x, w.to(x.dtype))  # 1x1 conv without bias (ref :756-761)
+        return x.transpose(1, 2)  # B, f_out, Npix
+
+
+@dataclass
+class SwinHPTransformerConfig:
+    """Same 23 fields and defaults as the reference config (ref :794-818)."""
+
+    patch_size: int = 4
+    window_size: int = 4
+    shift_size: int = 2
+    shift_strategy: Literal["nest_roll", "nest_grid_shift", "ring_shift"] = "nest_roll"
+    rel_pos_bias: Optional[Literal["flat"]] = None
+    embed_dim: int = 96
+    patch_embed_norm_layer: Optional[Literal[nn.LayerNorm]] = None
+    depths: List[int] = field(default_factory=lambda: [2, 2, 2, 2])
+    num_heads: List[int] = field(default_factory=lambda: [3, 6, 12, 24])
+    mlp_ratio: float = 4.0
+    qkv_bias: bool = True
+    qk_scale: Optional[float] = None
+    use_cos_attn: bool = False
+    drop_rate: float = 0.0
+    attn_drop_rate: float = 0.0
+    drop_path_rate: float = 0.1
+    norm_layer: Literal[nn.LayerNorm] = nn.LayerNorm
+    use_v2_norm_placement: bool = False
+    ape: bool = False
+    patch_norm: bool = True
+    use_checkpoint: bool = False
+    dev_mode: bool = False
+    decoder_class: Literal[UnetDecoder] = UnetDecoder
+
+
+class SwinHPTransformerSys(nn.Module):
+    """HEAL-SWIN-UNet: forward(x[B, f_in, Npix]) -> [B, f_out, Npix] (ref :821-955)."""
+
+    def __init__(self, config: SwinHPTransformerConfig, data_spec: DataSpec, **kwargs):
+        super().__init__()
+        self.config, self.data_spec = config, data_spec
+        L = self.num_layers = len(config.depths)
+        self.num_features = int(config.embed_dim * 2 ** (L - 1))
+        self.num_features_up = int(config.embed_dim * 2)
+        self.compute_dtype = kwargs.pop("compute_dtype", None)  # None: follow autocast, else the input dtype
+
+        self.patch_embed = PatchEmbed(config, data_spec=data_spec)
+        num_patches = self.patch_embed.num_patches
+        if config.ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, num_patches, config.embed_dim))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=0.02)
+        self.pos_drop = nn.Dropout(p=config.drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, config.drop_path_rate, sum(config.depths))]  # ref :871-873
+
+        self.layers = nn.ModuleList()
+        for i in range(L):
+            lo = sum(config.depths[:i])
+            self.layers.append(BasicLayer(
+                dim=int(config.embed_dim * 2 ** i), input_resolution=num_patches // (4 ** i), depth=config.depths[i],
+                num_heads=config.num_heads[i], window_size=config.window_size, base_pix=data_spec.base_pix,
+                shift_size=config.shift_size, shift_strategy=config.shift_strategy, rel_pos_bias=config.rel_pos_bias,
+                mlp_ratio=config.mlp_ratio, qkv_bias=config.qkv_bias, qk_scale=config.qk_scale,
+                use_cos_attn=config.use_cos_attn, drop=config.drop_rate, attn_drop=config.attn_drop_rate,
+                drop_path=dpr[lo:lo + config.depths[i]], norm_layer=config.norm_layer,
+                use_v2_norm_placement=config.use_v2_norm_placement,
+                downsample=PatchMerging if i < L - 1 else None, use_checkpoint=config.use_checkpoint))
+        self.decoder = config.decoder_class(config, data_spec, dpr)
+        self.norm = _make_norm(config.norm_layer, self.num_features)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):  # ref :912-919 (Conv1d layers keep the torch default init)
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"absolute_pos_embed"}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {"relative_position_bias_table"}
+
+    def _activation_dtype(self, x):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled():
+            return torch.get_autocast_gpu_dtype()
+        return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        if self.config.ape:
+            x = x + self.absolute_pos_embed.to(x.dtype)
+        x = self.pos_drop(x)
+        x_downsample = []
+        for k, layer in enumerate(self.layers):
+            x_downsample.append(x)  # the INPUT of encoder stage k is the skip tensor (ref :939-941)
+            x = layer(x)
+            if self.config.dev_mode:
+                print(f"feature shape after basic layer {k}: {x.size()}")
+        return self.norm(x), x_downsample
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("SwinHPTransformerSys (heal_swin_amd) runs only on an MI355X (HIP) device; there is no CPU path")
+        dt = self._activation_dtype(x)
+        with torch.autocast(device_type="cuda", enabled=False):
+            x, x_downsample = self.forward_features(x.to(dt))
+            return self.decoder(x, x_downsample)

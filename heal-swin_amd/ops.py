@@ -1,0 +1,175 @@
+"""torch.autograd.Function wrappers around the C ABI of libhealswin.so.
+
+PyTorch owns the memory (caching allocator), the stream and the autograd graph; every arithmetic step
+below runs in the HIP library.  All ops require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "heal_swin_amd ops run only on an MI355X (HIP) device: got a CPU tensor. "
+                "There is no CPU fallback; move the model and inputs to 'cuda'."
+            )
+
+
+def _f32(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+# ----------------------------------------------------------------------------- rel-pos bias
+class RelPosBiasFn(torch.autograd.Function):
+    """bias[h,i,j] = table[rel_idx[i,j], h]   (reference swin_hp_transformer.py:152-159)"""
+
+    @staticmethod
+    def forward(ctx, table, rel_idx, window_size):
+        _require_gpu(table, rel_idx)
+        assert rel_idx.dtype == torch.int32 and rel_idx.is_contiguous()
+        t = _f32(table)
+        rows, nh = t.shape
+        bias = torch.empty((nh, window_size, window_size), dtype=torch.float32, device=t.device)
+        check(lib.hs_rel_bias_gather(ptr(t), ptr(rel_idx), ptr(bias), rows, nh, window_size, stream_ptr(t.device)),
+              "hs_rel_bias_gather")
+        ctx.save_for_backward(rel_idx)
+        ctx.shape = (rows, nh, window_size)
+        ctx.table_dtype = table.dtype
+        return bias
+
+    @staticmethod
+    def backward(ctx, dbias):
+        (rel_idx,) = ctx.saved_tensors
+        rows, nh, ws = ctx.shape
+        dbias = dbias.to(torch.float32).contiguous()
+        dtable = torch.empty((rows, nh), dtype=torch.float32, device=dbias.device)
+        check(lib.hs_rel_bias_scatter_grad(ptr(dbias), ptr(rel_idx), ptr(dtable), rows, nh, ws, stream_ptr(dbias.device)),
+              "hs_rel_bias_scatter_grad")
+        return dtable.to(ctx.table_dtype), None, None
+
+
+# ----------------------------------------------------------------------------- fused shift + window attention
+class WindowAttnCoreFn(torch.autograd.Function):
+    """shift -> window_partition -> (cos|scaled) QK^T + bias + mask -> softmax -> @V -> window_reverse -> shift_back
+    on the un-shifted qkv tensor (reference swin_hp_transformer.py:319-330 around :136-171)."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine):
+        _require_gpu(qkv, bias, head_scale, idx, labels)
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        qkv = qkv.contiguous()
+        dt = _lib.dtype_code(qkv.dtype)
+        hs = _f32(head_scale).reshape(-1)
+        assert hs.numel() == num_heads
+        bias_c = _f32(bias)
+        out = torch.empty((B, N, C), dtype=qkv.dtype, device=qkv.device)
+        need_grad = any(ctx.needs_input_grad[:3])
+        lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=qkv.device) if need_grad else None
+        flags = _lib.HS_ATTN_COSINE if cosine else 0
+        check(lib.hs_window_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(bias_c), ptr(hs), ptr(idx), int(roll), ptr(labels),
+                                     B, N, C, num_heads, window_size, flags, dt, stream_ptr(qkv.device)),
+              "hs_window_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse, bias_c, hs, idx, labels)
+        ctx.args = (B, N, C, num_heads, window_size, flags, dt, int(roll))
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        ctx.scale_meta = (head_scale.dtype, head_scale.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, bias_c, hs, idx, labels = ctx.saved_tensors
+        B, N, C, nh, ws, flags, dt, roll = ctx.args
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.zeros_like(bias_c) if bias_c is not None else None
+        dscale = torch.zeros_like(hs)
+        check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale),
+                                     ptr(bias_c), ptr(hs), ptr(idx), roll, ptr(labels),
+                                     B, N, C, nh, ws, flags, dt, stream_ptr(qkv.device)),
+              "hs_window_attn_bwd")
+        dbias_out = None if dbias is None else dbias.to(ctx.bias_dtype)
+        sdt, sshape = ctx.scale_meta
+        dscale_out = dscale.to(sdt).reshape(sshape) if (flags & _lib.HS_ATTN_COSINE) else None
+        return dqkv, dbias_out, dscale_out, None, None, None, None, None, None
+
+
+def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine):
+    return WindowAttnCoreFn.apply(qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine)
+
+
+# ----------------------------------------------------------------------------- row LayerNorm (+ residual)
+class LayerNormFn(torch.autograd.Function):
+    """y = [residual +] LayerNorm(x) over the last dimension (eps 1e-5), statistics in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        _require_gpu(x, weight, bias, residual)
+        x = x.contiguous()
+        width = x.shape[-1]
+        rows = x.numel() // width
+        dt = _lib.dtype_code(x.dtype)
+        g, b = _f32(weight), _f32(bias)
+        res = None if residual is None else residual.contiguous()
+        if res is not None:
+            assert res.shape == x.shape and res.dtype == x.dtype
+        y = torch.empty_like(x)
+        need_grad = any(ctx.needs_input_grad[:3])
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        check(lib.hs_layernorm_fwd(ptr(x), ptr(res), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, width, dt,
+                                   stream_ptr(x.device)), "hs_layernorm_fwd")
+        ctx.save_for_backward(x, g, mean, rstd)
+        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        rows, width, dt, wdt, bdt, has_res = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(width, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(width, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=x.device)
+        check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                   rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
+        return dx, dgamma.to(wdt), dbeta.to(bdt), (dy if has_res else None)
+
+
+def layer_norm(x, weight, bias, residual=None):
+    return LayerNormFn.apply(x, weight, bias, residual)
+
+
+# ----------------------------------------------------------------------------- standalone shift (gather rows)
+class GatherRowsFn(torch.autograd.Function):
+    """out[:, j] = x[:, idx[j]]  (or roll); backward gathers with the inverse table."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv, roll):
+        _require_gpu(x, idx, inv)
+        x = x.contiguous()
+        B, N = x.shape[0], x.shape[1]
+        row_bytes = (x.numel() // (B * N)) * x.element_size()
+        out = torch.empty_like(x)
+        check(lib.hs_gather_rows(ptr(x), ptr(out), ptr(idx), int(roll), B, N, row_bytes, stream_ptr(x.device)), "hs_gather_rows")
+        ctx.save_for_backward(idx, inv)
+        ctx.meta = (B, N, row_bytes, int(roll))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, inv = ctx.saved_tensors
+        B, N, row_bytes, roll = ctx.meta
+        dout = dout.contiguous()
+        dx = torch.empty_like(dout)
+        back_roll = (N - roll) % N
+        check(lib.hs_gather_rows(ptr(dout), ptr(dx), ptr(inv), back_roll, B, N, row_bytes, stream_ptr(dout.device)), "hs_gather_rows")
+        return dx, None, None, None
+
+
+def gather_rows(x, idx=None, inv=None, roll=0):
+    return GatherRowsFn.apply(x, idx, inv, roll)

@@ -1,0 +1,13 @@
+"""Import alias.  The package directory is `heal-swin_amd/` (repo layout); a hyphen is not a valid Python
+identifier, so `import heal_swin_amd` loads that directory as the package `heal_swin_amd`."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "heal-swin_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir]
+)
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,178 @@
+/*
+ * healswin.h -- C ABI of the MI355X-native HEAL-SWIN hot path (libhealswin.so).
+ *
+ * The reference (JanEGerken/HEAL-SWIN) is pure Python/PyTorch and has no FFI of its own; these are the
+ * entry points a maintainer would bind (ctypes) to replace the stock-op call
+ * sites of heal_swin/models_torch/{hp_windowing,hp_shifting,swin_hp_transformer}.py.  Each entry
+ * point cites the reference interface it replaces as `file:line` relative to /root/reference/heal_swin/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  Device pointers are marked [dev], host [host].
+ *   - every function returns an hs_status (0 = ok); nothing throws across the ABI.
+ *   - kernels never allocate or free; all buffers (outputs, workspaces) are owned by the caller.
+ *   - device functions are stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and re-entrant (activation-checkpoint recompute calls them twice).
+ *   - activations are row-major [B, N, C] ("token rows"), dtype HS_F32 or HS_BF16; statistics,
+ *     softmax, bias and all accumulations are fp32 in both modes.
+ *   - "natural order" = the reference's nested HEALPix pixel order; "shifted order" = after
+ *     shifter.shift().  Window w of an image covers shifted positions [w*Ws, (w+1)*Ws).
+ */
+#ifndef HEALSWIN_H
+#define HEALSWIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    HS_OK = 0,
+    HS_ERR_INVALID_ARG = 1,   /* reference: bare `assert` at construction / call time */
+    HS_ERR_UNSUPPORTED = 2,   /* shape/dtype outside what the kernels implement */
+    HS_ERR_HIP = 3,           /* a HIP runtime call failed (no device, launch failure); see hs_last_error */
+    HS_ERR_NOT_PERMUTATION = 4 /* reference: _validate_shift_result, models_torch/hp_shifting.py:96-99,385-388 */
+} hs_status;
+
+typedef enum { HS_F32 = 0, HS_BF16 = 1 } hs_dtype;
+
+/* flags of hs_window_attn_* */
+#define HS_ATTN_COSINE 1u      /* cosine attention: L2-normalise q,k (eps 1e-12), per-head scale */
+
+const char* hs_version(void);
+/* human-readable message of the last failing call on this thread ("" if none) */
+const char* hs_last_error(void);
+const char* hs_status_string(int status);
+/* number of visible HIP devices (0 on a CPU-only host); never fails */
+int hs_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side HEALPix index tables, built once per model on the host (plain C++, no GPU needed).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* healpy.pixelfunc.nest2ring / ring2nest as called at models_torch/hp_shifting.py:333 / :329.
+ * nside must be a power of two; indices in [0, 12*nside^2).  in/out [host], n entries. */
+int hs_nest2ring(int nside, const int64_t* in, int64_t* out, int64_t n);
+int hs_ring2nest(int nside, const int64_t* in, int64_t* out, int64_t n);
+
+/* get_nest_win_idcs, models_torch/hp_windowing.py:43-62.  out [host] int64[side*side], row-major. */
+int hs_nest_win_idcs(int window_size, int64_t* out);
+
+/* relative_position_index of WindowAttention.__init__, models_torch/swin_hp_transformer.py:98-114.
+ * out [host] int64[Ws*Ws]. */
+int hs_rel_pos_index(int window_size, int64_t* out);
+
+/* Shifters.  All three fill
+ *   idx    int32[N]  shift(x)[:, j]      = x[:, idx[j]]     (.shift)
+ *   inv    int32[N]  shift_back(y)[:, i] = y[:, inv[i]]     (.shift_back), inv = idx^-1
+ *   labels uint8[N]  region label of shifted position j; attention inside a window is masked with
+ *                    -100 where labels differ (get_attn_mask_from_mask, models_torch/hp_shifting.py:10-28)
+ * any of the three output pointers may be NULL.  N = n_pix (roll) or base_pix*nside^2 (grid, ring). */
+
+/* NestRollShift, models_torch/hp_shifting.py:42-73 (valid for any base_pix). */
+int hs_build_nest_roll_shift(int64_t n_pix, int window_size, int shift_size,
+                             int32_t* idx, int32_t* inv, uint8_t* labels);
+/* NestGridShift, models_torch/hp_shifting.py:76-306 (base_pix must be 8, as the reference asserts :78). */
+int hs_build_nest_grid_shift(int nside, int base_pix, int window_size,
+                             int32_t* idx, int32_t* inv, uint8_t* labels);
+/* RingShift, models_torch/hp_shifting.py:309-404 (only valid for base_pix == 8, like the reference). */
+int hs_build_ring_shift(int nside, int base_pix, int window_size, int shift_size,
+                        int32_t* idx, int32_t* inv, uint8_t* labels);
+
+/* get_attn_mask_from_mask, models_torch/hp_shifting.py:10-28: out [host] float[nW*Ws*Ws] in {0,-100}.
+ * Only needed to emit the reference's `attn_mask` state-dict buffer; the kernels read `labels`. */
+int hs_attn_mask_from_labels(const uint8_t* labels, int64_t n, int window_size, float* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Relative-position bias: table[rel_idx] gather and its gradient.
+ * Replaces models_torch/swin_hp_transformer.py:152-159 (relative_position_bias_table[index].permute(2,0,1)).
+ * ---------------------------------------------------------------------------------------------- */
+/* bias[h, i, j] = table[rel_idx[i, j], h].  table [dev] f32[T, nH]; rel_idx [dev] int32[Ws*Ws];
+ * bias [dev] f32[nH, Ws, Ws]. */
+int hs_rel_bias_gather(const float* table, const int32_t* rel_idx, float* bias,
+                       int table_rows, int num_heads, int window_size, void* stream);
+/* dtable[t, h] = sum over (i,j) with rel_idx[i,j] == t of dbias[h, i, j]   (dtable is overwritten). */
+int hs_rel_bias_scatter_grad(const float* dbias, const int32_t* rel_idx, float* dtable,
+                             int table_rows, int num_heads, int window_size, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused  shift -> window_partition -> attention core -> window_reverse -> shift_back.
+ *
+ * Replaces, in one kernel, models_torch/swin_hp_transformer.py:319 (shifter.shift), :322
+ * (window_partition, hp_windowing.py:6-21), :136-171 of WindowAttention.forward (q/k/v split, cosine
+ * or scaled QK^T, + relative position bias, + shift mask, softmax, attn @ v, head merge), :327
+ * (window_reverse, hp_windowing.py:24-40) and :330 (shifter.shift_back).  Row permutations commute
+ * with the row-wise qkv / proj Linear layers, so the kernel gathers rows of the *unshifted* qkv
+ * tensor through `idx` and scatters its output rows back through the same `idx`.
+ *
+ *   qkv    [dev] dtype[B, N, 3C]  output of the qkv Linear in natural order, columns [q|k|v][head][hd]
+ *   out    [dev] dtype[B, N, C]   attention output in natural order, columns [head][hd] (input of proj)
+ *   lse    [dev] f32[B, nH, N]    log-sum-exp of every score row, indexed by SHIFTED position; saved
+ *                                 for the backward pass (may be NULL for inference)
+ *   bias   [dev] f32[nH, Ws, Ws]  or NULL (rel_pos_bias is None)
+ *   head_scale [dev] f32[nH]      cosine: exp(min(logit_scale, ln 100)) (:144-147); else qk scale (:81,:149)
+ *   idx    [dev] int32[N] gather table of the shifter, or NULL: then shifted position j reads token
+ *                         (j + roll) mod N   (roll = 0: NoShift; roll = shift_size: NestRollShift)
+ *   labels [dev] uint8[N] region labels in shifted order, or NULL (no mask; unshifted blocks)
+ *   flags  HS_ATTN_COSINE or 0
+ * Supported: Ws in {4,16,64,256}, Ws <= N, N % Ws == 0, head_dim in {1,2,4,8,16,32,64,128}.
+ * (Ws = 64, head_dim = 32, bf16 takes the MFMA path; everything else the fp32-VALU path.)
+ */
+int hs_window_attn_fwd(const void* qkv, void* out, float* lse,
+                       const float* bias, const float* head_scale,
+                       const int32_t* idx, int64_t roll, const uint8_t* labels,
+                       int batch, int64_t n_tokens, int channels, int num_heads, int window_size,
+                       unsigned flags, int dtype, void* stream);
+
+/* Backward of the above.
+ *   dout   [dev] dtype[B, N, C]   gradient w.r.t. `out`
+ *   dqkv   [dev] dtype[B, N, 3C]  gradient w.r.t. `qkv` (every row is written exactly once)
+ *   dbias  [dev] f32[nH, Ws, Ws]  ACCUMULATED into (caller zeroes it), or NULL when bias is NULL
+ *   dhead_scale [dev] f32[nH]     ACCUMULATED into (caller zeroes it); only written for HS_ATTN_COSINE
+ *                                 (the scaled variant's scale is a constant), may be NULL otherwise
+ */
+int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                       void* dqkv, float* dbias, float* dhead_scale,
+                       const float* bias, const float* head_scale,
+                       const int32_t* idx, int64_t roll, const uint8_t* labels,
+                       int batch, int64_t n_tokens, int channels, int num_heads, int window_size,
+                       unsigned flags, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Standalone shift along the nested pixel axis: out[b, j, :] = x[b, idx[j], :]  (idx NULL: roll,
+ * out[b, j, :] = x[b, (j + roll) mod N, :]).  Replaces shifter.shift / shift_back when called on their
+ * own: models_torch/hp_shifting.py:69-73 (torch.roll), :302-306 and :400-404 (x[:, idcs].contiguous()).
+ * Pass `inv` as idx for shift_back.  Not on the model's path (the permutation is fused into
+ * hs_window_attn_*); used by the shifter API and by the gather/scatter bandwidth measurement.
+ *   x, out [dev] distinct buffers of batch * n_tokens rows of row_bytes bytes each.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_gather_rows(const void* x, void* out, const int32_t* idx, int64_t roll,
+                   int batch, int64_t n_tokens, int64_t row_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row LayerNorm over contiguous rows (eps = 1e-5, affine), optionally fused with a residual add.
+ * This is the normalisation half of PatchMerging (LayerNorm over the 4C row formed by 4 sibling
+ * pixels, models_torch/swin_hp_transformer.py:385-392: the slicing + cat is a free view in nested
+ * order), of PatchExpand / FinalPatchExpand_X4 (LayerNorm over each C/p child row after the
+ * 'b n (p c) -> b (n p) c' view, :427-428, :449-450) and of the block norms (:316, :334-338, :945, :781).
+ *
+ *   y = LN(x) * gamma + beta               (residual == NULL)
+ *   y = residual + LN(x) * gamma + beta    (v2 norm placement, :334-335)
+ *   x, y, residual [dev] dtype[rows, width]; gamma, beta [dev] f32[width];
+ *   mean, rstd [dev] f32[rows] saved for backward (may be NULL for inference).
+ */
+int hs_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta,
+                     void* y, float* mean, float* rstd,
+                     int64_t rows, int width, int dtype, void* stream);
+/* dx [dev] dtype[rows, width]; dgamma, dbeta [dev] f32[width] are OVERWRITTEN (sum over all rows).
+ * The residual branch's gradient is dy itself (identity) and is not produced here.
+ * workspace [dev] f32[hs_layernorm_bwd_workspace(rows, width)] */
+int64_t hs_layernorm_bwd_workspace(int64_t rows, int width);
+int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, float* dgamma, float* dbeta, float* workspace,
+                     int64_t rows, int width, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEALSWIN_H */

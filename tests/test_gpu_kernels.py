@@ -1,0 +1,212 @@
+"""HIP kernels (through the C ABI / autograd ops) vs the oracle and the golden vectors.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import case, state_dict
+from _util import TOL, GRAD_TOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _mods():
+    from heal_swin_amd import ops
+    from heal_swin_amd.models_torch import swin_hp_transformer as M
+    from heal_swin_amd.models_torch import hp_shifting as S
+    return ops, M, S
+
+
+# ----------------------------------------------------------------------------- WindowAttention vs golden
+WA_CASES = [f"{a}_{m}" for a in ("scaled", "cos") for m in ("nomask", "rollmask", "ringmask")]
+
+
+def _run_module(mod, c, fwd, dtype):
+    mod = mod.to(DEV)
+    x = torch.from_numpy(c["x"]).to(DEV).to(dtype).requires_grad_(True)
+    y = fwd(mod, x)
+    assert y.dtype == dtype
+    assert_close(y, c["y"], TOL[dtype], "y")
+    y.backward(torch.from_numpy(c["dy"]).to(DEV).to(dtype))
+    assert_close(x.grad, c["dx"], GRAD_TOL[dtype], "dx")
+    params = dict(mod.named_parameters())
+    for k, g in c["grad"].items():
+        got = params[k].grad
+        got = torch.zeros_like(params[k]) if got is None else got
+        assert_close(got, g, GRAD_TOL[dtype], "grad " + k)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", WA_CASES)
+def test_window_attention_golden(name, dtype):
+    _, M, _ = _mods()
+    c = case("modules", "window_attention/" + name)
+    wa = M.WindowAttention(96, 64, 3, rel_pos_bias="flat", use_cos_attn=name.startswith("cos"))
+    wa.load_state_dict(state_dict(c))
+    mask = torch.from_numpy(c["mask"].astype(np.float32)) if "mask" in c else None
+    _run_module(wa, c, lambda m, x: m(x, mask=mask), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tag,C,nh,ws", [("w16", 16, 2, 16), ("w4", 2, 1, 4)])
+def test_window_attention_plain_golden(tag, C, nh, ws, dtype):
+    _, M, _ = _mods()
+    c = case("modules", "window_attention/plain_" + tag)
+    wa = M.WindowAttention(C, ws, nh, rel_pos_bias=None, qkv_bias=False)
+    wa.load_state_dict(state_dict(c))
+    _run_module(wa, c, lambda m, x: m(x), dtype)
+
+
+# ----------------------------------------------------------------------------- attention core vs oracle, larger / odd shapes
+def _oracle_core(qkv, bias, hscale, idx, labels, nH, Ws, cosine):
+    """oracle formulas for the fused op on CPU fp32 (oracle.model primitives)."""
+    from oracle import model as OM
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // nH
+    xs = qkv if idx is None else qkv[:, idx]
+    t = xs.reshape(B, N // Ws, Ws, 3, nH, hd)
+    q, k, v = (t[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3))  # [B, nW, nH, Ws, hd]
+    if cosine:
+        s = OM.l2_normalize(q) @ OM.l2_normalize(k).transpose(-1, -2)
+    else:
+        s = q @ k.transpose(-1, -2)
+    s = s * hscale.reshape(1, 1, nH, 1, 1)
+    if bias is not None:
+        s = s + bias[None, None]
+    if labels is not None:
+        lab = labels.reshape(N // Ws, Ws)
+        s = s + ((lab[:, :, None] != lab[:, None, :]).float() * -100.0)[None, :, None]
+    o = (OM.softmax_lastdim(s) @ v).permute(0, 1, 3, 2, 4).reshape(B, N, C)
+    if idx is not None:
+        inv = torch.empty_like(idx)
+        inv[idx] = torch.arange(N)
+        o = o[:, inv]
+    return o
+
+
+CORE_CASES = [
+    # B, nside, C, nH, Ws, strategy, shift, cosine, bias
+    (2, 16, 96, 3, 64, "ring_shift", 4, True, True),
+    (2, 16, 128, 4, 64, "nest_roll", 32, False, True),
+    (1, 16, 64, 2, 64, "nest_grid_shift", 32, False, False),
+    (3, 8, 48, 3, 16, "nest_roll", 8, True, True),
+    (2, 8, 24, 3, 16, "none", 0, False, True),
+    (1, 8, 40, 5, 4, "ring_shift", 2, True, False),
+    (1, 16, 32, 1, 256, "nest_roll", 128, False, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,nside,C,nH,Ws,strategy,shift,cosine,use_bias", CORE_CASES)
+def test_attn_core_vs_oracle(B, nside, C, nH, Ws, strategy, shift, cosine, use_bias, dtype):
+    ops, _, _ = _mods()
+    from oracle import tables as T
+    N = 8 * nside * nside
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn(B, N, 3 * C, generator=g)
+    bias = torch.randn(nH, Ws, Ws, generator=g) if use_bias else None
+    hscale = torch.rand(nH, generator=g) * (8 if cosine else 0.3) + 0.1
+    dout = torch.randn(B, N, C, generator=g)
+    if strategy == "none":
+        idx = labels = None
+    else:
+        fn = {"nest_roll": lambda: T.nest_roll_shift(N, Ws, shift), "nest_grid_shift": lambda: T.nest_grid_shift(nside, 8, Ws),
+              "ring_shift": lambda: T.ring_shift(nside, 8, Ws, shift)}[strategy]
+        idx_np, _, lab_np = fn()
+        idx, labels = torch.from_numpy(idx_np), torch.from_numpy(lab_np)
+
+    # oracle on the values the kernel actually sees (inputs rounded to the activation dtype)
+    qkv_r = qkv.to(dtype).float().requires_grad_(True)
+    bias_r = None if bias is None else bias.clone().requires_grad_(True)
+    hs_r = hscale.clone().requires_grad_(True)
+    o_ref = _oracle_core(qkv_r, bias_r, hs_r, idx, labels, nH, Ws, cosine)
+    o_ref.backward(dout.to(dtype).float())
+
+    qkv_d = qkv.to(DEV).to(dtype).requires_grad_(True)
+    bias_d = None if bias is None else bias.to(DEV).requires_grad_(True)
+    hs_d = hscale.to(DEV).requires_grad_(True)
+    idx_d = None if idx is None else idx.to(torch.int32).to(DEV)
+    lab_d = None if labels is None else labels.to(torch.uint8).to(DEV)
+    use_roll = strategy == "nest_roll"
+    o = ops.window_attn_core(qkv_d, bias_d, hs_d, None if use_roll else idx_d, shift if use_roll else 0, lab_d, nH, Ws, cosine)
+    assert_close(o, o_ref, TOL[dtype], "out")
+    o.backward(dout.to(DEV).to(dtype))
+    assert_close(qkv_d.grad, qkv_r.grad, GRAD_TOL[dtype], "dqkv")
+    if bias is not None:
+        assert_close(bias_d.grad, bias_r.grad, GRAD_TOL[dtype], "dbias")
+    if cosine:
+        assert_close(hs_d.grad, hs_r.grad, GRAD_TOL[dtype], "dhead_scale")
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,width", [(7, 2), (130, 16), (1000, 96), (513, 128), (300, 384), (64, 1536), (33, 2048), (50, 100)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_layernorm_vs_oracle(rows, width, residual, dtype):
+    ops, _, _ = _mods()
+    from oracle import model as OM
+    g = torch.Generator().manual_seed(rows * 31 + width)
+    x = (torch.randn(rows, width, generator=g) * 3 + 1.5)
+    w = 1 + 0.3 * torch.randn(width, generator=g)
+    b = 0.2 * torch.randn(width, generator=g)
+    r = torch.randn(rows, width, generator=g) if residual else None
+    dy = torch.randn(rows, width, generator=g)
+
+    xr = x.to(dtype).float().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = None if r is None else r.to(dtype).float().requires_grad_(True)
+    y_ref = OM.layer_norm(xr, wr, br) + (0 if rr is None else rr)
+    y_ref.backward(dy.to(dtype).float())
+
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rd = None if r is None else r.to(DEV).to(dtype).requires_grad_(True)
+    y = ops.layer_norm(xd, wd, bd, rd)
+    assert_close(y, y_ref, TOL[dtype], "y")
+    y.backward(dy.to(DEV).to(dtype))
+    assert_close(xd.grad, xr.grad, GRAD_TOL[dtype], "dx")
+    assert_close(wd.grad, wr.grad, GRAD_TOL[dtype], "dgamma")
+    assert_close(bd.grad, br.grad, GRAD_TOL[dtype], "dbeta")
+    if residual:
+        assert_close(rd.grad, rr.grad, GRAD_TOL[dtype], "dres")
+
+
+# ----------------------------------------------------------------------------- shifters (standalone gather) bit-exact
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.uint8])
+def test_shifters_bit_exact(dtype):
+    _, _, S = _mods()
+    from oracle import tables as T
+    nside, ws = 16, 16
+    N = 8 * nside * nside
+    x = torch.arange(2 * N * 6).reshape(2, N, 6).to(dtype).to(DEV)
+    cases = [
+        (S.NestRollShift(8, N, ws), T.nest_roll_shift(N, ws, 8)),
+        (S.NestGridShift(nside, 8, ws), T.nest_grid_shift(nside, 8, ws)),
+        (S.RingShift(nside, 8, ws, 4), T.ring_shift(nside, 8, ws, 4)),
+    ]
+    for sh, (idx, inv, lab) in cases:
+        xs = sh.shift(x)
+        assert torch.equal(xs.cpu(), x.cpu()[:, torch.from_numpy(idx)])
+        assert torch.equal(sh.shift_back(xs).cpu(), x.cpu())
+        assert np.array_equal(sh.get_mask(False).numpy().astype(np.int64), lab)
+        assert np.array_equal(sh.get_mask().numpy().astype(np.int64), T.attn_mask_from_labels(lab, ws))
+
+
+def test_gather_rows_autograd():
+    ops, _, S = _mods()
+    sh = S.RingShift(8, 8, 16, 4)
+    x = torch.randn(2, 512, 24, device=DEV, requires_grad=True)
+    y = sh.shift(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    assert torch.equal(x.grad.cpu(), w.cpu()[:, sh.back_shift_idcs])
+
+
+# ----------------------------------------------------------------------------- loud failure without a GPU tensor
+def test_cpu_tensors_are_rejected():
+    ops, _, _ = _mods()
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(torch.randn(4, 8), torch.ones(8), torch.zeros(8))
