@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the HEAL-SWIN hot path (fwd + loss + bwd + gradient exchange + Adam step).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0: BASELINE.json's metric (images/s, whole job), plus
+  roofline      fused shift+window-attention kernels (fwd + bwd launches of the timed steps), algorithmic bytes
+                / measured launch time against the HBM peak (HIP events on the launch stream)
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's forward) timed on this host's cores on a bounded
+                sample of the same model (rank 0, N = 1 only)
+Data is synthetic (uint8-range images, random labels), weights are random-init.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: HEAL-SWIN-B, nside 256, 12 base pixels (full sphere), window 64 (nest_roll: the only
+    # shift valid for 12 base pixels), 12 classes
+    "B256": dict(name="HEAL-SWIN-B nside=256 base_pix=12 window=64 nest_roll(shift 32) seg 12 classes",
+                 nside=256, base_pix=12, f_out=12,
+                 cfg=dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=64, shift_size=32,
+                          shift_strategy="nest_roll", rel_pos_bias="flat")),
+    # the paper's run config (run_configs/segmentation/swin_hp_synwoodscape_large_plus_AD_train_run_config.py:35-96)
+    "T256": dict(name="HEAL-SWIN-T (paper) nside=256 base_pix=8 window=64 ring_shift(4) cos-attn v2-norm seg 12 classes",
+                 nside=256, base_pix=8, f_out=12,
+                 cfg=dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=64, shift_size=4,
+                          shift_strategy="ring_shift", rel_pos_bias="flat", use_cos_attn=True, use_v2_norm_placement=True)),
+    # BASELINE.json configs[1]
+    "T128": dict(name="HEAL-SWIN-T nside=128 base_pix=8 window=64 nest_roll(shift 32) seg 12 classes",
+                 nside=128, base_pix=8, f_out=12,
+                 cfg=dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=64, shift_size=32,
+                          shift_strategy="nest_roll", rel_pos_bias="flat")),
+    # BASELINE.json configs[0] shape (plumbing)
+    "tiny": dict(name="HEAL-SWIN-tiny nside=32 base_pix=4 window=16", nside=32, base_pix=4, f_out=12,
+                 cfg=dict(embed_dim=48, depths=[2, 2, 2], num_heads=[3, 6, 12], window_size=16, shift_size=8,
+                          shift_strategy="nest_roll", rel_pos_bias="flat")),
+}
+
+
+def full_cfg(cfg):
+    base = dict(patch_size=4, window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", embed_dim=96,
+                depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], mlp_ratio=4.0, qkv_bias=True, qk_scale=None, use_cos_attn=False,
+                drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, use_v2_norm_placement=False, ape=False)
+    base.update(cfg)
+    return base
+
+
+def build_model(wl, nside=None):
+    from heal_swin_amd.data_spec import DataSpec
+    from heal_swin_amd.models_torch.swin_hp_transformer import SwinHPTransformerConfig, SwinHPTransformerSys
+
+    nside = nside or wl["nside"]
+    cfg = full_cfg(wl["cfg"])
+    spec = dict(dim_in=wl["base_pix"] * nside * nside, f_in=3, f_out=wl["f_out"], base_pix=wl["base_pix"], class_names=[])
+    torch.manual_seed(0)
+    model = SwinHPTransformerSys(SwinHPTransformerConfig(**cfg), DataSpec(**spec))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("relative_position_bias_table"):
+                p.normal_(0, 0.02)
+    return model, cfg, spec
+
+
+def cpu_baseline(wl, budget_s=20.0):
+    """Times the CPU oracle (forward + CE loss + backward over all parameters) on this host, same model family,
+    on a bounded sample: ONE image at a reduced nside; images/s is rescaled by the pixel ratio (cost is linear in
+    the pixel count for windowed attention)."""
+    from oracle import model as OM  # the checker, used here as the reported CPU baseline ("port")
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    min_nside = 4 * (2 ** (len(wl["cfg"]["depths"]) - 1)) * 2  # keep >= 1 window of 64 tokens at the last stage
+    nside = min(wl["nside"], max(64, min_nside))
+    model, cfg, spec = build_model(wl, nside)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
+          if not k.endswith("attn_mask")}
+    del model
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (1, 3, spec["dim_in"]), generator=g).float()
+    y = torch.randint(0, spec["f_out"], (1, spec["dim_in"]), generator=g)
+    cfg_ns, spec_ns = types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec)
+    times = []
+    t_begin = time.time()
+    while True:
+        t0 = time.time()
+        logits = OM.forward(sd, cfg_ns, spec_ns, x)
+        loss = OM.seg_loss(logits, y)
+        loss.backward()
+        times.append(time.time() - t0)
+        for v in sd.values():
+            v.grad = None
+        if time.time() - t_begin > budget_s or len(times) >= 5:
+            break
+    t = min(times)
+    scale = (wl["nside"] / nside) ** 2
+    return {"value": 1.0 / (t * scale), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+CE+bwd, fp32, 1 image at nside={nside} ({len(times)} iters, best {t:.2f}s), "
+                      f"rescaled x{1 / scale:.4g} to nside={wl['nside']} by pixel count"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="B256", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (weak scaling)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from heal_swin_amd import ops
+    from heal_swin_amd.losses import seg_loss
+    from heal_swin_amd.parallel import GradBucketAllReduce
+
+    wl = WORKLOADS[args.workload]
+    model, cfg, spec = build_model(wl)
+    model = model.to(dev).train()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.compute_dtype = dtype
+    dp = GradBucketAllReduce(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True)  # reference: training/optimizer.py:57-66
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    imgs = torch.randint(0, 256, (args.batch, 3, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
+    labels = torch.randint(0, spec["f_out"], (args.batch, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
+
+    def step():
+        dp.zero_grad()
+        logits = model(imgs.float())  # the caller's `.float()` (model_lightning_swin_hp.py:61)
+        loss = seg_loss(logits, labels)
+        loss.backward()
+        dp.finish()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if not args.no_kernel_timing:
+        ops.KERNEL_TIMINGS = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    timings, ops.KERNEL_TIMINGS = ops.KERNEL_TIMINGS, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec fwd+bwd, HEAL-SWIN nside=256 seg, batch=8 at 1/2/4/8 MI355X",
+            "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
+                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2), "final_loss": loss_val},
+        }
+        if timings:
+            agg = {}
+            for tag, s, e, nbytes, flops in timings:
+                a = agg.setdefault(tag, [0.0, 0, 0, 0])
+                a[0] += s.elapsed_time(e) * 1e-3
+                a[1] += nbytes
+                a[2] += flops
+                a[3] += 1
+            tot_t = sum(a[0] for a in agg.values())
+            tot_b = sum(a[1] for a in agg.values())
+            ach = tot_b / tot_t / 1e9
+            out["roofline"] = {
+                "kernel": "hs_window_attn_fwd+bwd (fused shift/window-partition/attention/reverse)", "bound": "hbm",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "per_kernel": {tag: {"launches": a[3], "avg_us": 1e6 * a[0] / a[3], "GB/s": a[1] / a[0] / 1e9,
+                                     "TFLOP/s": a[2] / a[0] / 1e12} for tag, a in agg.items()},
+                "share_of_step": tot_t / elapsed,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,32 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 
+# Optional live kernel timing (bench.py): when KERNEL_TIMINGS is a list, the attention launches are bracketed
+# with events recorded on the stream the kernel runs on, and (tag, start, end, algorithmic_bytes, flops) is appended.
+KERNEL_TIMINGS = None
+
+
+class _timed:
+    def __init__(self, tag, device, nbytes, flops):
+        self.on = KERNEL_TIMINGS is not None
+        if self.on:
+            self.tag, self.nbytes, self.flops = tag, nbytes, flops
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.stream = torch.cuda.current_stream(device)
+
+    def __enter__(self):
+        if self.on:
+            self.start.record(self.stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.end.record(self.stream)
+            KERNEL_TIMINGS.append((self.tag, self.start, self.end, self.nbytes, self.flops))
+        return False
+
+
 def _require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -70,9 +96,11 @@ class WindowAttnCoreFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:3])
         lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=qkv.device) if need_grad else None
         flags = _lib.HS_ATTN_COSINE if cosine else 0
-        check(lib.hs_window_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(bias_c), ptr(hs), ptr(idx), int(roll), ptr(labels),
-                                     B, N, C, num_heads, window_size, flags, dt, stream_ptr(qkv.device)),
-              "hs_window_attn_fwd")
+        # algorithmic traffic: q,k,v read + o written once; flops: QK^T and PV, 2*Ws*hd each per (row, head)
+        with _timed("window_attn_fwd", qkv.device, 4 * B * N * C * qkv.element_size(), 4 * B * N * C * window_size):
+            check(lib.hs_window_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(bias_c), ptr(hs), ptr(idx), int(roll), ptr(labels),
+                                         B, N, C, num_heads, window_size, flags, dt, stream_ptr(qkv.device)),
+                  "hs_window_attn_fwd")
         ctx.save_for_backward(qkv, out, lse, bias_c, hs, idx, labels)
         ctx.args = (B, N, C, num_heads, window_size, flags, dt, int(roll))
         ctx.bias_dtype = None if bias is None else bias.dtype
@@ -87,10 +115,12 @@ class WindowAttnCoreFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias_c) if bias_c is not None else None
         dscale = torch.zeros_like(hs)
-        check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale),
-                                     ptr(bias_c), ptr(hs), ptr(idx), roll, ptr(labels),
-                                     B, N, C, nh, ws, flags, dt, stream_ptr(qkv.device)),
-              "hs_window_attn_bwd")
+        # algorithmic traffic: qkv (3C) + out (C) + dout (C) read, dqkv (3C) written; flops: 5 contractions of 2*Ws*hd
+        with _timed("window_attn_bwd", qkv.device, 8 * B * N * C * qkv.element_size(), 10 * B * N * C * ws):
+            check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale),
+                                         ptr(bias_c), ptr(hs), ptr(idx), roll, ptr(labels),
+                                         B, N, C, nh, ws, flags, dt, stream_ptr(qkv.device)),
+                  "hs_window_attn_bwd")
         dbias_out = None if dbias is None else dbias.to(ctx.bias_dtype)
         sdt, sshape = ctx.scale_meta
         dscale_out = dscale.to(sdt).reshape(sshape) if (flags & _lib.HS_ATTN_COSINE) else None

@@ -23,19 +23,27 @@ def _mods():
 WA_CASES = [f"{a}_{m}" for a in ("scaled", "cos") for m in ("nomask", "rollmask", "ringmask")]
 
 
-def _run_module(mod, c, fwd, dtype):
+# The cosine-attention goldens push one head's logit_scale to the clamp (x100, ref :144-146).  A x100 logit gain turns the
+# 2^-9 relative rounding of bf16 q/k inputs into O(0.4) logit noise, so for those cases bf16 is bounded at 6e-2 here; the
+# kernel arithmetic itself is held to the tight bound against the oracle on identically rounded inputs
+# (test_attn_core_vs_oracle), and default-initialised cosine attention (x10) meets 1e-2 (test_gpu_model).
+def _bf16_slack(name, dtype):
+    return 6.0 if (dtype == torch.bfloat16 and name.startswith("cos")) else 1.0
+
+
+def _run_module(mod, c, fwd, dtype, slack=1.0):
     mod = mod.to(DEV)
     x = torch.from_numpy(c["x"]).to(DEV).to(dtype).requires_grad_(True)
     y = fwd(mod, x)
     assert y.dtype == dtype
-    assert_close(y, c["y"], TOL[dtype], "y")
+    assert_close(y, c["y"], TOL[dtype] * slack, "y")
     y.backward(torch.from_numpy(c["dy"]).to(DEV).to(dtype))
-    assert_close(x.grad, c["dx"], GRAD_TOL[dtype], "dx")
+    assert_close(x.grad, c["dx"], GRAD_TOL[dtype] * slack, "dx")
     params = dict(mod.named_parameters())
     for k, g in c["grad"].items():
         got = params[k].grad
         got = torch.zeros_like(params[k]) if got is None else got
-        assert_close(got, g, GRAD_TOL[dtype], "grad " + k)
+        assert_close(got, g, GRAD_TOL[dtype] * slack, "grad " + k)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -46,7 +54,7 @@ def test_window_attention_golden(name, dtype):
     wa = M.WindowAttention(96, 64, 3, rel_pos_bias="flat", use_cos_attn=name.startswith("cos"))
     wa.load_state_dict(state_dict(c))
     mask = torch.from_numpy(c["mask"].astype(np.float32)) if "mask" in c else None
-    _run_module(wa, c, lambda m, x: m(x, mask=mask), dtype)
+    _run_module(wa, c, lambda m, x: m(x, mask=mask), dtype, _bf16_slack(name, dtype))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -119,7 +127,7 @@ def test_attn_core_vs_oracle(B, nside, C, nH, Ws, strategy, shift, cosine, use_b
         idx, labels = torch.from_numpy(idx_np), torch.from_numpy(lab_np)
 
     # oracle on the values the kernel actually sees (inputs rounded to the activation dtype)
-    qkv_r = qkv.to(dtype).float().requires_grad_(True)
+    qkv_r = qkv.to(dtype).float().clone().requires_grad_(True)
     bias_r = None if bias is None else bias.clone().requires_grad_(True)
     hs_r = hscale.clone().requires_grad_(True)
     o_ref = _oracle_core(qkv_r, bias_r, hs_r, idx, labels, nH, Ws, cosine)
@@ -155,9 +163,9 @@ def test_layernorm_vs_oracle(rows, width, residual, dtype):
     r = torch.randn(rows, width, generator=g) if residual else None
     dy = torch.randn(rows, width, generator=g)
 
-    xr = x.to(dtype).float().requires_grad_(True)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
     wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    rr = None if r is None else r.to(dtype).float().requires_grad_(True)
+    rr = None if r is None else r.to(dtype).float().clone().requires_grad_(True)
     y_ref = OM.layer_norm(xr, wr, br) + (0 if rr is None else rr)
     y_ref.backward(dy.to(dtype).float())
 
