@@ -42,6 +42,7 @@ int launch_attn_bwd_generic(const AttnParams& p, int dtype, hipStream_t stream);
 // MFMA path: Ws == 64, head_dim == 32, bf16 I/O
 bool attn_mfma_supported(const AttnParams& p, int dtype);
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream);
-int launch_attn_bwd_mfma(const AttnParams& p, hipStream_t stream);
+int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p);
+int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream);
 
 }  // namespace hs

@@ -53,10 +53,22 @@ int hs_window_attn_fwd(const void* qkv, void* out, float* lse, const float* bias
     return hs::launch_attn_fwd_generic(p, dtype, s);
 }
 
+int64_t hs_window_attn_bwd_workspace(int batch, int64_t n_tokens, int channels, int num_heads, int window_size, int dtype) {
+    hs::AttnParams p{};
+    if (batch <= 0 || n_tokens <= 0 || channels <= 0 || num_heads <= 0 || window_size <= 0 || channels % num_heads) return 0;
+    p.B = batch;
+    p.N = n_tokens;
+    p.C = channels;
+    p.nH = num_heads;
+    p.Ws = window_size;
+    p.hd = channels / num_heads;
+    return hs::attn_mfma_supported(p, dtype) ? hs::attn_bwd_mfma_workspace_floats(p) : 0;
+}
+
 int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
-                       float* dhead_scale, const float* bias, const float* head_scale, const int32_t* idx, int64_t roll,
-                       const uint8_t* labels, int batch, int64_t n_tokens, int channels, int num_heads, int window_size,
-                       unsigned flags, int dtype, void* stream) {
+                       float* dhead_scale, float* workspace, const float* bias, const float* head_scale, const int32_t* idx,
+                       int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens, int channels, int num_heads,
+                       int window_size, unsigned flags, int dtype, void* stream) {
     hs::AttnParams p;
     if (int st = fill_params(p, qkv, const_cast<void*>(out), const_cast<float*>(lse), bias, head_scale, idx, roll, labels,
                              batch, n_tokens, channels, num_heads, window_size, flags, dtype))
@@ -69,7 +81,7 @@ int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
     p.dbias = bias ? dbias : nullptr;
     p.dhead_scale = (flags & HS_ATTN_COSINE) ? dhead_scale : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_bwd_mfma(p, s);
+    if (hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_bwd_mfma(p, workspace, s);
     return hs::launch_attn_bwd_generic(p, dtype, s);
 }
 

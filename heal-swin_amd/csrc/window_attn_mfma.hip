@@ -294,6 +294,412 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p)
     }
 }
 
+
+// ================================================================================================ backward
+// Per (window, head), on one wave, 40 MFMAs (the minimum: S, dP, dV, dK, dQ):
+//   S^T  = K^ Q^T , dP^T = V dO^T                       (lane = query, registers = keys)
+//   P^T  = exp2(S^T*f + bias - lse) ;  dS^T = P^T o (dP^T - D) ,  D[q] = dO[q].O[q]
+//   dS' = dS * f_q   (f_q = head scale [* 1/|q| for cosine])  ->  ONE bf16 matrix feeds both dK and dQ
+//   dV = P^T dO ,  dK^ = dS'^T Q      A operands = P / dS' TRANSPOSED: stored row-major [q][key] in an LDS scratch and
+//                                     read back with ds_read_b64_tr_b16 (hardware 4x16 transpose); B operands (dO, Q:
+//                                     8 consecutive tokens of one feature) come from the row-major token tiles the same way
+//   X  = dS' K^                       A operand straight from the dS' registers (as P.V in the forward), B by tr-read
+//   dq = X - q^(q^.X) , dk = (dK^ - k^(k^.dK^))/|k|     for cosine attention (plain: dq = X, dk = dK^)
+// The head's bias gradient is accumulated in registers over all windows of the launch (same layout as the bias) and
+// written once per workgroup to a partial buffer that a second tiny kernel reduces -- no atomics, deterministic.
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int kPsLd = 136;                    // bytes per query row of the P / dS' scratch (64 keys * 2 B + 8 pad)
+constexpr int kPsBytes = kWs * kPsLd;         // 8704
+
+struct LdsLayoutBwd {
+    // per head: Q | K | V | dO tiles (4096 each), scratch [64][64] bf16 (padded); then per-row scalars
+    int head, scratch_off, qinv, kinv, dsum, lab, total;
+    __host__ __device__ explicit LdsLayoutBwd(int hg) {
+        scratch_off = 4 * kTileBytes;
+        head = 4 * kTileBytes + kPsBytes;     // 25088 bytes per head
+        qinv = hg * head;
+        kinv = qinv + hg * kWs * 4;
+        dsum = kinv + hg * kWs * 4;
+        lab = dsum + hg * kWs * 4;
+        total = lab + kWs + 16;
+    }
+};
+
+// 8 k-slots (token rows t0..t0+3 and t0+8..t0+11 for half 0/1 handled by the caller) of feature column l&31 from a
+// swizzled row-major [64][32] bf16 tile: two hardware-transposed 8-byte reads
+__device__ __forceinline__ s16x4 tr_read_tile(const unsigned char* tile, int row0, int lane) {
+    const int L = lane & 15, nblk = (lane >> 4) & 1;
+    const int row = row0 + (L >> 2);
+    const int byte_in_row = nblk * 32 + (L & 3) * 8;
+    const int chunk = byte_in_row >> 4;
+    const unsigned char* a = tile + row * 64 + (((chunk ^ ((row >> 2) & 3)) << 4) | (byte_in_row & 8));
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+}
+// the same from the [64 q][64 key] scratch (row stride kPsLd): rows = q (contraction index), columns = key block kb*32..
+__device__ __forceinline__ s16x4 tr_read_scratch(const unsigned char* scr, int row0, int colblk, int lane) {
+    const int L = lane & 15, nblk = (lane >> 4) & 1;
+    const unsigned char* a = scr + (row0 + (L >> 2)) * kPsLd + (colblk * 32 + nblk * 16 + (L & 3) * 4) * 2;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+}
+__device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int HG>
+__global__ void __launch_bounds__(64 * HG) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
+                                                                 float* __restrict__ dscale_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LdsLayoutBwd L(HG);
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y * HG + g;
+    const int C = p.C;
+    const int64_t N = p.N;
+    const int nW = (int)(N / kWs);
+    const int64_t total_windows = (int64_t)p.B * nW;
+    const bool cosine = (p.flags & HS_ATTN_COSINE) != 0;
+    const float hscale = p.head_scale[h];
+    const uint16_t* qkv = (const uint16_t*)p.qkv;
+    const uint16_t* fo = (const uint16_t*)p.out;
+    const uint16_t* dout = (const uint16_t*)p.dout;
+    uint16_t* dqkv = (uint16_t*)p.dqkv;
+
+    unsigned char* my = smem + g * L.head;
+    unsigned char* q_tile = my;
+    unsigned char* k_tile = my + kTileBytes;
+    unsigned char* v_tile = my + 2 * kTileBytes;
+    unsigned char* do_tile = my + 3 * kTileBytes;
+    unsigned char* scr = my + L.scratch_off;
+    float* qinv_s = (float*)(smem + L.qinv);
+    float* kinv_s = (float*)(smem + L.kinv);
+    float* dsum_s = (float*)(smem + L.dsum);
+    unsigned char* lab_s = smem + L.lab;
+
+    float biasr[2][2][16], dbacc[2][2][16];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, qq = qt * 32 + l31;
+                biasr[kt][qt][r] = p.bias ? p.bias[((int64_t)h * kWs + qq) * kWs + key] * kLog2e : 0.f;
+                dbacc[kt][qt][r] = 0.f;
+            }
+    float dscale_acc = 0.f;
+
+    const int srow = tid / (4 * HG), sc = tid % (4 * HG), sg = sc >> 2, scc = sc & 3;
+    const int64_t col0 = (int64_t)blockIdx.y * HG * kHd + sc * 8;
+    unsigned char* st = smem + sg * L.head;  // staging target: the head this thread's chunk belongs to
+
+    for (int64_t wi = blockIdx.x; wi < total_windows; wi += gridDim.x) {
+        const int b = (int)(wi / nW);
+        const int w = (int)(wi - (int64_t)b * nW);
+        const int64_t j0 = (int64_t)w * kWs;
+
+        // ------------------------------------------------------------ stage q, k^, v, dO; D = dO.O; norms
+        int64_t tok[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) tok[rb] = (int64_t)b * N + shifted_source(p, j0 + rb * 16 + srow);
+        if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int row = rb * 16 + srow;
+            const uint4 vq = *(const uint4*)(qkv + tok[rb] * 3 * C + col0);
+            uint4 vk = *(const uint4*)(qkv + tok[rb] * 3 * C + C + col0);
+            const uint4 vv = *(const uint4*)(qkv + tok[rb] * 3 * C + 2 * (int64_t)C + col0);
+            const uint4 vdo = *(const uint4*)(dout + tok[rb] * C + col0);
+            const uint4 vo = *(const uint4*)(fo + tok[rb] * C + col0);
+            const uint32_t wq[4] = {vq.x, vq.y, vq.z, vq.w}, wdo[4] = {vdo.x, vdo.y, vdo.z, vdo.w}, wo[4] = {vo.x, vo.y, vo.z, vo.w};
+            uint32_t wk[4] = {vk.x, vk.y, vk.z, vk.w};
+            float ds = 0.f, sq = 0.f, sk = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ds += bf_lo(wdo[i]) * bf_lo(wo[i]) + bf_hi(wdo[i]) * bf_hi(wo[i]);
+                sq += bf_lo(wq[i]) * bf_lo(wq[i]) + bf_hi(wq[i]) * bf_hi(wq[i]);
+                sk += bf_lo(wk[i]) * bf_lo(wk[i]) + bf_hi(wk[i]) * bf_hi(wk[i]);
+            }
+            ds += __shfl_xor(ds, 1, 64);
+            ds += __shfl_xor(ds, 2, 64);
+            if (cosine) {
+                sq += __shfl_xor(sq, 1, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                sk += __shfl_xor(sk, 1, 64);
+                sk += __shfl_xor(sk, 2, 64);
+                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wk[i] = pack_bf16(bf_lo(wk[i]) * kinv, bf_hi(wk[i]) * kinv);
+                vk = make_uint4(wk[0], wk[1], wk[2], wk[3]);
+                if (scc == 0) {
+                    qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+                    kinv_s[sg * kWs + row] = kinv;
+                }
+            }
+            if (scc == 0) dsum_s[sg * kWs + row] = ds;
+            const int off = swz(row, scc);
+            *(uint4*)(st + off) = vq;
+            *(uint4*)(st + kTileBytes + off) = vk;
+            *(uint4*)(st + 2 * kTileBytes + off) = vv;
+            *(uint4*)(st + 3 * kTileBytes + off) = vdo;
+        }
+        __syncthreads();
+
+        bool mixed = false;
+        if (p.labels) {
+            const uint32_t* lw = (const uint32_t*)lab_s;
+            const uint32_t first = lab_s[0] * 0x01010101u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mixed |= lw[i] != first;
+        }
+
+        // ------------------------------------------------------------ S^T = K^ Q^T and dP^T = V dO^T
+        f32x16 accS[2][2], accP[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    accS[kt][qt][r] = 0.f;
+                    accP[kt][qt][r] = 0.f;
+                }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 kf[2], qf[2], vf[2], df[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int off = swz(t * 32 + l31, ks * 2 + half);
+                kf[t] = *(const bf16x8*)(k_tile + off);
+                qf[t] = *(const bf16x8*)(q_tile + off);
+                vf[t] = *(const bf16x8*)(v_tile + off);
+                df[t] = *(const bf16x8*)(do_tile + off);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    accS[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qf[qt], accS[kt][qt], 0, 0, 0);
+                    accP[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt], df[qt], accP[kt][qt], 0, 0, 0);
+                }
+        }
+
+        // ------------------------------------------------------------ P, dS' (fp32), bias / scale gradients; dS' kept in accS
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qq = qt * 32 + l31;
+            const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
+            const float fqn = hscale * qinv;                  // d s / d (q . k^)
+            const float fq2 = fqn * kLog2e;
+            const float lse2 = p.lse[((int64_t)b * p.nH + h) * N + j0 + qq] * kLog2e;
+            const float dsum = dsum_s[g * kWs + qq];
+            const int mylab = mixed ? lab_s[qq] : 0;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sraw = accS[kt][qt][r];
+                    float t = fmaf(sraw, fq2, biasr[kt][qt][r]);
+                    if (mixed) {
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (lab_s[key] != mylab) t += kMaskLog2;
+                    }
+                    const float pr = __builtin_amdgcn_exp2f(t - lse2);
+                    const float dsv = pr * (accP[kt][qt][r] - dsum);
+                    dbacc[kt][qt][r] += dsv;
+                    dscale_acc = fmaf(dsv * qinv, sraw, dscale_acc);
+                    accP[kt][qt][r] = pr;            // P
+                    accS[kt][qt][r] = dsv * fqn;     // dS'
+                }
+        }
+
+        // ------------------------------------------------------------ dV = P^T dO   (P through the scratch)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const uint2 v = make_uint2(pack_bf16(accP[kt][qt][4 * rg], accP[kt][qt][4 * rg + 1]),
+                                               pack_bf16(accP[kt][qt][4 * rg + 2], accP[kt][qt][4 * rg + 3]));
+                    *(uint2*)(scr + (qt * 32 + l31) * kPsLd + (kt * 32 + 8 * rg + 4 * half) * 2) = v;
+                }
+        // (own-wave LDS traffic only: program order suffices, no barrier)
+        f32x16 dv[2], dk[2], dq[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dv[t][r] = 0.f;
+                dk[t][r] = 0.f;
+                dq[t][r] = 0.f;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // 16 queries per step: half 0 -> q 16ks..+7, half 1 -> q 16ks+8..+15
+            const int qrow = ks * 16 + 8 * half;
+            const bf16x8 bo = join(tr_read_tile(do_tile, qrow, lane), tr_read_tile(do_tile, qrow + 4, lane));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 a = join(tr_read_scratch(scr, qrow, kt, lane), tr_read_scratch(scr, qrow + 4, kt, lane));
+                dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bo, dv[kt], 0, 0, 0);
+            }
+        }
+        // ------------------------------------------------------------ dK^ = dS'^T Q   (dS' through the same scratch)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const uint2 v = make_uint2(pack_bf16(accS[kt][qt][4 * rg], accS[kt][qt][4 * rg + 1]),
+                                               pack_bf16(accS[kt][qt][4 * rg + 2], accS[kt][qt][4 * rg + 3]));
+                    *(uint2*)(scr + (qt * 32 + l31) * kPsLd + (kt * 32 + 8 * rg + 4 * half) * 2) = v;
+                }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int qrow = ks * 16 + 8 * half;
+            const bf16x8 bq = join(tr_read_tile(q_tile, qrow, lane), tr_read_tile(q_tile, qrow + 4, lane));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 a = join(tr_read_scratch(scr, qrow, kt, lane), tr_read_scratch(scr, qrow + 4, kt, lane));
+                dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, dk[kt], 0, 0, 0);
+            }
+        }
+        // ------------------------------------------------------------ X = dS' K^   (A from registers, as P.V forward)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kt = ks >> 1, c = ks & 1;
+            const int kbase = kt * 32 + c * 16 + 4 * half;
+            const bf16x8 bk = join(tr_read_tile(k_tile, kbase, lane), tr_read_tile(k_tile, kbase + 8, lane));
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                bf16x8 af;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) af[jj] = (__bf16)accS[kt][qt][8 * c + jj];
+                dq[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bk, dq[qt], 0, 0, 0);
+            }
+        }
+
+        // ------------------------------------------------------------ results -> LDS (row-major [64][32] bf16) -> global
+        // X -> scratch[0:4096), dK^ -> scratch[4096:8192), dV -> the V tile (all private to this wave until the barrier)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                *(uint16_t*)(scr + rr * 64 + l31 * 2) = float_to_bf16(dq[t][r]);
+                *(uint16_t*)(scr + kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dk[t][r]);
+                *(uint16_t*)(v_tile + rr * 64 + l31 * 2) = float_to_bf16(dv[t][r]);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int row = rb * 16 + srow;
+            uint4 xq = *(const uint4*)(st + L.scratch_off + row * 64 + scc * 16);
+            uint4 xk = *(const uint4*)(st + L.scratch_off + kTileBytes + row * 64 + scc * 16);
+            const uint4 xv = *(const uint4*)(st + 2 * kTileBytes + row * 64 + scc * 16);
+            if (cosine) {  // remove the component along q^ / k^ (gradient through x / |x|)
+                const uint4 rq = *(const uint4*)(st + swz(row, scc));
+                const uint4 rk = *(const uint4*)(st + kTileBytes + swz(row, scc));
+                const float qinv = qinv_s[sg * kWs + row], kinv = kinv_s[sg * kWs + row];
+                uint32_t a[4] = {xq.x, xq.y, xq.z, xq.w}, bq[4] = {rq.x, rq.y, rq.z, rq.w};
+                uint32_t c2[4] = {xk.x, xk.y, xk.z, xk.w}, bk[4] = {rk.x, rk.y, rk.z, rk.w};
+                float pq = 0.f, pk = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pq += bf_lo(a[i]) * bf_lo(bq[i]) + bf_hi(a[i]) * bf_hi(bq[i]);
+                    pk += bf_lo(c2[i]) * bf_lo(bk[i]) + bf_hi(c2[i]) * bf_hi(bk[i]);
+                }
+                pq += __shfl_xor(pq, 1, 64);
+                pq += __shfl_xor(pq, 2, 64);
+                pk += __shfl_xor(pk, 1, 64);
+                pk += __shfl_xor(pk, 2, 64);
+                pq *= qinv * qinv;  // q^ = q*qinv on both sides of  X - q^ (q^ . X)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = pack_bf16(bf_lo(a[i]) - bf_lo(bq[i]) * pq, bf_hi(a[i]) - bf_hi(bq[i]) * pq);
+                    c2[i] = pack_bf16((bf_lo(c2[i]) - bf_lo(bk[i]) * pk) * kinv, (bf_hi(c2[i]) - bf_hi(bk[i]) * pk) * kinv);
+                }
+                xq = make_uint4(a[0], a[1], a[2], a[3]);
+                xk = make_uint4(c2[0], c2[1], c2[2], c2[3]);
+            }
+            uint16_t* dst = dqkv + tok[rb] * 3 * C + col0;
+            *(uint4*)dst = xq;
+            *(uint4*)(dst + C) = xk;
+            *(uint4*)(dst + 2 * (int64_t)C) = xv;
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------ per-workgroup partial parameter gradients
+    if (dbias_part) {
+        float* dst = dbias_part + ((int64_t)blockIdx.x * p.nH + h) * kWs * kWs;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int key = kt * 32 + 8 * rg + 4 * half, qq = qt * 32 + l31;
+                    *(float4*)(dst + (int64_t)qq * kWs + key) =
+                        make_float4(dbacc[kt][qt][4 * rg], dbacc[kt][qt][4 * rg + 1], dbacc[kt][qt][4 * rg + 2], dbacc[kt][qt][4 * rg + 3]);
+                }
+    }
+    if (dscale_part) {
+        const float tot = wave_sum(dscale_acc);
+        if (lane == 0) dscale_part[(int64_t)blockIdx.x * p.nH + h] = tot;
+    }
+}
+
+// dst[e] += sum over parts of src[part][e]
+__global__ void reduce_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < parts; ++s) acc += src[(int64_t)s * n + e];
+    dst[e] += acc;
+}
+
+int bwd_slots(const AttnParams& p, int hg) {
+    const int groups = p.nH / hg;
+    const int64_t windows = (int64_t)p.B * (p.N / kWs);
+    int64_t slots = (256 * 2 + groups - 1) / groups;
+    if (slots > windows) slots = windows;
+    return (int)(slots < 1 ? 1 : slots);
+}
+
+int pick_head_group_bwd(int nH) {
+    if (nH % 2 == 0) return 2;
+    if (nH % 3 == 0) return 3;
+    return 1;
+}
+
+template <int HG>
+int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
+    const LdsLayoutBwd L(HG);
+    auto kern = attn_bwd_mfma_kernel<HG>;
+    HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    const int groups = p.nH / HG, slots = bwd_slots(p, HG);
+    float* dbias_part = p.dbias ? workspace : nullptr;
+    float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots, (unsigned)groups), dim3(64 * HG), L.total, stream, p, dbias_part, dscale_part);
+    HS_LAUNCH_CHECK("attn_bwd_mfma");
+    if (dbias_part) {
+        const int64_t n = (int64_t)p.nH * kWs * kWs;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dbias_part, p.dbias, slots, n);
+        HS_LAUNCH_CHECK("reduce dbias partials");
+    }
+    if (dscale_part) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, dscale_part, p.dhead_scale, slots, (int64_t)p.nH);
+        HS_LAUNCH_CHECK("reduce dscale partials");
+    }
+    return HS_OK;
+}
+
 int pick_head_group(int nH) {
     if (nH % 4 == 0) return 4;
     if (nH % 3 == 0) return 3;
@@ -320,7 +726,12 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
 
 bool attn_mfma_supported(const AttnParams& p, int dtype) {
     // 16-byte vector access needs 8-element aligned columns: C % 8 == 0 holds since C = 32 * nH
-    return dtype == HS_BF16 && p.Ws == kWs && p.hd == kHd && p.dout == nullptr;
+    return dtype == HS_BF16 && p.Ws == kWs && p.hd == kHd;
+}
+
+int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
+    const int hg = pick_head_group_bwd(p.nH);
+    return (int64_t)bwd_slots(p, hg) * p.nH * (kWs * kWs + 1);
 }
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
@@ -332,6 +743,13 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     }
 }
 
-int launch_attn_bwd_mfma(const AttnParams&, hipStream_t) { return fail(HS_ERR_UNSUPPORTED, "mfma backward not built"); }
+int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream) {
+    if (!workspace) return fail(HS_ERR_INVALID_ARG, "the MFMA backward needs a workspace (hs_window_attn_bwd_workspace)");
+    switch (pick_head_group_bwd(p.nH)) {
+        case 2: return launch_bwd<2>(p, workspace, stream);
+        case 3: return launch_bwd<3>(p, workspace, stream);
+        default: return launch_bwd<1>(p, workspace, stream);
+    }
+}
 
 }  // namespace hs

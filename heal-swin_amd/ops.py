@@ -115,9 +115,11 @@ class WindowAttnCoreFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias_c) if bias_c is not None else None
         dscale = torch.zeros_like(hs)
+        nws = int(lib.hs_window_attn_bwd_workspace(B, N, C, nh, ws, dt))
+        wsp = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws else None
         # algorithmic traffic: qkv (3C) + out (C) + dout (C) read, dqkv (3C) written; flops: 5 contractions of 2*Ws*hd
         with _timed("window_attn_bwd", qkv.device, 8 * B * N * C * qkv.element_size(), 10 * B * N * C * ws):
-            check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale),
+            check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale), ptr(wsp),
                                          ptr(bias_c), ptr(hs), ptr(idx), roll, ptr(labels),
                                          B, N, C, nh, ws, flags, dt, stream_ptr(qkv.device)),
                   "hs_window_attn_bwd")

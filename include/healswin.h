@@ -130,9 +130,13 @@ int hs_window_attn_fwd(const void* qkv, void* out, float* lse,
  *   dbias  [dev] f32[nH, Ws, Ws]  ACCUMULATED into (caller zeroes it), or NULL when bias is NULL
  *   dhead_scale [dev] f32[nH]     ACCUMULATED into (caller zeroes it); only written for HS_ATTN_COSINE
  *                                 (the scaled variant's scale is a constant), may be NULL otherwise
+ *   workspace [dev] f32[hs_window_attn_bwd_workspace(...)]  per-workgroup partial bias/scale gradients of the
+ *                                 MFMA path (reduced deterministically, no atomics); may be NULL when the query
+ *                                 returns 0 (fp32-VALU path)
  */
+int64_t hs_window_attn_bwd_workspace(int batch, int64_t n_tokens, int channels, int num_heads, int window_size, int dtype);
 int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
-                       void* dqkv, float* dbias, float* dhead_scale,
+                       void* dqkv, float* dbias, float* dhead_scale, float* workspace,
                        const float* bias, const float* head_scale,
                        const int32_t* idx, int64_t roll, const uint8_t* labels,
                        int batch, int64_t n_tokens, int channels, int num_heads, int window_size,
