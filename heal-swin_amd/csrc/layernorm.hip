@@ -48,35 +48,48 @@ struct vec_io<T, 1> {
     static __device__ __forceinline__ void store(void* p, int64_t i, const float* v) { io<T>::store(p, i, v[0]); }
 };
 
-// lane `lane` owns the VEC-wide chunks lane, lane+64, ... of the row
-template <typename T, int VEC, int ITERS>
+// A wavefront normalises 64/LPR rows at a time: LPR lanes per row (a power of two >= the row's 16-byte chunk
+// count, capped at 64), lane `sub` of a row owning chunks sub, sub+LPR, ...  Narrow rows (C = 96..256 in bf16 are
+// 12..32 chunks) therefore still keep all 64 lanes busy and every global access is a 16-byte vector.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T, int VEC, int LPR, int ITERS>
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restrict__ x, const void* __restrict__ residual,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             void* __restrict__ y, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int64_t rows, int width) {
-    const int lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / LPR;  // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsub = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int nchunk = width / VEC;
-    for (int64_t row = wave; row < rows; row += nwaves) {
+    const float inv_w = 1.f / (float)width;
+    for (int64_t row0 = wave * RPW; row0 < rows; row0 += nwaves * RPW) {
+        const int64_t row = row0 + rsub;
+        const bool live = row < rows;
         const int64_t base = row * width;
         float v[ITERS][VEC];
         float sum = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nchunk) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, v[it]);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) sum += v[it][k];
             }
         }
-        const float mean = wave_sum(sum) / (float)width;
+        const float mean = row_sum<LPR>(sum) * inv_w;
         float sq = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nchunk) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     const float d = v[it][k] - mean;
@@ -84,11 +97,11 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                 }
             }
         }
-        const float rstd = rsqrtf(wave_sum(sq) / (float)width + kLnEps);
+        const float rstd = rsqrtf(row_sum<LPR>(sq) * inv_w + kLnEps);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nchunk) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
                 float g[VEC], b[VEC], r[VEC], o[VEC];
                 vec_io<float, VEC == 8 ? 4 : VEC>::load(gamma, (int64_t)c * VEC, g);
                 vec_io<float, VEC == 8 ? 4 : VEC>::load(beta, (int64_t)c * VEC, b);
@@ -105,30 +118,33 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                 vec_io<T, VEC>::store(y, base + (int64_t)c * VEC, o);
             }
         }
-        if (lane == 0 && mean_out) {
+        if (live && sub == 0 && mean_out) {
             mean_out[row] = mean;
             rstd_out[row] = rstd;
         }
     }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Each workgroup also accumulates
-// sum(dy * xhat) and sum(dy) over its rows and writes one partial row pair to `partials`
-// ([gridDim.x][2][width]); layernorm_param_reduce_kernel sums them.
-template <typename T, int VEC, int ITERS>
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Each lane also accumulates sum(dy * xhat) and
+// sum(dy) for its columns; they are combined across the wave's row groups by shuffles, across the workgroup's waves
+// through LDS, and written as one partial row pair per workgroup ([gridDim.x][2][width]) for the final reduce.
+template <typename T, int VEC, int LPR, int ITERS>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, void* __restrict__ dx,
                                                             float* __restrict__ partials, int64_t rows, int width) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][width]
+    constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int sub = lane % LPR, rsub = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * nw + wid;
     const int64_t nwaves = (int64_t)gridDim.x * nw;
     const int nchunk = width / VEC;
+    const float inv_w = 1.f / (float)width;
     float dg[ITERS][VEC], db[ITERS][VEC], gm[ITERS][VEC];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = lane + 64 * it;
+        const int c = sub + LPR * it;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             dg[it][k] = 0.f;
@@ -136,15 +152,17 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
             gm[it][k] = (c < nchunk) ? gamma[c * VEC + k] : 0.f;
         }
     }
-    for (int64_t row = wave; row < rows; row += nwaves) {
+    for (int64_t row0 = wave * RPW; row0 < rows; row0 += nwaves * RPW) {
+        const int64_t row = row0 + rsub;
+        const bool live = row < rows;
         const int64_t base = row * width;
-        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float mean = live ? mean_in[row] : 0.f, rstd = live ? rstd_in[row] : 0.f;
         float xh[ITERS][VEC], g[ITERS][VEC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nchunk) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
                 float dyv[VEC];
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, xh[it]);
                 vec_io<T, VEC>::load(dy, base + (int64_t)c * VEC, dyv);
@@ -159,11 +177,11 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
                 }
             }
         }
-        const float m1 = wave_sum(s1) / (float)width, m2 = wave_sum(s2) / (float)width;
+        const float m1 = row_sum<LPR>(s1) * inv_w, m2 = row_sum<LPR>(s2) * inv_w;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nchunk) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
                 float o[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = rstd * (g[it][k] - m1 - xh[it][k] * m2);
@@ -171,12 +189,22 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
             }
         }
     }
-    // combine the workgroup's waves: waves 1.. park their sums in LDS, wave 0 adds and writes the partial
-    if (wid > 0) {
+    // fold the wave's row groups (lanes sub, sub+LPR, ... hold the same columns)
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) {
+                dg[it][k] += __shfl_xor(dg[it][k], off, 64);
+                db[it][k] += __shfl_xor(db[it][k], off, 64);
+            }
+        }
+    if (wid > 0 && rsub == 0) {
         float* mine = red + (size_t)(wid - 1) * 2 * width;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = lane + 64 * it;
+            const int c = sub + LPR * it;
             if (c < nchunk)
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -186,11 +214,11 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
         }
     }
     __syncthreads();
-    if (wid == 0) {
+    if (wid == 0 && rsub == 0) {
         float* outp = partials + (size_t)blockIdx.x * 2 * width;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = lane + 64 * it;
+            const int c = sub + LPR * it;
             if (c < nchunk)
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -206,57 +234,74 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
     }
 }
 
-__global__ void layernorm_param_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
-                                              float* __restrict__ dbeta, int nblocks, int width) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*width
-    if (col >= 2 * width) return;
+// sums the per-workgroup partial rows: 32 columns x 8 row slices per workgroup
+__global__ void __launch_bounds__(256) layernorm_param_reduce_kernel(const float* __restrict__ partials,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     int nblocks, int width) {
+    __shared__ float part[8][33];
+    const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cl;  // over 2*width
     float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += partials[(size_t)b * 2 * width + col];
-    if (col < width) dgamma[col] = acc;
-    else dbeta[col - width] = acc;
+    if (col < 2 * width)
+        for (int b = slice; b < nblocks; b += 8) acc += partials[(size_t)b * 2 * width + col];
+    part[slice][cl] = acc;
+    __syncthreads();
+    if (slice == 0 && col < 2 * width) {
+        float tot = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) tot += part[s2][cl];
+        if (col < width) dgamma[col] = tot;
+        else dbeta[col - width] = tot;
+    }
 }
 
 int bwd_blocks(int64_t rows) {
-    const int64_t want = (rows + 3) / 4;
+    const int64_t want = (rows + 15) / 16;
     return (int)(want < kBwdMaxBlocks ? (want < 1 ? 1 : want) : kBwdMaxBlocks);
 }
 
-template <typename T, int VEC, int ITERS>
+template <typename T, int VEC, int LPR, int ITERS>
 int run_fwd(const void* x, const void* res, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t rows,
             int width, hipStream_t s) {
-    int64_t blocks = (rows + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL((layernorm_fwd_kernel<T, VEC, ITERS>), dim3((unsigned)blocks), dim3(256), 0, s, x, res, g, b, y, mean,
-                       rstd, rows, width);
+    constexpr int rows_per_block = 4 * (64 / LPR);
+    int64_t blocks = (rows + rows_per_block - 1) / rows_per_block;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, VEC, LPR, ITERS>), dim3((unsigned)blocks), dim3(256), 0, s, x, res, g, b, y,
+                       mean, rstd, rows, width);
     HS_LAUNCH_CHECK("layernorm_fwd");
     return HS_OK;
 }
 
-template <typename T, int VEC, int ITERS>
+template <typename T, int VEC, int LPR, int ITERS>
 int run_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
             float* dbeta, float* ws, int64_t rows, int width, hipStream_t s) {
     const int blocks = bwd_blocks(rows);
     const size_t smem = (size_t)3 * 2 * width * sizeof(float);
-    auto kern = layernorm_bwd_kernel<T, VEC, ITERS>;
+    auto kern = layernorm_bwd_kernel<T, VEC, LPR, ITERS>;
     if (smem > 48 * 1024) HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width);
     HS_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 255) / 256), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
+    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 31) / 32), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
                        width);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
     return HS_OK;
 }
 
-// picks the vector width and the per-lane register tile for a row width
+// picks lanes-per-row and the per-lane register tile for a row of `width` elements in VEC-wide chunks
 template <typename T, int VEC, typename F>
-int with_iters(int width, F&& f) {
+int with_shape(int width, F&& f) {
     const int chunks = width / VEC;
-    const int iters = (chunks + 63) / 64;
-    if (iters <= 1) return f(std::integral_constant<int, 1>{});
-    if (iters <= 2) return f(std::integral_constant<int, 2>{});
-    if (iters <= 4) return f(std::integral_constant<int, 4>{});
-    if (iters <= 8) return f(std::integral_constant<int, 8>{});
-    if (iters <= 16 && VEC == 1) return f(std::integral_constant<int, 16>{});
+    using std::integral_constant;
+    if (chunks <= 2) return f(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    if (chunks <= 4) return f(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+    if (chunks <= 8) return f(integral_constant<int, 8>{}, integral_constant<int, 1>{});
+    if (chunks <= 16) return f(integral_constant<int, 16>{}, integral_constant<int, 1>{});
+    if (chunks <= 32) return f(integral_constant<int, 32>{}, integral_constant<int, 1>{});
+    if (chunks <= 64) return f(integral_constant<int, 64>{}, integral_constant<int, 1>{});
+    if (chunks <= 128) return f(integral_constant<int, 64>{}, integral_constant<int, 2>{});
+    if (chunks <= 256) return f(integral_constant<int, 64>{}, integral_constant<int, 4>{});
+    if (chunks <= 512) return f(integral_constant<int, 64>{}, integral_constant<int, 8>{});
+    if (chunks <= 1024 && VEC == 1) return f(integral_constant<int, 64>{}, integral_constant<int, 16>{});
     return fail(HS_ERR_UNSUPPORTED, "layernorm width %d too large", width);
 }
 
@@ -276,12 +321,12 @@ int hs_layernorm_fwd(const void* x, const void* residual, const float* gamma, co
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
         if (width % 8 == 0)
-            return with_iters<bf16_t, 8>(width, [&](auto it) { return run_fwd<bf16_t, 8, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
-        return with_iters<bf16_t, 1>(width, [&](auto it) { return run_fwd<bf16_t, 1, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
+        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
     }
     if (width % 4 == 0)
-        return with_iters<float, 4>(width, [&](auto it) { return run_fwd<float, 4, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
-    return with_iters<float, 1>(width, [&](auto it) { return run_fwd<float, 1, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd<float, 4, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
+    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_fwd<float, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
 }
 
 int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) { return (int64_t)hs::bwd_blocks(rows) * 2 * width; }
@@ -295,12 +340,12 @@ int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
         if (width % 8 == 0)
-            return with_iters<bf16_t, 8>(width, [&](auto it) { return run_bwd<bf16_t, 8, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
-        return with_iters<bf16_t, 1>(width, [&](auto it) { return run_bwd<bf16_t, 1, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
+        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
     }
     if (width % 4 == 0)
-        return with_iters<float, 4>(width, [&](auto it) { return run_bwd<float, 4, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
-    return with_iters<float, 1>(width, [&](auto it) { return run_bwd<float, 1, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd<float, 4, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
+    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_bwd<float, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
 }
 
 }  // extern "C"
