@@ -483,7 +483,11 @@ class SwinHPTransformerSys(nn.Module):
                 drop_path=dpr[lo:lo + config.depths[i]], norm_layer=config.norm_layer,
                 use_v2_norm_placement=config.use_v2_norm_placement,
                 downsample=PatchMerging if i < L - 1 else None, use_checkpoint=config.use_checkpoint))
-        self.decoder = config.decoder_class(config, data_spec, dpr)
+        # a reference config object names the reference's own UnetDecoder class: use this package's counterpart
+        decoder_cls = config.decoder_class
+        if getattr(decoder_cls, "__name__", "") == "UnetDecoder":
+            decoder_cls = UnetDecoder
+        self.decoder = decoder_cls(config, data_spec, dpr)
         self.norm = _make_norm(config.norm_layer, self.num_features)
         self.apply(self._init_weights)
 

@@ -1,0 +1,92 @@
+"""Data-parallel gradient exchange (heal_swin_amd.parallel) on CPU with the gloo backend, world_size 2: bucketed
+all-reduce launched from post-accumulate hooks must equal single-process training on the concatenated batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.GELU(), torch.nn.LayerNorm(40), torch.nn.Linear(40, 7))
+
+
+def _worker(rank, world, port, bucket_bytes, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heal_swin_amd.parallel import GradBucketAllReduce
+
+    torch.set_num_threads(1)
+    model = _model()
+    dp = GradBucketAllReduce(model.parameters(), bucket_bytes=bucket_bytes)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 8, 12, generator=g)  # 3 steps, global batch 8
+    y = torch.randn(3, 8, 7, generator=g)
+    for step in range(3):
+        dp.zero_grad()
+        xs, ys = x[step].chunk(world)[rank], y[step].chunk(world)[rank]
+        torch.nn.functional.mse_loss(model(xs), ys).backward()
+        dp.finish()
+        opt.step()
+    q.put((rank, [p.detach().numpy().copy() for p in model.parameters()], len(dp.buckets)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [64 << 20, 1024])  # one bucket / many small buckets
+def test_dp_matches_single_process(bucket_bytes):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the full batch
+    model = _model()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 8, 12, generator=g)
+    y = torch.randn(3, 8, 7, generator=g)
+    for step in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(model(x[step]), y[step]).backward()
+        opt.step()
+    for (rank, params, nb) in results:
+        for a, b in zip(params, model.parameters()):
+            assert torch.allclose(torch.from_numpy(a), b.detach(), atol=1e-6, rtol=1e-5), rank
+    assert results[0][2] == (1 if bucket_bytes > 1e6 else results[0][2]) and (bucket_bytes > 1e6 or results[0][2] > 1)
+    for a, b in zip(results[0][1], results[1][1]):
+        assert (a == b).all()  # replicas stay bit-identical
+
+
+def test_single_process_is_a_noop_wrapper():
+    sys.path.insert(0, ROOT)
+    from heal_swin_amd.parallel import GradBucketAllReduce
+
+    model = _model()
+    dp = GradBucketAllReduce(model.parameters())
+    assert dp.world == 1
+    dp.zero_grad()
+    model(torch.randn(4, 12)).sum().backward()
+    dp.finish()
+    flat = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))])
+    assert torch.equal(flat, dp.buckets[0])  # .grad tensors are views into the flat bucket
