@@ -35,6 +35,7 @@ _SIGNATURES = {
     "hs_window_attn_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
                            c_int, c_i64, c_int, c_int, c_int, c_uint, c_int, c_ptr],
     "hs_gather_rows": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr],
+    "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_layernorm_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
     "hs_layernorm_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
 }
@@ -44,6 +45,7 @@ _OTHER = {
     "hs_status_string": ([c_int], ctypes.c_char_p),
     "hs_device_count": ([], c_int),
     "hs_layernorm_bwd_workspace": ([c_i64, c_int], c_i64),
+    "hs_linear_wgrad_workspace": ([c_i64, c_int, c_int], c_i64),
     "hs_window_attn_bwd_workspace": ([c_int, c_i64, c_int, c_int, c_int, c_int], c_i64),
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_OTHER))

@@ -1,0 +1,253 @@
+// Weight (and bias) gradient of the path's Linear layers:   dW[n, k] = sum_m dY[m, n] * X[m, k],   db[n] = sum_m dY[m, n]
+// for bf16 activations (qkv, proj, fc1, fc2, PatchMerging.reduction, PatchExpand.expand, concat_back_dim), fp32 results
+// (the master weights are fp32, so the gradient never passes through bf16).
+//
+// Shape regime: the output is tiny (128x128 .. 2048x512) and the reduction runs over every token of the batch
+// (98 304 .. 1 572 864 rows): a "TN" GEMM whose only parallelism is the reduction axis.  Structure:
+//   * workgroup = one 128 x 128 output tile x one SLICE of token rows; 4 waves in 2 x 2, each a 64 x 64 sub-tile
+//     (2 x 2 v_mfma_f32_32x32x16_bf16 accumulators); partial tiles go to a workspace and a second kernel sums the slices
+//     (deterministic, no atomics);
+//   * both MFMA operands need 8 consecutive TOKENS of one column per lane, but tokens are the row index of dY and X in
+//     memory: the 32-token tiles are staged row-major in LDS (row stride 320 B: the 4 rows of a transposing read fall
+//     on disjoint banks) and fragments come from ds_read_b64_tr_b16 (hardware 4x16 transpose);
+//   * register-staged double buffering: the next tile's global loads are issued before the current tile's MFMAs and
+//     written to the other LDS buffer after them (one barrier per 32 tokens);
+//   * all tiles of one token slice get consecutive ids on ONE XCD (id % 8), so dY / X slices are re-read from that XCD's
+//     L2, not from HBM: HBM traffic stays at one pass over dY and X;
+//   * the bias gradient falls out of the dY staging loads (column sums in registers), only in the k-tile-0 workgroups.
+// Roofline: flop/byte = N*K/(N+K): HBM-bound at C <= 256 (stage 0/1), MFMA-bound from C = 512.
+#include "hs_device.h"
+
+namespace hs {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int kTile = 128;            // output tile edge (both N and K direction)
+constexpr int kTok = 32;              // tokens per staged tile
+constexpr int kLd = 320;              // LDS row stride in bytes (256 B of data + 64 B skew)
+constexpr int kTileBytes = kTok * kLd;  // 10240
+constexpr int kMaxSlices = 4096;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int tok0, int col0, int lane) {
+    const int L = lane & 15, nblk = (lane >> 4) & 1;
+    const unsigned char* a = tile + (tok0 + (L >> 2)) * kLd + (col0 + nblk * 16 + (L & 3) * 4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * kLd));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+struct Geometry {
+    int tiles_n, tiles_k, tiles, slices;
+    int64_t rows_per_slice;
+};
+
+__host__ __device__ inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
+    Geometry g;
+    g.tiles_n = (n_out + kTile - 1) / kTile;
+    g.tiles_k = (k_in + kTile - 1) / kTile;
+    g.tiles = g.tiles_n * g.tiles_k;
+    // ~6 workgroups per CU over the chip, at least 256 tokens per slice, slices a multiple of 8 (one per XCD)
+    int64_t want = (256 * 6 + g.tiles - 1) / g.tiles;
+    int64_t max_by_rows = (rows + 255) / 256;
+    if (want > max_by_rows) want = max_by_rows;
+    if (want > kMaxSlices) want = kMaxSlices;
+    if (want < 1) want = 1;
+    if (want >= 8) want = (want / 8) * 8;
+    g.slices = (int)want;
+    int64_t rps = (rows + g.slices - 1) / g.slices;
+    g.rows_per_slice = ((rps + kTok - 1) / kTok) * kTok;
+    return g;
+}
+
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                       float* __restrict__ part_w, float* __restrict__ part_b, int64_t rows,
+                                                       int n_out, int k_in, Geometry g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * kTileBytes + 8 * 16 * 4 * 16];
+    auto ytile = [&](int b) { return smem + b * 2 * kTileBytes; };
+    auto xtile = [&](int b) { return smem + b * 2 * kTileBytes + kTileBytes; };
+    float* bred = (float*)(smem + 4 * kTileBytes);  // [16 row groups][128] bias partials
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;  // wave's 64x64 sub-tile inside the 128x128 tile
+
+    // block id -> (slice, tile): all tiles of a slice are consecutive on one XCD (dispatch places block b on XCD b % 8)
+    int slice, tile;
+    {
+        const int b = blockIdx.x;
+        if (g.slices % 8 == 0) {
+            const int xcd = b & 7, local = b >> 3;
+            slice = xcd + 8 * (local / g.tiles);
+            tile = local % g.tiles;
+        } else {
+            slice = b / g.tiles;
+            tile = b % g.tiles;
+        }
+    }
+    const int tn = tile / g.tiles_k, tk = tile % g.tiles_k;
+    const int n0 = tn * kTile, k0 = tk * kTile;
+    const int64_t m_begin = (int64_t)slice * g.rows_per_slice;
+    int64_t m_end = m_begin + g.rows_per_slice;
+    if (m_end > rows) m_end = rows;
+
+    // staging: thread -> (row r = tid/16 + 16*pass, 16-B chunk c = tid%16) of both tiles
+    const int sr = tid >> 4, scn = tid & 15;
+    const bool ycol_ok = n0 + scn * 8 < n_out, xcol_ok = k0 + scn * 8 < k_in;  // n_out, k_in are multiples of 8
+    const uint16_t* yptr = dy + n0 + scn * 8;
+    const uint16_t* xptr = x + k0 + scn * 8;
+    const bool do_bias = part_b != nullptr && tk == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
+
+    uint4 ry[2], rx[2];
+    auto load_regs = [&](int64_t m0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int64_t m = m0 + sr + 16 * ps;
+            const bool row_ok = m < m_end;
+            ry[ps] = (row_ok && ycol_ok) ? *(const uint4*)(yptr + m * n_out) : make_uint4(0, 0, 0, 0);
+            rx[ps] = (row_ok && xcol_ok) ? *(const uint4*)(xptr + m * k_in) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int off = (sr + 16 * ps) * kLd + scn * 16;
+            *(uint4*)(ytile(buf) + off) = ry[ps];
+            *(uint4*)(xtile(buf) + off) = rx[ps];
+            if (do_bias) {
+                const uint32_t w[4] = {ry[ps].x, ry[ps].y, ry[ps].z, ry[ps].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bsum[2 * i] += __uint_as_float(w[i] << 16);
+                    bsum[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+                }
+            }
+        }
+    };
+
+    if (m_begin < m_end) {
+        load_regs(m_begin);
+        store_lds(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += kTok) {
+        const bool more = m0 + kTok < m_end;
+        if (more) load_regs(m0 + kTok);  // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int tok0 = ks * 16 + 8 * half;
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = tr_frag(ytile(buf), tok0, wn * 64 + i * 32, lane);
+                bf[i] = tr_frag(xtile(buf), tok0, wk * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_lds(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // partial tile -> workspace [slice][n_out][k_in]; accumulator: column = k (lane & 31), rows = n
+    float* dst = part_w + (int64_t)slice * n_out * k_in;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (nn < n_out && kk < k_in) dst[(int64_t)nn * k_in + kk] = acc[i][j][r];
+            }
+        }
+    if (do_bias) {  // fold the 16 row groups that share a column chunk
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bred[sr * 128 + scn * 8 + i] = bsum[i];
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) t += bred[rg * 128 + tid];
+            if (n0 + tid < n_out) part_b[(int64_t)slice * n_out + n0 + tid] = t;
+        }
+    }
+}
+
+// out[e] = sum over slices of part[s][e]
+__global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int slices,
+                                                            int64_t n) {
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= n) return;
+    if (e + 3 < n) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < slices; ++s) {
+            const float4 v = *(const float4*)(part + (int64_t)s * n + e);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *(float4*)(out + e) = acc;
+    } else {
+        for (int64_t i = e; i < n; ++i) {
+            float acc = 0.f;
+            for (int s = 0; s < slices; ++s) acc += part[(int64_t)s * n + i];
+            out[i] = acc;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace hs
+
+extern "C" {
+
+int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in) {
+    if (rows <= 0 || n_out <= 0 || k_in <= 0) return 0;
+    const hs::Geometry g = hs::make_geometry(rows, n_out, k_in);
+    return (int64_t)g.slices * ((int64_t)n_out * k_in + n_out);
+}
+
+int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out,
+                    int k_in, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(dy && x && dw && workspace, "null pointer");
+    HS_CHECK_ARG(rows > 0 && n_out > 0 && k_in > 0, "bad shape");
+    if (dtype != HS_BF16) return fail(HS_ERR_UNSUPPORTED, "hs_linear_wgrad implements bf16 activations only");
+    if (n_out % 8 || k_in % 8) return fail(HS_ERR_UNSUPPORTED, "n_out and k_in must be multiples of 8 (16-byte rows)");
+    if (((int64_t)n_out * k_in) % 4) return fail(HS_ERR_UNSUPPORTED, "n_out*k_in must be a multiple of 4");
+    const Geometry g = make_geometry(rows, n_out, k_in);
+    float* part_w = workspace;
+    float* part_b = dbias ? workspace + (int64_t)g.slices * n_out * k_in : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(g.slices * g.tiles)), dim3(256), 0, s, (const uint16_t*)dy,
+                       (const uint16_t*)x, part_w, part_b, rows, n_out, k_in, g);
+    HS_LAUNCH_CHECK("linear_wgrad");
+    const int64_t n = (int64_t)n_out * k_in;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part_w, dw, g.slices, n);
+    HS_LAUNCH_CHECK("linear_wgrad reduce");
+    if (dbias) {
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n_out / 4 + 256) / 256)), dim3(256), 0, s, part_b, dbias,
+                           g.slices, (int64_t)n_out);
+        HS_LAUNCH_CHECK("linear_wgrad bias reduce");
+    }
+    return HS_OK;
+}
+
+}  // extern "C"

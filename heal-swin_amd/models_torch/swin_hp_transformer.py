@@ -56,14 +56,11 @@ def _norm_plus(norm, x, residual):
 
 
 class HSLinear(nn.Linear):
-    """fp32 master weights, GEMM in the activation dtype (library GEMM)."""
+    """fp32 master weights; forward and input-gradient GEMMs in the activation dtype (library GEMM), weight and bias
+    gradients by the HIP split-token kernel `hs_linear_wgrad` (ops.LinearFn)."""
 
     def forward(self, x):
-        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
-        b = self.bias
-        if b is not None and b.dtype != x.dtype:
-            b = b.to(x.dtype)
-        return F.linear(x, w, b)
+        return ops.linear(x, self.weight, self.bias)
 
 
 class DropPath(nn.Module):

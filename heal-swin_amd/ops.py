@@ -176,6 +176,58 @@ def layer_norm(x, weight, bias, residual=None):
     return LayerNormFn.apply(x, weight, bias, residual)
 
 
+# ----------------------------------------------------------------------------- Linear with HIP weight gradient
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b with fp32 master parameters and activations in x.dtype.
+    forward / input gradient: library GEMM; weight + bias gradient (bf16): `hs_linear_wgrad` (split over the token axis,
+    fp32 results straight into the master dtype)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, weight, bias)
+        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        n_out, k_in = weight.shape
+        dy2 = dy.reshape(-1, n_out)
+        x2 = x.reshape(-1, k_in)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w = weight if weight.dtype == dy.dtype else weight.to(dy.dtype)
+            dx = (dy2 @ w).reshape(x.shape)
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w or want_b:
+            rows = x2.shape[0]
+            if x.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and x2.is_contiguous():
+                dw32 = torch.empty((n_out, k_in), dtype=torch.float32, device=x.device)
+                db32 = torch.empty(n_out, dtype=torch.float32, device=x.device) if want_b else None
+                ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=x.device)
+                with _timed("linear_wgrad", x.device, 2 * rows * (n_out + k_in), 2 * rows * n_out * k_in):
+                    check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in,
+                                              _lib.HS_BF16, stream_ptr(x.device)), "hs_linear_wgrad")
+                dw = dw32.to(weight.dtype) if want_w else None
+                db = db32.to(ctx.bias_dtype) if want_b else None
+            else:  # fp32 activations (or odd widths): library GEMM
+                if want_w:
+                    dw = (dy2.t() @ x2).to(weight.dtype)
+                if want_b:
+                    db = dy2.sum(0).to(ctx.bias_dtype)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)
+
+
 # ----------------------------------------------------------------------------- standalone shift (gather rows)
 class GatherRowsFn(torch.autograd.Function):
     """out[:, j] = x[:, idx[j]]  (or roll); backward gathers with the inverse table."""

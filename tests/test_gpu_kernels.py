@@ -218,3 +218,28 @@ def test_cpu_tensors_are_rejected():
     ops, _, _ = _mods()
     with pytest.raises(RuntimeError):
         ops.layer_norm(torch.randn(4, 8), torch.ones(8), torch.zeros(8))
+
+
+# ----------------------------------------------------------------------------- Linear weight / bias gradient
+@pytest.mark.parametrize("rows,n_out,k_in", [(4096, 128, 128), (5000, 384, 128), (777, 96, 288), (33000, 512, 2048),
+                                              (2048, 256, 1024), (100, 8, 16), (65536, 128, 512), (3000, 24, 40)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_wgrad_vs_fp32(rows, n_out, k_in, bias):
+    ops, _, _ = _mods()
+    g = torch.Generator().manual_seed(rows + n_out)
+    x = torch.randn(rows, k_in, generator=g).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(rows, n_out, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(n_out, k_in, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = torch.zeros(n_out, device=DEV, requires_grad=True) if bias else None
+    xin = x.clone().requires_grad_(True)
+    y = ops.linear(xin, w, b)
+    y.backward(dy)
+    # fp32 reference on the same bf16-rounded operands: the kernel accumulates in fp32 and never rounds the result
+    ref_w = dy.float().t() @ x.float()
+    scale = float(ref_w.abs().max())
+    assert float((w.grad - ref_w).abs().max()) <= 2e-4 * max(1.0, scale) * max(1.0, (rows / 4096) ** 0.5)
+    if bias:
+        ref_b = dy.float().sum(0)
+        assert float((b.grad - ref_b).abs().max()) <= 2e-4 * max(1.0, float(ref_b.abs().max()))
+    ref_dx = (dy.float() @ w.detach().to(torch.bfloat16).float())
+    assert_close(xin.grad, ref_dx, 1e-2, "dx")
