@@ -73,6 +73,28 @@ def build_model(wl, nside=None):
     return model, cfg, spec
 
 
+def pmc_traffic_per_launch(attn_agg):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_attn_pmc_hbm_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, KiB units, FETCH x2 gfx950 correction), averaged over this run's launch
+    mix by matching each launch's algorithmic byte count; None if a launch shape was not profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_attn_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    table = {}
+    for r in json.load(open(path))["records"]:
+        tag = r["kernel"].replace("hs_", "")
+        table.setdefault((tag, int(r["algorithmic_bytes"])), []).append(r["hbm_bytes_corrected"])
+    tot, n = 0.0, 0
+    for tag, a in attn_agg.items():
+        for nbytes, cnt in a[4].items():
+            vals = table.get((tag, int(nbytes)))
+            if not vals:
+                return None
+            tot += cnt * sum(vals) / len(vals)
+            n += cnt
+    return tot / n if n else None
+
+
 def usable_cores():
     """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose
     256 hardware threads but a 16-CPU quota; running 256 threads against it throttles everything)."""
@@ -220,20 +242,25 @@ def main():
         if timings:
             agg = {}
             for tag, s, e, nbytes, flops in timings:
-                a = agg.setdefault(tag, [0.0, 0, 0, 0])
+                a = agg.setdefault(tag, [0.0, 0, 0, 0, {}])
                 a[0] += s.elapsed_time(e) * 1e-3
                 a[1] += nbytes
                 a[2] += flops
                 a[3] += 1
-            tot_t = sum(a[0] for a in agg.values())
-            tot_b = sum(a[1] for a in agg.values())
+                a[4][nbytes] = a[4].get(nbytes, 0) + 1
+            attn = {t: a for t, a in agg.items() if t.startswith("window_attn")}
+            tot_t = sum(a[0] for a in attn.values())
+            tot_b = sum(a[1] for a in attn.values())
+            launches = sum(a[3] for a in attn.values())
             ach = tot_b / tot_t / 1e9
             out["roofline"] = {
-                "kernel": "hs_window_attn_fwd+bwd (fused shift/window-partition/attention/reverse)", "bound": "hbm",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "hs_window_attn_fwd + hs_window_attn_bwd (fused shift / window partition / attention / reverse)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic_per_launch(attn), "algorithmic_bytes_per_launch": tot_b / launches,
+                "avg_launch_us": 1e6 * tot_t / launches, "launches": launches, "share_of_step": tot_t / elapsed,
                 "per_kernel": {tag: {"launches": a[3], "avg_us": 1e6 * a[0] / a[3], "GB/s": a[1] / a[0] / 1e9,
-                                     "TFLOP/s": a[2] / a[0] / 1e12} for tag, a in agg.items()},
-                "share_of_step": tot_t / elapsed,
+                                     "TFLOP/s": a[2] / a[0] / 1e12, "share_of_step": a[0] / elapsed}
+                               for tag, a in agg.items()},
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)

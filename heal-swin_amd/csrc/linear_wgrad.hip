@@ -27,34 +27,37 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int kTile = 128;            // output tile edge (both N and K direction)
+constexpr int kTileK = 128;           // output tile extent along k_in
 constexpr int kTok = 32;              // tokens per staged tile
-constexpr int kLd = 320;              // LDS row stride in bytes (256 B of data + 64 B skew)
-constexpr int kTileBytes = kTok * kLd;  // 10240
-constexpr int kMaxSlices = 4096;
+constexpr int kMaxSlices = 2048;
+constexpr int kReduceChunks = 32;     // first-stage groups of the slice reduction
+// LDS row stride: data bytes + 64 B skew, so the 4 token rows of a transposing read fall on disjoint banks
+__host__ __device__ constexpr int row_stride(int cols) { return cols * 2 + 64; }
 
+template <int LD>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int tok0, int col0, int lane) {
     const int L = lane & 15, nblk = (lane >> 4) & 1;
-    const unsigned char* a = tile + (tok0 + (L >> 2)) * kLd + (col0 + nblk * 16 + (L & 3) * 4) * 2;
+    const unsigned char* a = tile + (tok0 + (L >> 2)) * LD + (col0 + nblk * 16 + (L & 3) * 4) * 2;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * kLd));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * LD));
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
 
 struct Geometry {
-    int tiles_n, tiles_k, tiles, slices;
+    int tile_n, tiles_n, tiles_k, tiles, slices, chunks;
     int64_t rows_per_slice;
 };
 
 __host__ __device__ inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
     Geometry g;
-    g.tiles_n = (n_out + kTile - 1) / kTile;
-    g.tiles_k = (k_in + kTile - 1) / kTile;
+    g.tile_n = (n_out % 256 == 0 || n_out >= 512) ? 256 : 128;
+    g.tiles_n = (n_out + g.tile_n - 1) / g.tile_n;
+    g.tiles_k = (k_in + kTileK - 1) / kTileK;
     g.tiles = g.tiles_n * g.tiles_k;
-    // ~6 workgroups per CU over the chip, at least 256 tokens per slice, slices a multiple of 8 (one per XCD)
-    int64_t want = (256 * 6 + g.tiles - 1) / g.tiles;
-    int64_t max_by_rows = (rows + 255) / 256;
+    // ~4 workgroups per CU over the chip, at least 512 tokens per slice, slices a multiple of 8 (one per XCD)
+    int64_t want = (256 * 4 + g.tiles - 1) / g.tiles;
+    int64_t max_by_rows = (rows + 511) / 512;
     if (want > max_by_rows) want = max_by_rows;
     if (want > kMaxSlices) want = kMaxSlices;
     if (want < 1) want = 1;
@@ -62,19 +65,27 @@ __host__ __device__ inline Geometry make_geometry(int64_t rows, int n_out, int k
     g.slices = (int)want;
     int64_t rps = (rows + g.slices - 1) / g.slices;
     g.rows_per_slice = ((rps + kTok - 1) / kTok) * kTok;
+    g.chunks = g.slices > 2 * kReduceChunks ? kReduceChunks : 1;
     return g;
 }
 
+// NB = 32-row blocks per wave along n: the workgroup tile is (64*NB) x 128, waves in 2 x 2, each (32*NB) x 64
+template <int NB>
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                        float* __restrict__ part_w, float* __restrict__ part_b, int64_t rows,
                                                        int n_out, int k_in, Geometry g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * kTileBytes + 8 * 16 * 4 * 16];
-    auto ytile = [&](int b) { return smem + b * 2 * kTileBytes; };
-    auto xtile = [&](int b) { return smem + b * 2 * kTileBytes + kTileBytes; };
-    float* bred = (float*)(smem + 4 * kTileBytes);  // [16 row groups][128] bias partials
+    constexpr int TN = 64 * NB;                      // tile extent along n_out
+    constexpr int LDY = row_stride(TN), LDX = row_stride(kTileK);
+    constexpr int YB = kTok * LDY, XB = kTok * LDX;  // bytes of one staged dY / X tile
+    constexpr int YCH = TN / 8;                      // 16-byte chunks per dY tile row
+    constexpr int YPASS = (kTok * YCH) / 256;        // staging passes over the dY tile (2 or 4)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
+    auto ytile = [&](int b) { return smem + b * (YB + XB); };
+    auto xtile = [&](int b) { return smem + b * (YB + XB) + YB; };
+    float* bred = (float*)smem;  // bias partials [256 / YCH row groups][TN], reuses the tiles after the main loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int wn = wave >> 1, wk = wave & 1;  // wave's 64x64 sub-tile inside the 128x128 tile
+    const int wn = wave >> 1, wk = wave & 1;  // wave's (32*NB) x 64 sub-tile inside the tile
 
     // block id -> (slice, tile): all tiles of a slice are consecutive on one XCD (dispatch places block b on XCD b % 8)
     int slice, tile;
@@ -90,43 +101,45 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
         }
     }
     const int tn = tile / g.tiles_k, tk = tile % g.tiles_k;
-    const int n0 = tn * kTile, k0 = tk * kTile;
+    const int n0 = tn * TN, k0 = tk * kTileK;
     const int64_t m_begin = (int64_t)slice * g.rows_per_slice;
     int64_t m_end = m_begin + g.rows_per_slice;
     if (m_end > rows) m_end = rows;
 
-    // staging: thread -> (row r = tid/16 + 16*pass, 16-B chunk c = tid%16) of both tiles
-    const int sr = tid >> 4, scn = tid & 15;
-    const bool ycol_ok = n0 + scn * 8 < n_out, xcol_ok = k0 + scn * 8 < k_in;  // n_out, k_in are multiples of 8
-    const uint16_t* yptr = dy + n0 + scn * 8;
-    const uint16_t* xptr = x + k0 + scn * 8;
+    // staging: X tile: thread -> (row tid/16 + 16*pass, chunk tid%16); dY tile: (row tid/YCH + (256/YCH)*pass, chunk tid%YCH)
+    const int xr = tid >> 4, xc = tid & 15;
+    const int yr = tid / YCH, yc = tid % YCH;
+    const bool ycol_ok = n0 + yc * 8 < n_out, xcol_ok = k0 + xc * 8 < k_in;  // n_out, k_in are multiples of 8
+    const uint16_t* yptr = dy + n0 + yc * 8;
+    const uint16_t* xptr = x + k0 + xc * 8;
     const bool do_bias = part_b != nullptr && tk == 0;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    f32x16 acc[2][2];
+    f32x16 acc[NB][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
 
-    uint4 ry[2], rx[2];
+    uint4 ry[YPASS], rx[2];
     auto load_regs = [&](int64_t m0) {
 #pragma unroll
+        for (int ps = 0; ps < YPASS; ++ps) {
+            const int64_t m = m0 + yr + (256 / YCH) * ps;
+            ry[ps] = (m < m_end && ycol_ok) ? *(const uint4*)(yptr + m * n_out) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const int64_t m = m0 + sr + 16 * ps;
-            const bool row_ok = m < m_end;
-            ry[ps] = (row_ok && ycol_ok) ? *(const uint4*)(yptr + m * n_out) : make_uint4(0, 0, 0, 0);
-            rx[ps] = (row_ok && xcol_ok) ? *(const uint4*)(xptr + m * k_in) : make_uint4(0, 0, 0, 0);
+            const int64_t m = m0 + xr + 16 * ps;
+            rx[ps] = (m < m_end && xcol_ok) ? *(const uint4*)(xptr + m * k_in) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int off = (sr + 16 * ps) * kLd + scn * 16;
-            *(uint4*)(ytile(buf) + off) = ry[ps];
-            *(uint4*)(xtile(buf) + off) = rx[ps];
+        for (int ps = 0; ps < YPASS; ++ps) {
+            *(uint4*)(ytile(buf) + (yr + (256 / YCH) * ps) * LDY + yc * 16) = ry[ps];
             if (do_bias) {
                 const uint32_t w[4] = {ry[ps].x, ry[ps].y, ry[ps].z, ry[ps].w};
 #pragma unroll
@@ -136,6 +149,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
                 }
             }
         }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) *(uint4*)(xtile(buf) + (xr + 16 * ps) * LDX + xc * 16) = rx[ps];
     };
 
     if (m_begin < m_end) {
@@ -150,14 +165,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int tok0 = ks * 16 + 8 * half;
-            bf16x8 af[2], bf[2];
+            bf16x8 af[NB], bf[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = tr_frag(ytile(buf), tok0, wn * 64 + i * 32, lane);
-                bf[i] = tr_frag(xtile(buf), tok0, wk * 64 + i * 32, lane);
-            }
+            for (int j = 0; j < 2; ++j) bf[j] = tr_frag<LDX>(xtile(buf), tok0, wk * 64 + j * 32, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NB; ++i) af[i] = tr_frag<LDY>(ytile(buf), tok0, wn * 32 * NB + i * 32, lane);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
@@ -169,37 +183,41 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
     // partial tile -> workspace [slice][n_out][k_in]; accumulator: column = k (lane & 31), rows = n
     float* dst = part_w + (int64_t)slice * n_out * k_in;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int kk = k0 + wk * 64 + j * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int nn = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int nn = n0 + wn * 32 * NB + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (nn < n_out && kk < k_in) dst[(int64_t)nn * k_in + kk] = acc[i][j][r];
             }
         }
-    if (do_bias) {  // fold the 16 row groups that share a column chunk
+    if (do_bias) {  // fold the row groups that share a column chunk (tile buffers are free: last loop barrier passed)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bred[sr * 128 + scn * 8 + i] = bsum[i];
+        for (int i = 0; i < 8; ++i) bred[yr * TN + yc * 8 + i] = bsum[i];
         __syncthreads();
-        if (tid < 128) {
+        if (tid < TN) {
             float t = 0.f;
 #pragma unroll
-            for (int rg = 0; rg < 16; ++rg) t += bred[rg * 128 + tid];
+            for (int rg = 0; rg < 256 / YCH; ++rg) t += bred[rg * TN + tid];
             if (n0 + tid < n_out) part_b[(int64_t)slice * n_out + n0 + tid] = t;
         }
     }
 }
 
-// out[e] = sum over slices of part[s][e]
+// out[c][e] = sum over the slices of chunk c (blockIdx.y) of part[s][e]; chunks == 1 writes the final result
 __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int slices,
                                                             int64_t n) {
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e >= n) return;
+    const int per = (slices + gridDim.y - 1) / gridDim.y;
+    const int s_begin = blockIdx.y * per;
+    const int s_end = s_begin + per < slices ? s_begin + per : slices;
+    out += (int64_t)blockIdx.y * n;
     if (e + 3 < n) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < slices; ++s) {
+        for (int s = s_begin; s < s_end; ++s) {
             const float4 v = *(const float4*)(part + (int64_t)s * n + e);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
@@ -207,7 +225,7 @@ __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restr
     } else {
         for (int64_t i = e; i < n; ++i) {
             float acc = 0.f;
-            for (int s = 0; s < slices; ++s) acc += part[(int64_t)s * n + i];
+            for (int s = s_begin; s < s_end; ++s) acc += part[(int64_t)s * n + i];
             out[i] = acc;
         }
     }
@@ -221,7 +239,7 @@ extern "C" {
 int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in) {
     if (rows <= 0 || n_out <= 0 || k_in <= 0) return 0;
     const hs::Geometry g = hs::make_geometry(rows, n_out, k_in);
-    return (int64_t)g.slices * ((int64_t)n_out * k_in + n_out);
+    return (int64_t)(g.slices + (g.chunks > 1 ? g.chunks : 0)) * ((int64_t)n_out * k_in + n_out);
 }
 
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out,
@@ -233,20 +251,35 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     if (n_out % 8 || k_in % 8) return fail(HS_ERR_UNSUPPORTED, "n_out and k_in must be multiples of 8 (16-byte rows)");
     if (((int64_t)n_out * k_in) % 4) return fail(HS_ERR_UNSUPPORTED, "n_out*k_in must be a multiple of 4");
     const Geometry g = make_geometry(rows, n_out, k_in);
-    float* part_w = workspace;
-    float* part_b = dbias ? workspace + (int64_t)g.slices * n_out * k_in : nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(g.slices * g.tiles)), dim3(256), 0, s, (const uint16_t*)dy,
-                       (const uint16_t*)x, part_w, part_b, rows, n_out, k_in, g);
-    HS_LAUNCH_CHECK("linear_wgrad");
     const int64_t n = (int64_t)n_out * k_in;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part_w, dw, g.slices, n);
-    HS_LAUNCH_CHECK("linear_wgrad reduce");
-    if (dbias) {
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n_out / 4 + 256) / 256)), dim3(256), 0, s, part_b, dbias,
-                           g.slices, (int64_t)n_out);
-        HS_LAUNCH_CHECK("linear_wgrad bias reduce");
-    }
+    float* part_w = workspace;
+    float* part_b = dbias ? workspace + (int64_t)g.slices * n : nullptr;
+    float* mid_w = workspace + (int64_t)g.slices * (n + n_out);
+    float* mid_b = mid_w + (int64_t)g.chunks * n;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(g.slices * g.tiles));
+    if (g.tile_n == 256)
+        hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b, rows,
+                           n_out, k_in, g);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b, rows,
+                           n_out, k_in, g);
+    HS_LAUNCH_CHECK("linear_wgrad");
+    auto reduce = [&](const float* part, float* mid, float* out, int64_t cnt) -> int {
+        const unsigned bx = (unsigned)((cnt / 4 + 256) / 256);
+        if (g.chunks > 1) {
+            hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, g.chunks), dim3(256), 0, s, part, mid, g.slices, cnt);
+            HS_LAUNCH_CHECK("linear_wgrad reduce 1");
+            hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, mid, out, g.chunks, cnt);
+        } else {
+            hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, part, out, g.slices, cnt);
+        }
+        HS_LAUNCH_CHECK("linear_wgrad reduce");
+        return HS_OK;
+    };
+    if (int st = reduce(part_w, mid_w, dw, n)) return st;
+    if (dbias)
+        if (int st = reduce(part_b, mid_b, dbias, (int64_t)n_out)) return st;
     return HS_OK;
 }
 
