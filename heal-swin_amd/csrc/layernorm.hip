@@ -51,6 +51,13 @@ struct vec_io<T, 1> {
 // A wavefront normalises 64/LPR rows at a time: LPR lanes per row (a power of two >= the row's 16-byte chunk
 // count, capped at 64), lane `sub` of a row owning chunks sub, sub+LPR, ...  Narrow rows (C = 96..256 in bf16 are
 // 12..32 chunks) therefore still keep all 64 lanes busy and every global access is a 16-byte vector.
+template <typename T>
+__device__ __forceinline__ float round_to(float v);
+template <>
+__device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_float(float_to_bf16(v)); }
+
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
 #pragma unroll
@@ -62,7 +69,8 @@ template <typename T, int VEC, int LPR, int ITERS>
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restrict__ x, const void* __restrict__ residual,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             void* __restrict__ y, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, int64_t rows, int width) {
+                                                            float* __restrict__ rstd_out, int64_t rows, int width,
+                                                            const void* __restrict__ add_in, void* __restrict__ sum_out) {
     constexpr int RPW = 64 / LPR;  // rows per wave
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsub = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -80,6 +88,13 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, v[it]);
+                if (add_in) {  // s = x + add_in, rounded to the activation dtype exactly as a separate add would store it
+                    float a2[VEC];
+                    vec_io<T, VEC>::load(add_in, base + (int64_t)c * VEC, a2);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) v[it][k] = round_to<T>(v[it][k] + a2[k]);
+                    vec_io<T, VEC>::store(sum_out, base + (int64_t)c * VEC, v[it]);
+                }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) sum += v[it][k];
             }
@@ -132,7 +147,8 @@ template <typename T, int VEC, int LPR, int ITERS>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, void* __restrict__ dx,
-                                                            float* __restrict__ partials, int64_t rows, int width) {
+                                                            float* __restrict__ partials, int64_t rows, int width,
+                                                            const void* __restrict__ dres_in) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][width]
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -185,6 +201,12 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
                 float o[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = rstd * (g[it][k] - m1 - xh[it][k] * m2);
+                if (dres_in) {  // gradient arriving through the residual path of the fused add
+                    float d2[VEC];
+                    vec_io<T, VEC>::load(dres_in, base + (int64_t)c * VEC, d2);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o[k] += d2[k];
+                }
                 vec_io<T, VEC>::store(dx, base + (int64_t)c * VEC, o);
             }
         }
@@ -262,24 +284,24 @@ int bwd_blocks(int64_t rows) {
 
 template <typename T, int VEC, int LPR, int ITERS>
 int run_fwd(const void* x, const void* res, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t rows,
-            int width, hipStream_t s) {
+            int width, hipStream_t s, const void* add_in, void* sum_out) {
     constexpr int rows_per_block = 4 * (64 / LPR);
     int64_t blocks = (rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, VEC, LPR, ITERS>), dim3((unsigned)blocks), dim3(256), 0, s, x, res, g, b, y,
-                       mean, rstd, rows, width);
+                       mean, rstd, rows, width, add_in, sum_out);
     HS_LAUNCH_CHECK("layernorm_fwd");
     return HS_OK;
 }
 
 template <typename T, int VEC, int LPR, int ITERS>
 int run_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
-            float* dbeta, float* ws, int64_t rows, int width, hipStream_t s) {
+            float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in) {
     const int blocks = bwd_blocks(rows);
     const size_t smem = (size_t)3 * 2 * width * sizeof(float);
     auto kern = layernorm_bwd_kernel<T, VEC, LPR, ITERS>;
     if (smem > 48 * 1024) HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in);
     HS_LAUNCH_CHECK("layernorm_bwd");
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 31) / 32), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
                        width);
@@ -308,31 +330,30 @@ int with_shape(int width, F&& f) {
 }  // namespace
 }  // namespace hs
 
-extern "C" {
+namespace {
 
-int hs_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, float* mean,
-                     float* rstd, int64_t rows, int width, int dtype, void* stream) {
+int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                int64_t rows, int width, int dtype, void* stream, const void* add_in, void* sum_out) {
     using namespace hs;
     HS_CHECK_ARG(x && gamma && beta && y, "null pointer");
     HS_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "mean and rstd must both be given or both be null");
+    HS_CHECK_ARG((add_in == nullptr) == (sum_out == nullptr), "add_in and sum_out go together");
     HS_CHECK_ARG(rows >= 0 && width > 0, "bad shape");
     HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
     if (rows == 0) return HS_OK;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
         if (width % 8 == 0)
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
-        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
+        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
     }
     if (width % 4 == 0)
-        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd<float, 4, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
-    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_fwd<float, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd<float, 4, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
+    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_fwd<float, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
 }
 
-int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) { return (int64_t)hs::bwd_blocks(rows) * 2 * width; }
-
-int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                     float* dgamma, float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream) {
+int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream, const void* dres_in) {
     using namespace hs;
     HS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && width > 0, "bad shape");
@@ -340,12 +361,40 @@ int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
         if (width % 8 == 0)
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
-        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
+        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
     }
     if (width % 4 == 0)
-        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd<float, 4, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
-    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_bwd<float, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd<float, 4, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
+    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_bwd<float, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
+}
+
+}  // namespace
+
+extern "C" {
+
+int hs_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, float* mean,
+                     float* rstd, int64_t rows, int width, int dtype, void* stream) {
+    return ln_fwd_impl(x, residual, gamma, beta, y, mean, rstd, rows, width, dtype, stream, nullptr, nullptr);
+}
+
+int hs_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* sum_out, void* y,
+                         float* mean, float* rstd, int64_t rows, int width, int dtype, void* stream) {
+    HS_CHECK_ARG(b && sum_out, "null pointer");
+    return ln_fwd_impl(a, nullptr, gamma, beta, y, mean, rstd, rows, width, dtype, stream, b, sum_out);
+}
+
+int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) { return (int64_t)hs::bwd_blocks(rows) * 2 * width; }
+
+int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                     float* dgamma, float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream) {
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, nullptr);
+}
+
+int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
+                         const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows, int width,
+                         int dtype, void* stream) {
+    return ln_bwd_impl(dy, sum, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, dsum);
 }
 
 }  // extern "C"

@@ -228,9 +228,28 @@ class SwinTransformerBlock(nn.Module):
             return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels)
         return self.attn.attend(x, self.window_size, idx, 0, labels)
 
+    def can_defer(self):
+        """v1 placement without active stochastic depth: both residual adds can be fused into the following LayerNorm."""
+        return (not self.use_v2_norm_placement and isinstance(self.norm1, HSLayerNorm) and isinstance(self.norm2, HSLayerNorm)
+                and (isinstance(self.drop_path, nn.Identity) or not self.training))
+
+    def forward_deferred(self, x, pending):
+        """v1 block on the input `x + pending` (pending may be None); returns (x1, m) with the block output = x1 + m.
+        Every residual add rides on the LayerNorm kernel that consumes its result (ref :337-338, :316)."""
+        if pending is None:
+            n1 = self.norm1(x)
+        else:
+            x, n1 = ops.add_layer_norm(x, pending, self.norm1.weight, self.norm1.bias)
+        a = self._attention_branch(n1)
+        x1, n2 = ops.add_layer_norm(x, a, self.norm2.weight, self.norm2.bias)
+        return x1, self.mlp(n2)
+
     def forward(self, x):
         B, N, C = x.shape
         assert N == self.input_resolution, f"expected {self.input_resolution} tokens, got {N}"
+        if self.can_defer():
+            x1, m = self.forward_deferred(x, None)
+            return x1 + m
         plain_path = isinstance(self.drop_path, nn.Identity) or not self.training
         if self.use_v2_norm_placement:  # ref :334-335
             a = self._attention_branch(x)
@@ -305,9 +324,15 @@ def _build_blocks(dim, input_resolution, depth, num_heads, window_size, base_pix
 
 class _Stage(nn.Module):
     def _run_blocks(self, x):
+        pending = None  # second residual branch of the previous block, added inside the next block's first LayerNorm
         for blk in self.blocks:
-            x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
-        return x
+            if self.use_checkpoint or not blk.can_defer():
+                if pending is not None:
+                    x, pending = x + pending, None
+                x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
+            else:
+                x, pending = blk.forward_deferred(x, pending)
+        return x if pending is None else x + pending
 
     def extra_repr(self):
         return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"

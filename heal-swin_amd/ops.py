@@ -176,6 +176,50 @@ def layer_norm(x, weight, bias, residual=None):
     return LayerNormFn.apply(x, weight, bias, residual)
 
 
+class AddLayerNormFn(torch.autograd.Function):
+    """(s, y) = (a + b, LayerNorm(a + b)) in one pass; backward folds the residual-path gradient into the LN backward."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias):
+        _require_gpu(a, b, weight, bias)
+        a, b = a.contiguous(), b.contiguous()
+        assert a.shape == b.shape and a.dtype == b.dtype
+        width = a.shape[-1]
+        rows = a.numel() // width
+        dt = _lib.dtype_code(a.dtype)
+        g, be = _f32(weight), _f32(bias)
+        s = torch.empty_like(a)
+        y = torch.empty_like(a)
+        mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+        check(lib.hs_add_layernorm_fwd(ptr(a), ptr(b), ptr(g), ptr(be), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, width, dt,
+                                       stream_ptr(a.device)), "hs_add_layernorm_fwd")
+        ctx.save_for_backward(s, g, mean, rstd)
+        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, g, mean, rstd = ctx.saved_tensors
+        rows, width, dt, wdt, bdt = ctx.meta
+        if dy is None:  # only the sum was used downstream
+            return ds, ds, None, None
+        dy = dy.contiguous()
+        ds_c = None if ds is None else ds.contiguous()
+        dx = torch.empty_like(s)
+        dgamma = torch.empty(width, dtype=torch.float32, device=s.device)
+        dbeta = torch.empty(width, dtype=torch.float32, device=s.device)
+        ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=s.device)
+        check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                       ptr(ws), rows, width, dt, stream_ptr(s.device)), "hs_add_layernorm_bwd")
+        return dx, dx, dgamma.to(wdt), dbeta.to(bdt)
+
+
+def add_layer_norm(a, b, weight, bias):
+    """returns (a + b, LayerNorm(a + b))"""
+    return AddLayerNormFn.apply(a, b, weight, bias)
+
+
 # ----------------------------------------------------------------------------- Linear with HIP weight gradient
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b with fp32 master parameters and activations in x.dtype.

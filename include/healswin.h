@@ -176,6 +176,17 @@ int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
                      void* dx, float* dgamma, float* dbeta, float* workspace,
                      int64_t rows, int width, int dtype, void* stream);
 
+/* Fused residual add + LayerNorm (v1 norm placement, models_torch/swin_hp_transformer.py:337-338 and :316 of the
+ * following block):   sum = a + b (stored in the activation dtype),  y = LN(sum) * gamma + beta.
+ * Backward: dx = LN_bwd(dy) + dsum, which is the gradient of BOTH a and b (dsum may be NULL: no other consumer of sum);
+ * `sum` is the tensor saved by the forward; workspace as for hs_layernorm_bwd. */
+int hs_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta,
+                         void* sum_out, void* y, float* mean, float* rstd,
+                         int64_t rows, int width, int dtype, void* stream);
+int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma,
+                         const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
+                         int64_t rows, int width, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight / bias gradient of the path's Linear layers (autograd of nn.Linear at
  * models_torch/swin_hp_transformer.py:33,:35 (Mlp), :116,:118 (qkv, proj), :375 (PatchMerging.reduction), :415-416

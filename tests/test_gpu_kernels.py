@@ -243,3 +243,37 @@ def test_linear_wgrad_vs_fp32(rows, n_out, k_in, bias):
         assert float((b.grad - ref_b).abs().max()) <= 2e-4 * max(1.0, float(ref_b.abs().max()))
     ref_dx = (dy.float() @ w.detach().to(torch.bfloat16).float())
     assert_close(xin.grad, ref_dx, 1e-2, "dx")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,width", [(9, 16), (1000, 96), (513, 128), (64, 1024), (50, 100)])
+def test_add_layernorm_vs_oracle(rows, width, dtype):
+    ops, _, _ = _mods()
+    from oracle import model as OM
+    g = torch.Generator().manual_seed(rows + 7 * width)
+    a = torch.randn(rows, width, generator=g) * 2
+    b = torch.randn(rows, width, generator=g)
+    w = 1 + 0.3 * torch.randn(width, generator=g)
+    be = 0.2 * torch.randn(width, generator=g)
+    ds, dy = torch.randn(rows, width, generator=g), torch.randn(rows, width, generator=g)
+
+    ar = a.to(dtype).float().clone().requires_grad_(True)
+    br = b.to(dtype).float().clone().requires_grad_(True)
+    wr, ber = w.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    s_ref = (ar + br)
+    s_round = s_ref + (s_ref.detach().to(dtype).float() - s_ref.detach())  # the kernel normalises the stored (rounded) sum
+    y_ref = OM.layer_norm(s_round, wr, ber)
+    (s_ref * ds.to(dtype).float()).sum().backward(retain_graph=True)
+    (y_ref * dy.to(dtype).float()).sum().backward()
+
+    ad = a.to(DEV).to(dtype).requires_grad_(True)
+    bd = b.to(DEV).to(dtype).requires_grad_(True)
+    wd, bed = w.to(DEV).requires_grad_(True), be.to(DEV).requires_grad_(True)
+    s, y = ops.add_layer_norm(ad, bd, wd, bed)
+    assert_close(s, s_ref, TOL[dtype], "sum")
+    assert_close(y, y_ref, TOL[dtype], "y")
+    torch.autograd.backward([s, y], [ds.to(DEV).to(dtype), dy.to(DEV).to(dtype)])
+    assert_close(ad.grad, ar.grad, GRAD_TOL[dtype], "da")
+    assert torch.equal(ad.grad, bd.grad)
+    assert_close(wd.grad, wr.grad, GRAD_TOL[dtype], "dgamma")
+    assert_close(bed.grad, ber.grad, GRAD_TOL[dtype], "dbeta")
