@@ -11,12 +11,16 @@ struct bf16_t {
 };
 
 __device__ __forceinline__ float bf16_to_float(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-// round-to-nearest-even, NaN preserved (same rounding as torch's float -> bfloat16)
+// round-to-nearest-even (same rounding as torch's float -> bfloat16): one v_cvt_pk_bf16_f32 on gfx950 -- a software
+// RNE sequence costs ~7 VALU ops per value and dominated the attention kernels' instruction count before
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint16_t float_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T>

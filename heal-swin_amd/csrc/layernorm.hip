@@ -38,7 +38,7 @@ struct vec_io<bf16_t, 8> {
     static __device__ __forceinline__ void store(void* p, int64_t i, const float* v) {
         uint32_t w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)float_to_bf16(v[2 * k]) | ((uint32_t)float_to_bf16(v[2 * k + 1]) << 16);
+        for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
         *(uint4*)((uint16_t*)p + i) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

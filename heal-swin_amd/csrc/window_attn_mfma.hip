@@ -46,9 +46,7 @@ __device__ __forceinline__ int vt_row(int d) { return ((d & 7) << 2) + (d >> 3);
 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    return (uint32_t)float_to_bf16(a) | ((uint32_t)float_to_bf16(b) << 16);
-}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
 
 struct LdsLayout {
     // [HG] Q tiles | [HG] K tiles | [HG] transposed V tiles | qinv[HG][64] | labels[64] | flags
@@ -315,11 +313,13 @@ constexpr int kPsLd = 136;                    // bytes per query row of the P / 
 constexpr int kPsBytes = kWs * kPsLd;         // 8704
 
 struct LdsLayoutBwd {
-    // per head: Q | K | V | dO tiles (4096 each), scratch [64][64] bf16 (padded); then per-row scalars
-    int head, scratch_off, qinv, kinv, dsum, lab, total;
+    // per head: Q | K | V | dO tiles (4096 each) | P/dS' scratch [64][64] bf16 (padded) | dq, dk, dv staging (4096 each);
+    // then per-row scalars
+    int head, scratch_off, stage_off, qinv, kinv, dsum, lab, total;
     __host__ __device__ explicit LdsLayoutBwd(int hg) {
         scratch_off = 4 * kTileBytes;
-        head = 4 * kTileBytes + kPsBytes;     // 25088 bytes per head
+        stage_off = scratch_off + kPsBytes;
+        head = stage_off + 3 * kTileBytes;  // 37376 bytes per head
         qinv = hg * head;
         kinv = qinv + hg * kWs * 4;
         dsum = kinv + hg * kWs * 4;
@@ -328,8 +328,7 @@ struct LdsLayoutBwd {
     }
 };
 
-// 8 k-slots (token rows t0..t0+3 and t0+8..t0+11 for half 0/1 handled by the caller) of feature column l&31 from a
-// swizzled row-major [64][32] bf16 tile: two hardware-transposed 8-byte reads
+// 4 token rows x feature column (l&31) from a swizzled row-major [64][32] bf16 tile (hardware-transposed 8-byte read)
 __device__ __forceinline__ s16x4 tr_read_tile(const unsigned char* tile, int row0, int lane) {
     const int L = lane & 15, nblk = (lane >> 4) & 1;
     const int row = row0 + (L >> 2);
@@ -338,7 +337,7 @@ __device__ __forceinline__ s16x4 tr_read_tile(const unsigned char* tile, int row
     const unsigned char* a = tile + row * 64 + (((chunk ^ ((row >> 2) & 3)) << 4) | (byte_in_row & 8));
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
 }
-// the same from the [64 q][64 key] scratch (row stride kPsLd): rows = q (contraction index), columns = key block kb*32..
+// the same from the [64 q][64 key] scratch (row stride kPsLd): rows = q (contraction index), columns = key block colblk*32..
 __device__ __forceinline__ s16x4 tr_read_scratch(const unsigned char* scr, int row0, int colblk, int lane) {
     const int L = lane & 15, nblk = (lane >> 4) & 1;
     const unsigned char* a = scr + (row0 + (L >> 2)) * kPsLd + (colblk * 32 + nblk * 16 + (L & 3) * 4) * 2;
@@ -350,12 +349,17 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// Workgroup = HG heads x 2 waves: wave (g, qt) owns the 32 queries qt*32.. of head g (20 of the head's 40 MFMAs, half of
+// the bias / bias-gradient registers), which fits 2 waves per SIMD.  dQ rows are private to a wave; dV and dK are sums
+// over queries, so the two waves of a head exchange fp32 partials through LDS: wave 1 sends its dV half to wave 0 (into
+// the then-free V/dO tiles), wave 0 its dK half to wave 1 (into the P/dS' scratch).
 template <int HG>
-__global__ void __launch_bounds__(64 * HG) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
-                                                                 float* __restrict__ dscale_part) {
+__global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
+                                                                     float* __restrict__ dscale_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayoutBwd L(HG);
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = wv >> 1, qt = wv & 1;
     const int half = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y * HG + g;
     const int C = p.C;
@@ -375,41 +379,49 @@ __global__ void __launch_bounds__(64 * HG) attn_bwd_mfma_kernel(AttnParams p, fl
     unsigned char* v_tile = my + 2 * kTileBytes;
     unsigned char* do_tile = my + 3 * kTileBytes;
     unsigned char* scr = my + L.scratch_off;
+    unsigned char* stg = my + L.stage_off;  // [dq | dk | dv] row-major [64][32] bf16
     float* qinv_s = (float*)(smem + L.qinv);
     float* kinv_s = (float*)(smem + L.kinv);
     float* dsum_s = (float*)(smem + L.dsum);
     unsigned char* lab_s = smem + L.lab;
+    const int qq = qt * 32 + l31;  // this lane's query
 
-    float biasr[2][2][16], dbacc[2][2][16];
+    float biasr[2][16], dbacc[2][16];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, qq = qt * 32 + l31;
-                biasr[kt][qt][r] = p.bias ? p.bias[((int64_t)h * kWs + qq) * kWs + key] * kLog2e : 0.f;
-                dbacc[kt][qt][r] = 0.f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            biasr[kt][r] = p.bias ? p.bias[((int64_t)h * kWs + qq) * kWs + key] * kLog2e : 0.f;
+            dbacc[kt][r] = 0.f;
+        }
     float dscale_acc = 0.f;
 
+    // staging geometry: 128*HG threads move 32 rows x HG*64 B per pass, 2 passes per tile
     const int srow = tid / (4 * HG), sc = tid % (4 * HG), sg = sc >> 2, scc = sc & 3;
     const int64_t col0 = (int64_t)blockIdx.y * HG * kHd + sc * 8;
-    unsigned char* st = smem + sg * L.head;  // staging target: the head this thread's chunk belongs to
+    unsigned char* st = smem + sg * L.head;
 
     for (int64_t wi = blockIdx.x; wi < total_windows; wi += gridDim.x) {
         const int b = (int)(wi / nW);
         const int w = (int)(wi - (int64_t)b * nW);
         const int64_t j0 = (int64_t)w * kWs;
+        // Per-lane LDS addresses below are loop-invariant; hoisted out of this loop they would pin ~40 VGPRs for the whole
+        // kernel and spill.  An opaque copy of the lane id makes the compiler re-derive them (a few ALU ops) per window.
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int half = lane_o >> 5, l31 = lane_o & 31;
+        const int qq = qt * 32 + l31;
+        const int lane = lane_o;
 
         // ------------------------------------------------------------ stage q, k^, v, dO; D = dO.O; norms
-        int64_t tok[4];
+        int64_t tok[2];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) tok[rb] = (int64_t)b * N + shifted_source(p, j0 + rb * 16 + srow);
+        for (int rb = 0; rb < 2; ++rb) tok[rb] = (int64_t)b * N + shifted_source(p, j0 + rb * 32 + srow);
         if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const int row = rb * 16 + srow;
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = rb * 32 + srow;
             const uint4 vq = *(const uint4*)(qkv + tok[rb] * 3 * C + col0);
             uint4 vk = *(const uint4*)(qkv + tok[rb] * 3 * C + C + col0);
             const uint4 vv = *(const uint4*)(qkv + tok[rb] * 3 * C + 2 * (int64_t)C + col0);
@@ -457,43 +469,34 @@ __global__ void __launch_bounds__(64 * HG) attn_bwd_mfma_kernel(AttnParams p, fl
             for (int i = 0; i < 16; ++i) mixed |= lw[i] != first;
         }
 
-        // ------------------------------------------------------------ S^T = K^ Q^T and dP^T = V dO^T
-        f32x16 accS[2][2], accP[2][2];
+        // ------------------------------------------------------------ S^T = K^ Q^T and dP^T = V dO^T for this wave's 32 queries
+        f32x16 accS[2], accP[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    accS[kt][qt][r] = 0.f;
-                    accP[kt][qt][r] = 0.f;
-                }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 kf[2], qf[2], vf[2], df[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int off = swz(t * 32 + l31, ks * 2 + half);
-                kf[t] = *(const bf16x8*)(k_tile + off);
-                qf[t] = *(const bf16x8*)(q_tile + off);
-                vf[t] = *(const bf16x8*)(v_tile + off);
-                df[t] = *(const bf16x8*)(do_tile + off);
+            for (int r = 0; r < 16; ++r) {
+                accS[kt][r] = 0.f;
+                accP[kt][r] = 0.f;
             }
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 2 + half;
+            const bf16x8 qf = *(const bf16x8*)(q_tile + swz(qq, chunk));
+            const bf16x8 df = *(const bf16x8*)(do_tile + swz(qq, chunk));
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    accS[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qf[qt], accS[kt][qt], 0, 0, 0);
-                    accP[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt], df[qt], accP[kt][qt], 0, 0, 0);
-                }
+            for (int kt = 0; kt < 2; ++kt) {
+                const int off = swz(kt * 32 + l31, chunk);
+                const bf16x8 kf = *(const bf16x8*)(k_tile + off);
+                const bf16x8 vf = *(const bf16x8*)(v_tile + off);
+                accS[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, accS[kt], 0, 0, 0);
+                accP[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df, accP[kt], 0, 0, 0);
+            }
         }
 
-        // ------------------------------------------------------------ P, dS' (fp32), bias / scale gradients; dS' kept in accS
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int qq = qt * 32 + l31;
+        // ------------------------------------------------------------ P, dS' (fp32); bias / scale gradients
+        {
             const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
-            const float fqn = hscale * qinv;                  // d s / d (q . k^)
+            const float fqn = hscale * qinv;  // d s / d (q . k^)
             const float fq2 = fqn * kLog2e;
             const float lse2 = p.lse[((int64_t)b * p.nH + h) * N + j0 + qq] * kLog2e;
             const float dsum = dsum_s[g * kWs + qq];
@@ -502,66 +505,61 @@ __global__ void __launch_bounds__(64 * HG) attn_bwd_mfma_kernel(AttnParams p, fl
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float sraw = accS[kt][qt][r];
-                    float t = fmaf(sraw, fq2, biasr[kt][qt][r]);
+                    const float sraw = accS[kt][r];
+                    float t = fmaf(sraw, fq2, biasr[kt][r]);
                     if (mixed) {
                         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         if (lab_s[key] != mylab) t += kMaskLog2;
                     }
                     const float pr = __builtin_amdgcn_exp2f(t - lse2);
-                    const float dsv = pr * (accP[kt][qt][r] - dsum);
-                    dbacc[kt][qt][r] += dsv;
+                    const float dsv = pr * (accP[kt][r] - dsum);
+                    dbacc[kt][r] += dsv;
                     dscale_acc = fmaf(dsv * qinv, sraw, dscale_acc);
-                    accP[kt][qt][r] = pr;            // P
-                    accS[kt][qt][r] = dsv * fqn;     // dS'
+                    accP[kt][r] = pr;         // P
+                    accS[kt][r] = dsv * fqn;  // dS'
                 }
         }
 
-        // ------------------------------------------------------------ dV = P^T dO   (P through the scratch)
+        // Order chosen for register pressure: X first (its A operand is the dS' registers), then dS' -> scratch -> dK^,
+        // then P -> scratch -> dV; each accumulator set dies before the next one is born.
+        // ------------------------------------------------------------ X = dS' K^ for this wave's 32 query rows
+        {
+            f32x16 dq;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+            for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kt = ks >> 1, c = ks & 1;
+                const int kbase = kt * 32 + c * 16 + 4 * half;
+                const bf16x8 bk = join(tr_read_tile(k_tile, kbase, lane), tr_read_tile(k_tile, kbase + 8, lane));
+                bf16x8 af;
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const uint2 v = make_uint2(pack_bf16(accP[kt][qt][4 * rg], accP[kt][qt][4 * rg + 1]),
-                                               pack_bf16(accP[kt][qt][4 * rg + 2], accP[kt][qt][4 * rg + 3]));
-                    *(uint2*)(scr + (qt * 32 + l31) * kPsLd + (kt * 32 + 8 * rg + 4 * half) * 2) = v;
-                }
-        // (own-wave LDS traffic only: program order suffices, no barrier)
-        f32x16 dv[2], dk[2], dq[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dv[t][r] = 0.f;
-                dk[t][r] = 0.f;
-                dq[t][r] = 0.f;
+                for (int jj = 0; jj < 8; ++jj) af[jj] = (__bf16)accS[kt][8 * c + jj];
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bk, dq, 0, 0, 0);
             }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {  // 16 queries per step: half 0 -> q 16ks..+7, half 1 -> q 16ks+8..+15
-            const int qrow = ks * 16 + 8 * half;
-            const bf16x8 bo = join(tr_read_tile(do_tile, qrow, lane), tr_read_tile(do_tile, qrow + 4, lane));
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 a = join(tr_read_scratch(scr, qrow, kt, lane), tr_read_scratch(scr, qrow + 4, kt, lane));
-                dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bo, dv[kt], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {  // dq rows are private to this wave: straight to the staging tile
+                const int rr = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                *(uint16_t*)(stg + rr * 64 + l31 * 2) = float_to_bf16(dq[r]);
             }
         }
-        // ------------------------------------------------------------ dK^ = dS'^T Q   (dS' through the same scratch)
+        // ------------------------------------------------------------ dK^_partial = dS'^T Q over this wave's queries
+        unsigned char* myrow = scr + qq * kPsLd + 4 * half * 2;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int rg = 0; rg < 4; ++rg)
+                *(uint2*)(myrow + (kt * 32 + 8 * rg) * 2) =
+                    make_uint2(pack_bf16(accS[kt][4 * rg], accS[kt][4 * rg + 1]), pack_bf16(accS[kt][4 * rg + 2], accS[kt][4 * rg + 3]));
+        f32x16 dv[2], dk[2];
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const uint2 v = make_uint2(pack_bf16(accS[kt][qt][4 * rg], accS[kt][qt][4 * rg + 1]),
-                                               pack_bf16(accS[kt][qt][4 * rg + 2], accS[kt][qt][4 * rg + 3]));
-                    *(uint2*)(scr + (qt * 32 + l31) * kPsLd + (kt * 32 + 8 * rg + 4 * half) * 2) = v;
-                }
+        for (int r = 0; r < 16; ++r) {
+            dk[0][r] = 0.f;
+            dk[1][r] = 0.f;
+        }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int qrow = ks * 16 + 8 * half;
+        for (int ks = 0; ks < 2; ++ks) {  // 16 of this wave's queries per step: half 0 -> +0..7, half 1 -> +8..15
+            const int qrow = qt * 32 + ks * 16 + 8 * half;
             const bf16x8 bq = join(tr_read_tile(q_tile, qrow, lane), tr_read_tile(q_tile, qrow + 4, lane));
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
@@ -569,39 +567,71 @@ __global__ void __launch_bounds__(64 * HG) attn_bwd_mfma_kernel(AttnParams p, fl
                 dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, dk[kt], 0, 0, 0);
             }
         }
-        // ------------------------------------------------------------ X = dS' K^   (A from registers, as P.V forward)
+        // ------------------------------------------------------------ dV_partial = P^T dO (same scratch rows, program order)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kt = ks >> 1, c = ks & 1;
-            const int kbase = kt * 32 + c * 16 + 4 * half;
-            const bf16x8 bk = join(tr_read_tile(k_tile, kbase, lane), tr_read_tile(k_tile, kbase + 8, lane));
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                bf16x8 af;
+            for (int rg = 0; rg < 4; ++rg)
+                *(uint2*)(myrow + (kt * 32 + 8 * rg) * 2) =
+                    make_uint2(pack_bf16(accP[kt][4 * rg], accP[kt][4 * rg + 1]), pack_bf16(accP[kt][4 * rg + 2], accP[kt][4 * rg + 3]));
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) af[jj] = (__bf16)accS[kt][qt][8 * c + jj];
-                dq[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bk, dq[qt], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+            dv[0][r] = 0.f;
+            dv[1][r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int qrow = qt * 32 + ks * 16 + 8 * half;
+            const bf16x8 bo = join(tr_read_tile(do_tile, qrow, lane), tr_read_tile(do_tile, qrow + 4, lane));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 a = join(tr_read_scratch(scr, qrow, kt, lane), tr_read_scratch(scr, qrow + 4, kt, lane));
+                dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bo, dv[kt], 0, 0, 0);
             }
         }
 
-        // ------------------------------------------------------------ results -> LDS (row-major [64][32] bf16) -> global
-        // X -> scratch[0:4096), dK^ -> scratch[4096:8192), dV -> the V tile (all private to this wave until the barrier)
+        // ------------------------------------------------------------ exchange the query-sum partials between the head's waves
+        __syncthreads();  // every wave is done with the V / dO tiles and with the scratch
+        float* xch_v = (float*)v_tile;  // 8 KB = V + dO tiles: wave 1 -> wave 0, [kt][r][lane]
+        float* xch_k = (float*)scr;     // 8 KB of the scratch:  wave 0 -> wave 1
+        if (qt == 1) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                *(uint16_t*)(scr + rr * 64 + l31 * 2) = float_to_bf16(dq[t][r]);
-                *(uint16_t*)(scr + kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dk[t][r]);
-                *(uint16_t*)(v_tile + rr * 64 + l31 * 2) = float_to_bf16(dv[t][r]);
-            }
+                for (int r = 0; r < 16; ++r) xch_v[(kt * 16 + r) * 64 + lane] = dv[kt][r];
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch_k[(kt * 16 + r) * 64 + lane] = dk[kt][r];
+        }
         __syncthreads();
+        if (qt == 0) {
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const int row = rb * 16 + srow;
-            uint4 xq = *(const uint4*)(st + L.scratch_off + row * 64 + scc * 16);
-            uint4 xk = *(const uint4*)(st + L.scratch_off + kTileBytes + row * 64 + scc * 16);
-            const uint4 xv = *(const uint4*)(st + 2 * kTileBytes + row * 64 + scc * 16);
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    *(uint16_t*)(stg + 2 * kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dv[kt][r] + xch_v[(kt * 16 + r) * 64 + lane]);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    *(uint16_t*)(stg + kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dk[kt][r] + xch_k[(kt * 16 + r) * 64 + lane]);
+                }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ staged results -> global (cosine: normalisation Jacobian)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = rb * 32 + srow;
+            uint4 xq = *(const uint4*)(st + L.stage_off + row * 64 + scc * 16);
+            uint4 xk = *(const uint4*)(st + L.stage_off + kTileBytes + row * 64 + scc * 16);
+            const uint4 xv = *(const uint4*)(st + L.stage_off + 2 * kTileBytes + row * 64 + scc * 16);
             if (cosine) {  // remove the component along q^ / k^ (gradient through x / |x|)
                 const uint4 rq = *(const uint4*)(st + swz(row, scc));
                 const uint4 rk = *(const uint4*)(st + kTileBytes + swz(row, scc));
@@ -637,21 +667,17 @@ __global__ void __launch_bounds__(64 * HG) attn_bwd_mfma_kernel(AttnParams p, fl
 
     // ------------------------------------------------------------ per-workgroup partial parameter gradients
     if (dbias_part) {
-        float* dst = dbias_part + ((int64_t)blockIdx.x * p.nH + h) * kWs * kWs;
+        float* dst = dbias_part + ((int64_t)blockIdx.x * p.nH + h) * kWs * kWs + (int64_t)qq * kWs;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int key = kt * 32 + 8 * rg + 4 * half, qq = qt * 32 + l31;
-                    *(float4*)(dst + (int64_t)qq * kWs + key) =
-                        make_float4(dbacc[kt][qt][4 * rg], dbacc[kt][qt][4 * rg + 1], dbacc[kt][qt][4 * rg + 2], dbacc[kt][qt][4 * rg + 3]);
-                }
+            for (int rg = 0; rg < 4; ++rg)
+                *(float4*)(dst + kt * 32 + 8 * rg + 4 * half) =
+                    make_float4(dbacc[kt][4 * rg], dbacc[kt][4 * rg + 1], dbacc[kt][4 * rg + 2], dbacc[kt][4 * rg + 3]);
     }
-    if (dscale_part) {
+    if (dscale_part) {  // two waves per head: [slot][head][qt]
         const float tot = wave_sum(dscale_acc);
-        if (lane == 0) dscale_part[(int64_t)blockIdx.x * p.nH + h] = tot;
+        if (lane == 0) dscale_part[((int64_t)blockIdx.x * p.nH + h) * 2 + qt] = tot;
     }
 }
 
@@ -662,6 +688,15 @@ __global__ void reduce_partials_kernel(const float* __restrict__ src, float* __r
     float acc = 0.f;
     for (int s = 0; s < parts; ++s) acc += src[(int64_t)s * n + e];
     dst[e] += acc;
+}
+
+// dhead_scale[h] += sum over slots and the head's two waves of part[slot][h][qt]
+__global__ void reduce_scale_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int slots, int nH) {
+    const int h = threadIdx.x;
+    if (h >= nH) return;
+    float acc = 0.f;
+    for (int s2 = 0; s2 < slots; ++s2) acc += src[((int64_t)s2 * nH + h) * 2] + src[((int64_t)s2 * nH + h) * 2 + 1];
+    dst[h] += acc;
 }
 
 int bwd_slots(const AttnParams& p, int hg) {
@@ -686,7 +721,7 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     const int groups = p.nH / HG, slots = bwd_slots(p, HG);
     float* dbias_part = p.dbias ? workspace : nullptr;
     float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots, (unsigned)groups), dim3(64 * HG), L.total, stream, p, dbias_part, dscale_part);
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots, (unsigned)groups), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part);
     HS_LAUNCH_CHECK("attn_bwd_mfma");
     if (dbias_part) {
         const int64_t n = (int64_t)p.nH * kWs * kWs;
@@ -694,7 +729,7 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
         HS_LAUNCH_CHECK("reduce dbias partials");
     }
     if (dscale_part) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, dscale_part, p.dhead_scale, slots, (int64_t)p.nH);
+        hipLaunchKernelGGL(reduce_scale_partials_kernel, dim3(1), dim3(256), 0, stream, dscale_part, p.dhead_scale, slots, p.nH);
         HS_LAUNCH_CHECK("reduce dscale partials");
     }
     return HS_OK;
@@ -731,7 +766,7 @@ bool attn_mfma_supported(const AttnParams& p, int dtype) {
 
 int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
     const int hg = pick_head_group_bwd(p.nH);
-    return (int64_t)bwd_slots(p, hg) * p.nH * (kWs * kWs + 1);
+    return (int64_t)bwd_slots(p, hg) * p.nH * (kWs * kWs + 2);
 }
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
