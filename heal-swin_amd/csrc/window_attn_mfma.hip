@@ -103,21 +103,31 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p)
     const int sg = sc >> 2, scc = sc & 3;
     const int64_t col0 = (int64_t)blockIdx.y * HG * kHd + sc * 8;  // element column inside a C-wide part
 
+    // software pipeline: the q/k/v rows of window i+1 are in flight (in registers) while window i is computed, so every
+    // workgroup keeps ~HG*12 KB of HBM requests outstanding all the time instead of only during a load phase
+    int64_t tok[4], tok_next[4];
+    uint4 ld[3][4];
+    auto issue_loads = [&](int64_t wi_l) {
+        const int b_l = (int)(wi_l / nW);
+        const int64_t j_l = (wi_l - (int64_t)b_l * nW) * kWs;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) tok_next[rb] = (int64_t)b_l * N + shifted_source(p, j_l + rb * 16 + srow);
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                ld[part][rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + (int64_t)part * C + col0);
+    };
+    if ((int64_t)blockIdx.x < total_windows) issue_loads(blockIdx.x);
+
     for (int64_t wi = blockIdx.x; wi < total_windows; wi += gridDim.x) {
         const int b = (int)(wi / nW);
         const int w = (int)(wi - (int64_t)b * nW);
         const int64_t j0 = (int64_t)w * kWs;
 
-        // ------------------------------------------------------------ stage q, k, v of this window into LDS
-        int64_t tok[4];
+        // ------------------------------------------------------------ stage q, k, v of this window (already loaded) into LDS
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) tok[rb] = (int64_t)b * N + shifted_source(p, j0 + rb * 16 + srow);
-        uint4 ld[3][4];
-#pragma unroll
-        for (int part = 0; part < 3; ++part)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-                ld[part][rb] = *(const uint4*)(qkv + tok[rb] * 3 * C + (int64_t)part * C + col0);
+        for (int rb = 0; rb < 4; ++rb) tok[rb] = tok_next[rb];
         if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
 
 #pragma unroll
@@ -167,6 +177,7 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p)
             }
         }
         __syncthreads();
+        if (wi + gridDim.x < total_windows) issue_loads(wi + gridDim.x);  // prefetch: lands during the MFMAs / softmax below
 
         bool mixed = false;  // does this window contain more than one region label?
         if (p.labels) {
@@ -749,7 +760,7 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
     HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     const int groups = p.nH / HG;
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    int64_t slots = (256 * 3 + groups - 1) / groups;  // ~3 resident workgroups per CU over the whole chip
+    int64_t slots = (256 * 2 + groups - 1) / groups;  // persistent grid = resident workgroups (2 per CU at 256 VGPRs)
     if (slots > windows) slots = windows;
     if (slots < 1) slots = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)slots, (unsigned)groups), dim3(64 * HG), L.total, stream, p);
