@@ -162,19 +162,23 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
     for (int64_t m0 = m_begin; m0 < m_end; m0 += kTok) {
         const bool more = m0 + kTok < m_end;
         if (more) load_regs(m0 + kTok);  // in flight during the MFMAs below
+        // all fragment reads of the stage first: the second half's LDS latency hides under the first half's MFMAs
+        bf16x8 af[2][NB], bf[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int tok0 = ks * 16 + 8 * half;
-            bf16x8 af[NB], bf[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = tr_frag<LDX>(xtile(buf), tok0, wk * 64 + j * 32, lane);
+            for (int j = 0; j < 2; ++j) bf[ks][j] = tr_frag<LDX>(xtile(buf), tok0, wk * 64 + j * 32, lane);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) af[i] = tr_frag<LDY>(ytile(buf), tok0, wn * 32 * NB + i * 32, lane);
+            for (int i = 0; i < NB; ++i) af[ks][i] = tr_frag<LDY>(ytile(buf), tok0, wn * 32 * NB + i * 32, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
         if (more) store_lds(buf ^ 1);
         __syncthreads();
         buf ^= 1;
