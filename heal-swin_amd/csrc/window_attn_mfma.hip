@@ -719,16 +719,21 @@ int bwd_slots(const AttnParams& p, int hg) {
 }
 
 int pick_head_group_bwd(int nH) {
-    if (nH % 2 == 0) return 2;
-    if (nH % 3 == 0) return 3;
-    return 1;
+    // 37 KB of LDS per head: pairs (128-B segments) where the head count allows; a 3-head group would need 112 KB and
+    // leave one workgroup per CU, so odd head counts (nH = 3 at stage 0 of the T model) run one head per workgroup and
+    // let the neighbouring workgroup's half of each 128-B line come from L2
+    return nH % 2 == 0 ? 2 : 1;
 }
 
 template <int HG>
 int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     const LdsLayoutBwd L(HG);
     auto kern = attn_bwd_mfma_kernel<HG>;
-    HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    static bool configured = false;
+    if (!configured) {
+        HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        configured = true;
+    }
     const int groups = p.nH / HG, slots = bwd_slots(p, HG);
     float* dbias_part = p.dbias ? workspace : nullptr;
     float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
@@ -757,7 +762,11 @@ template <int HG>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
     const LdsLayout L(HG);
     auto kern = attn_fwd_mfma_kernel<HG>;
-    HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    static bool configured = false;  // per instantiation; the attribute is a property of the function, set once
+    if (!configured) {
+        HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        configured = true;
+    }
     const int groups = p.nH / HG;
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
     int64_t slots = (256 * 2 + groups - 1) / groups;  // persistent grid = resident workgroups (2 per CU at 256 VGPRs)
@@ -793,7 +802,6 @@ int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stre
     if (!workspace) return fail(HS_ERR_INVALID_ARG, "the MFMA backward needs a workspace (hs_window_attn_bwd_workspace)");
     switch (pick_head_group_bwd(p.nH)) {
         case 2: return launch_bwd<2>(p, workspace, stream);
-        case 3: return launch_bwd<3>(p, workspace, stream);
         default: return launch_bwd<1>(p, workspace, stream);
     }
 }

@@ -123,6 +123,7 @@ class WindowAttention(nn.Module):
             rel = _lib.rel_pos_index(window_size)
             self.register_buffer("relative_position_index", torch.from_numpy(rel))
             self.register_buffer("_rel_idx32", torch.from_numpy(rel.astype(np.int32).reshape(-1)), persistent=False)
+        self._scale_cache = None  # constant per-head scale tensor of the non-cosine variant, built once per device
         self.qkv = HSLinear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = HSLinear(dim, dim)
@@ -135,7 +136,10 @@ class WindowAttention(nn.Module):
         """Per-head multiplier of the raw scores: exp(min(logit_scale, ln 100)) (ref :144-147) or the qk scale."""
         if self.use_cos_attn:
             return torch.exp(torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01))).reshape(-1)
-        return torch.full((self.num_heads,), float(self.scale), dtype=torch.float32, device=self.qkv.weight.device)
+        dev = self.qkv.weight.device
+        if self._scale_cache is None or self._scale_cache.device != dev:
+            self._scale_cache = torch.full((self.num_heads,), float(self.scale), dtype=torch.float32, device=dev)
+        return self._scale_cache
 
     def bias(self):
         if self.rel_pos_bias is None:
