@@ -10,7 +10,7 @@ namespace hs {
 namespace {
 
 constexpr float kLnEps = 1e-5f;  // torch.nn.LayerNorm default, used by every norm in the reference
-constexpr int kBwdMaxBlocks = 512;
+constexpr int kBwdMaxBlocks = 2048;
 
 template <typename T, int VEC>
 struct vec_io;
@@ -256,30 +256,35 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
     }
 }
 
-// sums the per-workgroup partial rows: 32 columns x 8 row slices per workgroup
+// sums the per-workgroup partial rows: 16 columns x 16 row slices per workgroup
 __global__ void __launch_bounds__(256) layernorm_param_reduce_kernel(const float* __restrict__ partials,
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                      int nblocks, int width) {
-    __shared__ float part[8][33];
-    const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + cl;  // over 2*width
+    __shared__ float part[16][17];
+    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;  // over 2*width
     float acc = 0.f;
     if (col < 2 * width)
-        for (int b = slice; b < nblocks; b += 8) acc += partials[(size_t)b * 2 * width + col];
+        for (int b = slice; b < nblocks; b += 16) acc += partials[(size_t)b * 2 * width + col];
     part[slice][cl] = acc;
     __syncthreads();
     if (slice == 0 && col < 2 * width) {
         float tot = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) tot += part[s2][cl];
+        for (int s2 = 0; s2 < 16; ++s2) tot += part[s2][cl];
         if (col < width) dgamma[col] = tot;
         else dbeta[col - width] = tot;
     }
 }
 
+// workgroups of the backward: enough to fill the chip for long inputs, few enough that the partial rows stay cheap
 int bwd_blocks(int64_t rows) {
-    const int64_t want = (rows + 15) / 16;
-    return (int)(want < kBwdMaxBlocks ? (want < 1 ? 1 : want) : kBwdMaxBlocks);
+    int64_t want = rows / 128;
+    if (want < 64) want = 64;
+    if (want > kBwdMaxBlocks) want = kBwdMaxBlocks;
+    const int64_t by_rows = (rows + 15) / 16;
+    if (want > by_rows) want = by_rows;
+    return (int)(want < 1 ? 1 : want);
 }
 
 template <typename T, int VEC, int LPR, int ITERS>
@@ -303,7 +308,7 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     if (smem > 48 * 1024) HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in);
     HS_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 31) / 32), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
+    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
                        width);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
     return HS_OK;
