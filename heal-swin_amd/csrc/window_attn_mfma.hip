@@ -397,23 +397,24 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     unsigned char* lab_s = smem + L.lab;
     const int qq = qt * 32 + l31;  // this lane's query
 
-    float biasr[2][16], dbacc[2][16];
+    // bias gradient of this wave's 32 queries, accumulated over all windows of the launch.  (The bias VALUES are re-read
+    // per window from L2 right before the score MFMAs instead of being pinned in 32 more registers: the backward is at
+    // the 256-VGPR limit of 2 waves/SIMD and spilled with them resident.)
+    float dbacc[2][16];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            biasr[kt][r] = p.bias ? p.bias[((int64_t)h * kWs + qq) * kWs + key] * kLog2e : 0.f;
-            dbacc[kt][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
     float dscale_acc = 0.f;
 
-    // staging geometry: 128*HG threads move 32 rows x HG*64 B per pass, 2 passes per tile
-    const int srow = tid / (4 * HG), sc = tid % (4 * HG), sg = sc >> 2, scc = sc & 3;
-    const int64_t col0 = (int64_t)blockIdx.y * HG * kHd + sc * 8;
-    unsigned char* st = smem + sg * L.head;
-
     for (int64_t wi = blockIdx.x; wi < total_windows; wi += gridDim.x) {
+        // staging geometry: 128*HG threads move 32 rows x HG*64 B per pass, 2 passes per tile.  Derived from an opaque
+        // copy of the thread id inside the loop so that the ~40 VGPRs of per-thread addresses are not hoisted and pinned.
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;
+        const int64_t col0 = (int64_t)blockIdx.y * HG * kHd + sc * 8;
+        unsigned char* st = smem + sg * L.head;
         const int b = (int)(wi / nW);
         const int w = (int)(wi - (int64_t)b * nW);
         const int64_t j0 = (int64_t)w * kWs;
@@ -481,6 +482,13 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         }
 
         // ------------------------------------------------------------ S^T = K^ Q^T and dP^T = V dO^T for this wave's 32 queries
+        float4 biasv[2][4];  // bias[h][qq][kt*32 + 8*rg + 4*half .. +3], in flight during the MFMAs below
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                biasv[kt][rg] = p.bias ? *(const float4*)(p.bias + ((int64_t)h * kWs + qq) * kWs + kt * 32 + 8 * rg + 4 * half)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
         f32x16 accS[2], accP[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -504,6 +512,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             }
         }
 
+        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ P, dS' (fp32); bias / scale gradients
         {
             const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
@@ -517,7 +526,9 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float sraw = accS[kt][r];
-                    float t = fmaf(sraw, fq2, biasr[kt][r]);
+                    const float4 b4 = biasv[kt][r >> 2];
+                    const float bias_r = (r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w;
+                    float t = fmaf(sraw, fq2, bias_r * kLog2e);
                     if (mixed) {
                         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         if (lab_s[key] != mylab) t += kMaskLog2;
@@ -531,6 +542,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 }
         }
 
+        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // Order chosen for register pressure: X first (its A operand is the dS' registers), then dS' -> scratch -> dK^,
         // then P -> scratch -> dV; each accumulator set dies before the next one is born.
         // ------------------------------------------------------------ X = dS' K^ for this wave's 32 query rows
@@ -554,6 +566,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 *(uint16_t*)(stg + rr * 64 + l31 * 2) = float_to_bf16(dq[r]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ dK^_partial = dS'^T Q over this wave's queries
         unsigned char* myrow = scr + qq * kPsLd + 4 * half * 2;
 #pragma unroll
@@ -578,6 +591,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, dk[kt], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ dV_partial = P^T dO (same scratch rows, program order)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -601,6 +615,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             }
         }
 
+        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ exchange the query-sum partials between the head's waves
         __syncthreads();  // every wave is done with the V / dO tiles and with the scratch
         float* xch_v = (float*)v_tile;  // 8 KB = V + dO tiles: wave 1 -> wave 0, [kt][r][lane]
