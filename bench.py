@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-tuned-gemm", action="store_true", help="ignore the shipped TunableOp results for the library GEMMs")
+    ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -181,6 +183,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
+    # Library GEMMs (forward / input-gradient of the Linear layers): load the per-shape hipBLASLt/rocBLAS solution choices
+    # tuned once on an MI355X with PyTorch TunableOp (tuning itself stays OFF here; a validator mismatch -- other ROCm,
+    # other GPU -- makes PyTorch ignore the file and fall back to the library heuristic).
+    tuned = os.path.join(ROOT, "heal-swin_amd", "tuning", f"tunableop_gfx950_{args.workload}_bs{args.batch}_{args.dtype}.csv")
+    if os.path.exists(tuned) and not args.no_tuned_gemm:
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(False)
+        torch.cuda.tunable.set_filename(tuned, insert_device_ordinal=False)
+        torch.cuda.tunable.read_file(tuned)
+
     from heal_swin_amd import ops
     from heal_swin_amd.losses import seg_loss
     from heal_swin_amd.parallel import GradBucketAllReduce
@@ -190,7 +202,7 @@ def main():
     model = model.to(dev).train()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.compute_dtype = dtype
-    dp = GradBucketAllReduce(model.parameters())
+    dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True)  # reference: training/optimizer.py:57-66
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -237,7 +249,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
-                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2), "final_loss": loss_val},
+                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2), "final_loss": loss_val,
+                       "library_gemm_selection": "TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic"},
         }
         if timings:
             agg = {}

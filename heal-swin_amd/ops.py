@@ -221,6 +221,28 @@ def add_layer_norm(a, b, weight, bias):
 
 
 # ----------------------------------------------------------------------------- Linear with HIP weight gradient
+class AsyncWgrad:
+    """Opt-in: run the weight/bias-gradient kernels of every Linear on a SIDE stream and deposit their results straight
+    into the parameters' .grad buffers (which must already exist, e.g. as views into parallel.GradBucketAllReduce's flat
+    buckets, zeroed each step).  Nothing on the backward critical path consumes dW, and the wgrad kernels are MFMA work
+    while much of the rest of backward (LayerNorm, GELU, attention) is HBM-bound, so the two co-schedule on the chip.
+
+    `sink(param)` is called after each deposit is ENQUEUED (bucket bookkeeping); `sync()` makes the current stream wait
+    for everything enqueued so far (call before reading gradients: all-reduce, optimizer step)."""
+
+    def __init__(self, device, sink=None):
+        self.stream = torch.cuda.Stream(device=device)
+        self.sink = sink
+        self.event = torch.cuda.Event()
+
+    def sync(self):
+        cur = torch.cuda.current_stream(self.stream.device)
+        cur.wait_stream(self.stream)
+
+
+ASYNC_WGRAD = None  # an AsyncWgrad instance, or None for plain autograd semantics
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b with fp32 master parameters and activations in x.dtype.
     forward / input gradient: library GEMM; weight + bias gradient (bf16): `hs_linear_wgrad` (split over the token axis,
@@ -232,13 +254,27 @@ class LinearFn(torch.autograd.Function):
         w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
         b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        ctx.bias_dtype = None if bias is None else bias.dtype
+        ctx.bias_param = bias
         return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None):
+        rows = x2.shape[0]
+        dev = x2.device
+        dw32 = dw_out if dw_out is not None else torch.empty((n_out, k_in), dtype=torch.float32, device=dev)
+        db32 = None
+        if want_b:
+            db32 = db_out if db_out is not None else torch.empty(n_out, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=dev)
+        with _timed("linear_wgrad", dev, 2 * rows * (n_out + k_in), 2 * rows * n_out * k_in):
+            check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, _lib.HS_BF16,
+                                      stream_ptr(dev)), "hs_linear_wgrad")
+        return dw32, db32
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        bias = ctx.bias_param
         n_out, k_in = weight.shape
         dy2 = dy.reshape(-1, n_out)
         x2 = x.reshape(-1, k_in)
@@ -248,23 +284,36 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w = weight if weight.dtype == dy.dtype else weight.to(dy.dtype)
             dx = (dy2 @ w).reshape(x.shape)
-        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        if want_w or want_b:
-            rows = x2.shape[0]
-            if x.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and x2.is_contiguous():
-                dw32 = torch.empty((n_out, k_in), dtype=torch.float32, device=x.device)
-                db32 = torch.empty(n_out, dtype=torch.float32, device=x.device) if want_b else None
-                ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=x.device)
-                with _timed("linear_wgrad", x.device, 2 * rows * (n_out + k_in), 2 * rows * n_out * k_in):
-                    check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in,
-                                              _lib.HS_BF16, stream_ptr(x.device)), "hs_linear_wgrad")
-                dw = dw32.to(weight.dtype) if want_w else None
-                db = db32.to(ctx.bias_dtype) if want_b else None
-            else:  # fp32 activations (or odd widths): library GEMM
-                if want_w:
-                    dw = (dy2.t() @ x2).to(weight.dtype)
+        want_w = ctx.needs_input_grad[1]
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        if not (want_w or want_b):
+            return dx, None, None
+        hip_ok = x.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and x2.is_contiguous()
+        aw = ASYNC_WGRAD
+        direct = (aw is not None and hip_ok and want_w and weight.grad is not None and weight.grad.dtype == torch.float32
+                  and weight.grad.is_contiguous() and (not want_b or (bias.grad is not None and bias.grad.dtype == torch.float32)))
+        if direct:
+            # side stream: wait for dy / x, write dW (and db) directly into the parameters' grad buffers
+            cur = torch.cuda.current_stream(x.device)
+            aw.stream.wait_stream(cur)
+            dy2.record_stream(aw.stream)
+            x2.record_stream(aw.stream)
+            with torch.cuda.stream(aw.stream):
+                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, weight.grad, bias.grad if want_b else None)
+            if aw.sink is not None:
+                aw.sink(weight)
                 if want_b:
-                    db = dy2.sum(0).to(ctx.bias_dtype)
+                    aw.sink(bias)
+            return dx, None, None
+        if hip_ok:
+            dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b)
+            dw = dw32.to(weight.dtype) if want_w else None
+            db = db32.to(bias.dtype) if want_b else None
+        else:  # fp32 activations (or odd widths): library GEMM
+            if want_w:
+                dw = (dy2.t() @ x2).to(weight.dtype)
+            if want_b:
+                db = dy2.sum(0).to(bias.dtype)
         return dx, dw, db
 
 

@@ -14,9 +14,10 @@ import torch.distributed as dist
 
 
 class GradBucketAllReduce:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, async_wgrad=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
+        self.async_wgrad = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = []       # flat fp32 tensors
         self._pending = []      # per bucket: number of grads still missing this step
@@ -28,6 +29,12 @@ class GradBucketAllReduce:
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if async_wgrad and self.params and self.params[0].is_cuda:
+            # Linear weight/bias gradients are produced on a side stream straight into the bucket views (ops.AsyncWgrad)
+            from . import ops
+
+            self.async_wgrad = ops.AsyncWgrad(self.params[0].device, sink=self._on_grad if self.world > 1 else None)
+            ops.ASYNC_WGRAD = self.async_wgrad
 
     def _build(self, bucket_bytes):
         order = list(reversed(self.params))
@@ -65,11 +72,15 @@ class GradBucketAllReduce:
         self._pending[b] -= 1
         if self._pending[b] == 0:
             flat = self.buckets[b]
+            if self.async_wgrad is not None:
+                self.async_wgrad.sync()  # gradients deposited from the side stream must have landed before the exchange
             flat.mul_(1.0 / self.world)  # average, as DDP does (gloo has no AVG op)
             self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Wait for every in-flight bucket; call after backward(), before optimizer.step()."""
+        if self.async_wgrad is not None:
+            self.async_wgrad.sync()
         if self.world > 1:
             # parameters that received no gradient this step (unused) still need their bucket exchanged
             for b, left in enumerate(self._pending):
@@ -86,3 +97,9 @@ class GradBucketAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self.async_wgrad is not None:
+            from . import ops
+
+            if ops.ASYNC_WGRAD is self.async_wgrad:
+                ops.ASYNC_WGRAD = None
+            self.async_wgrad = None

@@ -140,3 +140,34 @@ def test_oracle_parity_medium_model_fp32():
     assert_close(y, y_ref, 1e-3, "logits fp32")
     model.compute_dtype = torch.bfloat16
     assert_close(model(x.to(DEV)), y_ref, 3e-2, "logits bf16")
+
+
+def test_async_wgrad_matches_autograd_path():
+    """Side-stream weight gradients deposited straight into the DP bucket views equal the plain autograd result."""
+    M = _M()
+    from heal_swin_amd import ops
+    from heal_swin_amd.data_spec import DataSpec
+    from heal_swin_amd.parallel import GradBucketAllReduce
+    cfg = dict(patch_size=4, window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", embed_dim=64,
+               depths=[2, 2], num_heads=[2, 4], drop_path_rate=0.0)
+    spec = dict(dim_in=12 * 32 * 32, f_in=3, f_out=12, base_pix=12, class_names=[])
+    torch.manual_seed(5)
+    model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), DataSpec(**spec)).to(DEV)
+    model.compute_dtype = torch.bfloat16
+    x = torch.randint(0, 256, (2, 3, spec["dim_in"]), device=DEV).float()
+    grads = {}
+    for mode in (False, True):
+        dp = GradBucketAllReduce(model.parameters(), async_wgrad=mode)
+        assert (ops.ASYNC_WGRAD is not None) == mode
+        for _ in range(2):  # second pass re-uses the zeroed buckets
+            dp.zero_grad()
+            model(x).float().square().mean().backward()
+            dp.finish()
+        torch.cuda.synchronize()
+        grads[mode] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        dp.remove()
+        for p in model.parameters():
+            p.grad = None
+    assert ops.ASYNC_WGRAD is None
+    for n in grads[False]:
+        assert torch.equal(grads[False][n], grads[True][n]), n
