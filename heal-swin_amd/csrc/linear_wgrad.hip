@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
     }
 
     // partial tile -> workspace [slice][n_out][k_in]; accumulator: column = k (lane & 31), rows = n
-    float* dst = part_w + (int64_t)slice * n_out * k_in;
+    float* dst = part_w + (int64_t)slice * ((int64_t)n_out * k_in + n_out);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -205,34 +205,38 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
             float t = 0.f;
 #pragma unroll
             for (int rg = 0; rg < 256 / YCH; ++rg) t += bred[rg * TN + tid];
-            if (n0 + tid < n_out) part_b[(int64_t)slice * n_out + n0 + tid] = t;
+            if (n0 + tid < n_out) part_b[(int64_t)slice * ((int64_t)n_out * k_in + n_out) + n0 + tid] = t;
         }
     }
 }
 
-// out[c][e] = sum over the slices of chunk c (blockIdx.y) of part[s][e]; chunks == 1 writes the final result
-__global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int slices,
-                                                            int64_t n) {
-    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (e >= n) return;
+// Sums the slices of chunk blockIdx.y of the partial records part[s * in_stride + 0..count) (n_w weight entries followed
+// by bias entries).  Intermediate pass (final_pass == 0): out[chunk * count + 0..count).  Final pass: weights to dw, bias
+// to db (skipped if null), added to the existing contents when accumulate != 0.
+__global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int64_t in_stride,
+                                                            float* __restrict__ out, float* __restrict__ dw,
+                                                            float* __restrict__ db, int slices, int64_t n_w, int64_t count,
+                                                            int final_pass, int accumulate) {
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;  // n_w and count are multiples of 4
+    if (e >= count) return;
     const int per = (slices + gridDim.y - 1) / gridDim.y;
     const int s_begin = blockIdx.y * per;
     const int s_end = s_begin + per < slices ? s_begin + per : slices;
-    out += (int64_t)blockIdx.y * n;
-    if (e + 3 < n) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = s_begin; s < s_end; ++s) {
-            const float4 v = *(const float4*)(part + (int64_t)s * n + e);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        *(float4*)(out + e) = acc;
-    } else {
-        for (int64_t i = e; i < n; ++i) {
-            float acc = 0.f;
-            for (int s = s_begin; s < s_end; ++s) acc += part[(int64_t)s * n + i];
-            out[i] = acc;
-        }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = s_begin; s < s_end; ++s) {
+        const float4 v = *(const float4*)(part + (int64_t)s * in_stride + e);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    float* dst;
+    if (!final_pass) dst = out + (int64_t)blockIdx.y * count + e;
+    else if (e < n_w) dst = dw + e;
+    else if (db) dst = db + (e - n_w);
+    else return;
+    if (final_pass && accumulate) {
+        const float4 o = *(const float4*)dst;
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *(float4*)dst = acc;
 }
 
 }  // namespace
@@ -247,19 +251,17 @@ int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in) {
 }
 
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out,
-                    int k_in, int dtype, void* stream) {
+                    int k_in, int accumulate, int dtype, void* stream) {
     using namespace hs;
     HS_CHECK_ARG(dy && x && dw && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && n_out > 0 && k_in > 0, "bad shape");
     if (dtype != HS_BF16) return fail(HS_ERR_UNSUPPORTED, "hs_linear_wgrad implements bf16 activations only");
     if (n_out % 8 || k_in % 8) return fail(HS_ERR_UNSUPPORTED, "n_out and k_in must be multiples of 8 (16-byte rows)");
-    if (((int64_t)n_out * k_in) % 4) return fail(HS_ERR_UNSUPPORTED, "n_out*k_in must be a multiple of 4");
     const Geometry g = make_geometry(rows, n_out, k_in);
-    const int64_t n = (int64_t)n_out * k_in;
+    const int64_t n = (int64_t)n_out * k_in, rec = n + n_out;
     float* part_w = workspace;
-    float* part_b = dbias ? workspace + (int64_t)g.slices * n : nullptr;
-    float* mid_w = workspace + (int64_t)g.slices * (n + n_out);
-    float* mid_b = mid_w + (int64_t)g.chunks * n;
+    float* part_b = dbias ? workspace + n : nullptr;  // bias partials live behind each slice's weight partial
+    float* mid = workspace + (int64_t)g.slices * rec;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.slices * g.tiles));
     if (g.tile_n == 256)
@@ -269,21 +271,19 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
         hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b, rows,
                            n_out, k_in, g);
     HS_LAUNCH_CHECK("linear_wgrad");
-    auto reduce = [&](const float* part, float* mid, float* out, int64_t cnt) -> int {
-        const unsigned bx = (unsigned)((cnt / 4 + 256) / 256);
-        if (g.chunks > 1) {
-            hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, g.chunks), dim3(256), 0, s, part, mid, g.slices, cnt);
-            HS_LAUNCH_CHECK("linear_wgrad reduce 1");
-            hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, mid, out, g.chunks, cnt);
-        } else {
-            hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, part, out, g.slices, cnt);
-        }
-        HS_LAUNCH_CHECK("linear_wgrad reduce");
-        return HS_OK;
-    };
-    if (int st = reduce(part_w, mid_w, dw, n)) return st;
-    if (dbias)
-        if (int st = reduce(part_b, mid_b, dbias, (int64_t)n_out)) return st;
+    const int64_t count = dbias ? rec : n;  // without a bias the tail of each record is never written nor read
+    const unsigned bx = (unsigned)((count / 4 + 255) / 256);
+    if (g.chunks > 1) {
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, g.chunks), dim3(256), 0, s, part_w, rec, mid, nullptr, nullptr, g.slices,
+                           n, count, 0, 0);
+        HS_LAUNCH_CHECK("linear_wgrad reduce 1");
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, mid, count, nullptr, dw, dbias, g.chunks, n, count,
+                           1, accumulate);
+    } else {
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, part_w, rec, nullptr, dw, dbias, g.slices, n, count,
+                           1, accumulate);
+    }
+    HS_LAUNCH_CHECK("linear_wgrad reduce");
     return HS_OK;
 }
 

@@ -240,7 +240,11 @@ class AsyncWgrad:
         cur.wait_stream(self.stream)
 
 
-ASYNC_WGRAD = None  # an AsyncWgrad instance, or None for plain autograd semantics
+ASYNC_WGRAD = None  # an AsyncWgrad instance, or None
+# Direct gradient deposit on the CURRENT stream: when set (True, or a callable notified per parameter), Linear weight/bias
+# gradients are accumulated by the wgrad kernel straight into existing fp32 .grad buffers and autograd sees no gradient for
+# them (post-accumulate hooks do not fire: the callable replaces them).  Set by parallel.GradBucketAllReduce.
+GRAD_SINK = None
 
 
 class LinearFn(torch.autograd.Function):
@@ -259,16 +263,18 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None):
+        """dW (and db) of one Linear.  With dw_out/db_out (existing fp32 .grad buffers) the result is ADDED there."""
         rows = x2.shape[0]
         dev = x2.device
+        accumulate = 1 if dw_out is not None else 0
         dw32 = dw_out if dw_out is not None else torch.empty((n_out, k_in), dtype=torch.float32, device=dev)
         db32 = None
         if want_b:
             db32 = db_out if db_out is not None else torch.empty(n_out, dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=dev)
         with _timed("linear_wgrad", dev, 2 * rows * (n_out + k_in), 2 * rows * n_out * k_in):
-            check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, _lib.HS_BF16,
-                                      stream_ptr(dev)), "hs_linear_wgrad")
+            check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate,
+                                      _lib.HS_BF16, stream_ptr(dev)), "hs_linear_wgrad")
         return dw32, db32
 
     @staticmethod
@@ -290,20 +296,26 @@ class LinearFn(torch.autograd.Function):
             return dx, None, None
         hip_ok = x.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and x2.is_contiguous()
         aw = ASYNC_WGRAD
-        direct = (aw is not None and hip_ok and want_w and weight.grad is not None and weight.grad.dtype == torch.float32
-                  and weight.grad.is_contiguous() and (not want_b or (bias.grad is not None and bias.grad.dtype == torch.float32)))
+        sink = GRAD_SINK if aw is None else aw.sink
+        direct = ((aw is not None or GRAD_SINK is not None) and hip_ok and want_w and weight.grad is not None
+                  and weight.grad.dtype == torch.float32 and weight.grad.is_contiguous()
+                  and (not want_b or (bias.grad is not None and bias.grad.dtype == torch.float32)))
         if direct:
-            # side stream: wait for dy / x, write dW (and db) directly into the parameters' grad buffers
-            cur = torch.cuda.current_stream(x.device)
-            aw.stream.wait_stream(cur)
-            dy2.record_stream(aw.stream)
-            x2.record_stream(aw.stream)
-            with torch.cuda.stream(aw.stream):
+            # accumulate dW (and db) straight into the parameters' .grad buffers (no autograd AccumulateGrad kernels, no
+            # dtype round trip); optionally on the side stream
+            if aw is not None:
+                cur = torch.cuda.current_stream(x.device)
+                aw.stream.wait_stream(cur)
+                dy2.record_stream(aw.stream)
+                x2.record_stream(aw.stream)
+                with torch.cuda.stream(aw.stream):
+                    LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, weight.grad, bias.grad if want_b else None)
+            else:
                 LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, weight.grad, bias.grad if want_b else None)
-            if aw.sink is not None:
-                aw.sink(weight)
+            if callable(sink):
+                sink(weight)
                 if want_b:
-                    aw.sink(bias)
+                    sink(bias)
             return dx, None, None
         if hip_ok:
             dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b)

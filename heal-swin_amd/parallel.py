@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 
 class GradBucketAllReduce:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, async_wgrad=False):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, async_wgrad=False, direct_wgrad=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.async_wgrad = None
@@ -29,6 +29,13 @@ class GradBucketAllReduce:
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._direct = False
+        if direct_wgrad and not async_wgrad and self.params and self.params[0].is_cuda:
+            # Linear weight/bias gradients are accumulated by the wgrad kernel straight into the bucket views
+            from . import ops
+
+            ops.GRAD_SINK = self._on_grad if self.world > 1 else True
+            self._direct = True
         if async_wgrad and self.params and self.params[0].is_cuda:
             # Linear weight/bias gradients are produced on a side stream straight into the bucket views (ops.AsyncWgrad)
             from . import ops
@@ -103,3 +110,8 @@ class GradBucketAllReduce:
             if ops.ASYNC_WGRAD is self.async_wgrad:
                 ops.ASYNC_WGRAD = None
             self.async_wgrad = None
+        if self._direct:
+            from . import ops
+
+            ops.GRAD_SINK = None
+            self._direct = False

@@ -192,13 +192,14 @@ int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, cons
  * models_torch/swin_hp_transformer.py:33,:35 (Mlp), :116,:118 (qkv, proj), :375 (PatchMerging.reduction), :415-416
  * (PatchExpand.expand), :438, :717 (concat_back_dim)):
  *     dw[n, k] = sum_m dy[m, n] * x[m, k]        dbias[n] = sum_m dy[m, n]
- *   dy [dev] bf16[rows, n_out], x [dev] bf16[rows, k_in] (row-major token rows), dw [dev] f32[n_out, k_in] and
- *   dbias [dev] f32[n_out] (may be NULL) are OVERWRITTEN; workspace [dev] f32[hs_linear_wgrad_workspace(...)].
+ *   dy [dev] bf16[rows, n_out], x [dev] bf16[rows, k_in] (row-major token rows); dw [dev] f32[n_out, k_in] and
+ *   dbias [dev] f32[n_out] (may be NULL) are overwritten (accumulate == 0) or added to (accumulate != 0: the
+ *   caller's .grad buffers); workspace [dev] f32[hs_linear_wgrad_workspace(...)].
  * bf16 activations only (HS_BF16); n_out and k_in multiples of 8.  Split over the token axis, deterministic.
  * ---------------------------------------------------------------------------------------------- */
 int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in);
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace,
-                    int64_t rows, int n_out, int k_in, int dtype, void* stream);
+                    int64_t rows, int n_out, int k_in, int accumulate, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

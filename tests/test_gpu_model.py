@@ -142,8 +142,9 @@ def test_oracle_parity_medium_model_fp32():
     assert_close(model(x.to(DEV)), y_ref, 3e-2, "logits bf16")
 
 
-def test_async_wgrad_matches_autograd_path():
-    """Side-stream weight gradients deposited straight into the DP bucket views equal the plain autograd result."""
+def test_direct_and_async_wgrad_match_autograd_path():
+    """Weight gradients accumulated by the wgrad kernel straight into the DP bucket views (current stream, or side stream)
+    equal the plain autograd result bit for bit, also on a second backward into the same (zeroed) buckets."""
     M = _M()
     from heal_swin_amd import ops
     from heal_swin_amd.data_spec import DataSpec
@@ -156,9 +157,9 @@ def test_async_wgrad_matches_autograd_path():
     model.compute_dtype = torch.bfloat16
     x = torch.randint(0, 256, (2, 3, spec["dim_in"]), device=DEV).float()
     grads = {}
-    for mode in (False, True):
-        dp = GradBucketAllReduce(model.parameters(), async_wgrad=mode)
-        assert (ops.ASYNC_WGRAD is not None) == mode
+    for mode, kw in (("autograd", dict(direct_wgrad=False)), ("direct", dict(direct_wgrad=True)), ("async", dict(async_wgrad=True))):
+        dp = GradBucketAllReduce(model.parameters(), **kw)
+        assert (ops.ASYNC_WGRAD is not None) == (mode == "async") and (ops.GRAD_SINK is not None) == (mode == "direct")
         for _ in range(2):  # second pass re-uses the zeroed buckets
             dp.zero_grad()
             model(x).float().square().mean().backward()
@@ -168,6 +169,17 @@ def test_async_wgrad_matches_autograd_path():
         dp.remove()
         for p in model.parameters():
             p.grad = None
-    assert ops.ASYNC_WGRAD is None
-    for n in grads[False]:
-        assert torch.equal(grads[False][n], grads[True][n]), n
+    assert ops.ASYNC_WGRAD is None and ops.GRAD_SINK is None
+    for n in grads["autograd"]:
+        assert torch.equal(grads["autograd"][n], grads["direct"][n]), n
+        assert torch.equal(grads["autograd"][n], grads["async"][n]), n
+    # accumulation semantics: two backwards without zeroing double the gradient
+    dp = GradBucketAllReduce(model.parameters())
+    dp.zero_grad()
+    for _ in range(2):
+        model(x).float().square().mean().backward()
+    dp.finish()
+    torch.cuda.synchronize()
+    w = dict(model.named_parameters())["layers.0.blocks.0.mlp.fc1.weight"]
+    assert_close(w.grad, 2 * grads["autograd"]["layers.0.blocks.0.mlp.fc1.weight"], 1e-5, "accumulate")
+    dp.remove()

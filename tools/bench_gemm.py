@@ -55,7 +55,7 @@ def main():
         tw = t_of(lambda: dy.t() @ x)
         dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
         ws = torch.empty(int(lib.hs_linear_wgrad_workspace(M, N, K)), device="cuda")
-        th = t_of(lambda: check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), M, N, K, 1, None), "wgrad"))
+        th = t_of(lambda: check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), M, N, K, 0, 1, None), "wgrad"))
         hbm = 2.0 * M * (N + K)
         ms = (tf + td + tw) * cnt * 1e3
         tot_t += ms

@@ -16,5 +16,5 @@ dw = torch.empty(N, K, device="cuda")
 db = torch.empty(N, device="cuda")
 ws = torch.empty(int(lib.hs_linear_wgrad_workspace(M, N, K)), device="cuda")
 for _ in range(iters):
-    check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), M, N, K, 1, None), "wgrad")
+    check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), M, N, K, 0, 1, None), "wgrad")
 torch.cuda.synchronize()
