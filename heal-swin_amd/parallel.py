@@ -24,6 +24,7 @@ class GradBucketAllReduce:
         self._counts = []
         self._where = {}        # param -> bucket id
         self._works = []
+        self._seen = set()      # parameters already counted in this step
         self._build(bucket_bytes)
         self._hooks = []
         if self.world > 1:
@@ -73,8 +74,14 @@ class GradBucketAllReduce:
             flat.zero_()
         self._pending = list(self._counts)
         self._works = []
+        self._seen = set()
 
     def _on_grad(self, p):
+        # idempotent per step: a parameter whose gradient is deposited directly by a kernel is announced by the op itself,
+        # and PyTorch may ALSO run its post-accumulate hook (it does, with an undefined gradient)
+        if p in self._seen:
+            return
+        self._seen.add(p)
         b = self._where[p]
         self._pending[b] -= 1
         if self._pending[b] == 0:
