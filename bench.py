@@ -203,7 +203,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.compute_dtype = dtype
     dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True)  # reference: training/optimizer.py:57-66
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)  # reference: training/optimizer.py:57-66 (Adam)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     imgs = torch.randint(0, 256, (args.batch, 3, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)

@@ -259,6 +259,7 @@ class LinearFn(torch.autograd.Function):
         b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
         ctx.save_for_backward(x, weight)
         ctx.bias_param = bias
+        ctx.w_cast = w if w is not weight else None  # activation-dtype copy, reused by the input-gradient GEMM
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -288,8 +289,10 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            w = weight if weight.dtype == dy.dtype else weight.to(dy.dtype)
+            w = ctx.w_cast if (ctx.w_cast is not None and ctx.w_cast.dtype == dy.dtype) else (
+                weight if weight.dtype == dy.dtype else weight.to(dy.dtype))
             dx = (dy2 @ w).reshape(x.shape)
+        ctx.w_cast = None
         want_w = ctx.needs_input_grad[1]
         want_b = bias is not None and ctx.needs_input_grad[2]
         if not (want_w or want_b):
