@@ -31,9 +31,9 @@ _SIGNATURES = {
     "hs_rel_bias_gather": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_rel_bias_scatter_grad": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_window_attn_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
-                           c_int, c_i64, c_int, c_int, c_int, c_uint, c_int, c_ptr],
+                           c_int, c_i64, c_int, c_int, c_int, c_uint, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_window_attn_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
-                           c_int, c_i64, c_int, c_int, c_int, c_uint, c_int, c_ptr],
+                           c_int, c_i64, c_int, c_int, c_int, c_uint, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_gather_rows": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr],
     "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     "hs_layernorm_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],

@@ -21,6 +21,11 @@ struct AttnParams {
     int Ws;
     int hd;
     unsigned flags;
+    // attention dropout (swin_hp_transformer.py:169): probabilities are zeroed with probability drop_p and the survivors
+    // scaled by 1/(1-drop_p); the keep decision of element (image, head, shifted query row, key) is a pure function of
+    // (seed, element index), so the backward regenerates exactly the forward's mask
+    float drop_p;
+    uint32_t seed_lo, seed_hi;
     // backward only
     const void* dout;    // [B, N, C]
     void* dqkv;          // [B, N, 3C]
@@ -34,6 +39,29 @@ __device__ __forceinline__ int64_t shifted_source(const AttnParams& p, int64_t j
     int64_t s = j + p.roll;
     return s >= p.N ? s - p.N : s;
 }
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {  // "lowbias32" integer finaliser
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+struct DropRng {
+    uint32_t row_key, thresh;
+    float keep_scale;
+    // row = ((b * nH + h) * N + shifted_row): one per (image, head, query)
+    __device__ __forceinline__ DropRng(const AttnParams& p, int64_t row) {
+        const uint64_t base = (uint64_t)row * 256u;  // up to 256 keys per window
+        row_key = hash32((uint32_t)(base >> 32) ^ p.seed_hi) ^ p.seed_lo ^ (uint32_t)base;
+        const float pd = p.drop_p;
+        thresh = pd >= 1.f ? 0xffffffffu : (uint32_t)(pd * 4294967296.f);
+        keep_scale = pd >= 1.f ? 0.f : 1.f / (1.f - pd);
+    }
+    // multiplier of probability (row, key): 0 or 1/(1-p)
+    __device__ __forceinline__ float mult(int key) const { return hash32(row_key + (uint32_t)key * 0x9E3779B9u) >= thresh ? keep_scale : 0.f; }
+};
 
 // fp32-VALU path: any Ws in {4,16,64,256}, head_dim <= 128 (fwd) / <= 64 (bwd); fp32 or bf16 I/O
 int launch_attn_fwd_generic(const AttnParams& p, int dtype, hipStream_t stream);

@@ -6,7 +6,7 @@ namespace {
 
 int fill_params(hs::AttnParams& p, const void* qkv, void* out, float* lse, const float* bias, const float* head_scale,
                 const int32_t* idx, int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens, int channels,
-                int num_heads, int window_size, unsigned flags, int dtype) {
+                int num_heads, int window_size, unsigned flags, float attn_drop, uint64_t seed, int dtype) {
     HS_CHECK_ARG(qkv && out && head_scale, "qkv, out and head_scale must not be null");
     HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
     HS_CHECK_ARG(batch > 0 && n_tokens > 0 && channels > 0 && num_heads > 0, "non-positive size");
@@ -18,7 +18,11 @@ int fill_params(hs::AttnParams& p, const void* qkv, void* out, float* lse, const
     HS_CHECK_ARG(n_tokens % window_size == 0, "n_tokens %lld not divisible by window_size %d", (long long)n_tokens, window_size);
     HS_CHECK_ARG(window_size >= 4, "window_size must be at least 4");
     HS_CHECK_ARG(roll >= 0 && roll < n_tokens, "roll must be in [0, n_tokens)");
+    HS_CHECK_ARG(attn_drop >= 0.f && attn_drop <= 1.f, "attn_drop must be in [0, 1]");
     p = hs::AttnParams{};
+    p.drop_p = attn_drop;
+    p.seed_lo = (uint32_t)seed;
+    p.seed_hi = (uint32_t)(seed >> 32);
     p.qkv = qkv;
     p.out = out;
     p.lse = lse;
@@ -43,10 +47,11 @@ extern "C" {
 
 int hs_window_attn_fwd(const void* qkv, void* out, float* lse, const float* bias, const float* head_scale,
                        const int32_t* idx, int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens,
-                       int channels, int num_heads, int window_size, unsigned flags, int dtype, void* stream) {
+                       int channels, int num_heads, int window_size, unsigned flags, float attn_drop, uint64_t seed, int dtype,
+                       void* stream) {
     hs::AttnParams p;
     if (int st = fill_params(p, qkv, out, lse, bias, head_scale, idx, roll, labels, batch, n_tokens, channels, num_heads,
-                             window_size, flags, dtype))
+                             window_size, flags, attn_drop, seed, dtype))
         return st;
     hipStream_t s = (hipStream_t)stream;
     if (hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_fwd_mfma(p, s);
@@ -68,10 +73,10 @@ int64_t hs_window_attn_bwd_workspace(int batch, int64_t n_tokens, int channels, 
 int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
                        float* dhead_scale, float* workspace, const float* bias, const float* head_scale, const int32_t* idx,
                        int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens, int channels, int num_heads,
-                       int window_size, unsigned flags, int dtype, void* stream) {
+                       int window_size, unsigned flags, float attn_drop, uint64_t seed, int dtype, void* stream) {
     hs::AttnParams p;
     if (int st = fill_params(p, qkv, const_cast<void*>(out), const_cast<float*>(lse), bias, head_scale, idx, roll, labels,
-                             batch, n_tokens, channels, num_heads, window_size, flags, dtype))
+                             batch, n_tokens, channels, num_heads, window_size, flags, attn_drop, seed, dtype))
         return st;
     HS_CHECK_ARG(dout && dqkv && lse, "dout, dqkv and lse must not be null");
     HS_CHECK_ARG(!bias || dbias, "dbias must be given when bias is");

@@ -73,6 +73,8 @@ __global__ void __launch_bounds__(256) attn_fwd_generic_kernel(AttnParams p) {
     float o[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    const bool dropping = p.drop_p > 0.f;
+    const DropRng rng(p, ((int64_t)b * p.nH + h) * p.N + j);
 
     for (int j0 = 0; j0 < Ws; j0 += 4) {
         float s[4];
@@ -95,10 +97,11 @@ __global__ void __launch_bounds__(256) attn_fwd_generic_kernel(AttnParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float e = expf(s[u] - m_new);
-            l += e;
+            l += e;  // the softmax denominator is not affected by dropout
+            const float ed = dropping ? e * rng.mult(j0 + u) : e;
             const float* vr = v_s + (t0 + j0 + u) * LD;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) o[d] = fmaf(e, vr[d], o[d]);
+            for (int d = 0; d < HD; ++d) o[d] = fmaf(ed, vr[d], o[d]);
         }
         m = m_new;
     }
@@ -190,6 +193,8 @@ __global__ void __launch_bounds__(256) attn_bwd_generic_kernel(AttnParams p) {
                 dq[d] = 0.f;
             }
             const float my_lse = lse_s[t], my_dsum = dsum_s[t];
+            const bool dropping = p.drop_p > 0.f;
+            const DropRng rng(p, ((int64_t)b * p.nH + h) * p.N + j);
             const float* bias_row = p.bias ? p.bias + ((int64_t)h * Ws + i) * Ws : nullptr;
             float* dbias_row = p.dbias ? p.dbias + ((int64_t)h * Ws + i) * Ws : nullptr;
             for (int jj = 0; jj < Ws; ++jj) {
@@ -205,6 +210,7 @@ __global__ void __launch_bounds__(256) attn_bwd_generic_kernel(AttnParams p) {
                 if (bias_row) s += bias_row[jj];
                 if (lab_s[t0 + jj] != my_lab) s += kMaskValue;
                 const float pr = expf(s - my_lse);
+                if (dropping) dp *= rng.mult(jj);  // d(out)/d(P) passes through the mask
                 const float ds = pr * (dp - my_dsum);
                 const float dsk = ds * hscale;
 #pragma unroll
@@ -235,6 +241,8 @@ __global__ void __launch_bounds__(256) attn_bwd_generic_kernel(AttnParams p) {
                 dv[d] = 0.f;
             }
             const float* bias_col = p.bias ? p.bias + (int64_t)h * Ws * Ws + i : nullptr;
+            const bool dropping = p.drop_p > 0.f;
+            const int64_t row0 = ((int64_t)b * p.nH + h) * p.N + (j - i);  // first query row of this window
             for (int ii = 0; ii < Ws; ++ii) {
                 const float* qr = q_s + (t0 + ii) * LD;
                 const float* dor = do_s + (t0 + ii) * LD;
@@ -248,12 +256,18 @@ __global__ void __launch_bounds__(256) attn_bwd_generic_kernel(AttnParams p) {
                 if (bias_col) s += bias_col[(int64_t)ii * Ws];
                 if (lab_s[t0 + ii] != my_lab) s += kMaskValue;
                 const float pr = expf(s - lse_s[t0 + ii]);
+                float prd = pr;  // dropped probability (what multiplied V in the forward)
+                if (dropping) {
+                    const float mlt = DropRng(p, row0 + ii).mult(i);
+                    dp *= mlt;
+                    prd *= mlt;
+                }
                 const float ds = pr * (dp - dsum_s[t0 + ii]);
                 const float dsq = ds * hscale;
 #pragma unroll
                 for (int d = 0; d < HD; ++d) {
                     dk[d] = fmaf(dsq, qr[d], dk[d]);
-                    dv[d] = fmaf(pr, dor[d], dv[d]);
+                    dv[d] = fmaf(prd, dor[d], dv[d]);
                 }
             }
             if (cosine) {

@@ -62,7 +62,7 @@ struct LdsLayout {
     }
 };
 
-template <int HG>
+template <int HG, bool DROP>
 __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L(HG);
@@ -253,10 +253,19 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p)
                 }
             l += __shfl_xor(l, 32, 64);
             const float linv = 1.f / l;
+            if constexpr (DROP) {  // attention dropout on the normalised probabilities (train mode only)
+                const DropRng rng(p, ((int64_t)b * p.nH + h) * N + j0 + qq);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv;
+                    for (int r = 0; r < 16; ++r)
+                        acc[kt][qt][r] *= linv * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv;
+            }
             if (p.lse && half == 0) p.lse[((int64_t)b * p.nH + h) * N + j0 + qq] = (m + __builtin_amdgcn_logf(l)) * kLn2;
         }
 
@@ -364,7 +373,7 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
 // the bias / bias-gradient registers), which fits 2 waves per SIMD.  dQ rows are private to a wave; dV and dK are sums
 // over queries, so the two waves of a head exchange fp32 partials through LDS: wave 1 sends its dV half to wave 0 (into
 // the then-free V/dO tiles), wave 0 its dK half to wave 1 (into the P/dS' scratch).
-template <int HG>
+template <int HG, bool DROP>
 __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
                                                                      float* __restrict__ dscale_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -521,6 +530,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             const float lse2 = p.lse[((int64_t)b * p.nH + h) * N + j0 + qq] * kLog2e;
             const float dsum = dsum_s[g * kWs + qq];
             const int mylab = mixed ? lab_s[qq] : 0;
+            const DropRng rng(p, ((int64_t)b * p.nH + h) * N + j0 + qq);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -534,10 +544,16 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                         if (lab_s[key] != mylab) t += kMaskLog2;
                     }
                     const float pr = __builtin_amdgcn_exp2f(t - lse2);
-                    const float dsv = pr * (accP[kt][r] - dsum);
+                    float dpv = accP[kt][r], prd = pr;
+                    if constexpr (DROP) {  // the forward multiplied V by P o mask/(1-p): regenerate the same mask
+                        const float mlt = rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                        dpv *= mlt;
+                        prd *= mlt;
+                    }
+                    const float dsv = pr * (dpv - dsum);
                     dbacc[kt][r] += dsv;
                     dscale_acc = fmaf(dsv * qinv, sraw, dscale_acc);
-                    accP[kt][r] = pr;         // P
+                    accP[kt][r] = prd;        // (dropped) P, the operand of dV
                     accS[kt][r] = dsv * fqn;  // dS'
                 }
         }
@@ -740,10 +756,10 @@ int pick_head_group_bwd(int nH) {
     return nH % 2 == 0 ? 2 : 1;
 }
 
-template <int HG>
+template <int HG, bool DROP>
 int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     const LdsLayoutBwd L(HG);
-    auto kern = attn_bwd_mfma_kernel<HG>;
+    auto kern = attn_bwd_mfma_kernel<HG, DROP>;
     static bool configured = false;
     if (!configured) {
         HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -773,10 +789,10 @@ int pick_head_group(int nH) {
     return 1;
 }
 
-template <int HG>
+template <int HG, bool DROP>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
     const LdsLayout L(HG);
-    auto kern = attn_fwd_mfma_kernel<HG>;
+    auto kern = attn_fwd_mfma_kernel<HG, DROP>;
     static bool configured = false;  // per instantiation; the attribute is a property of the function, set once
     if (!configured) {
         HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -805,19 +821,21 @@ int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
 }
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
+    const bool drop = p.drop_p > 0.f;
     switch (pick_head_group(p.nH)) {
-        case 4: return launch_fwd<4>(p, stream);
-        case 3: return launch_fwd<3>(p, stream);
-        case 2: return launch_fwd<2>(p, stream);
-        default: return launch_fwd<1>(p, stream);
+        case 4: return drop ? launch_fwd<4, true>(p, stream) : launch_fwd<4, false>(p, stream);
+        case 3: return drop ? launch_fwd<3, true>(p, stream) : launch_fwd<3, false>(p, stream);
+        case 2: return drop ? launch_fwd<2, true>(p, stream) : launch_fwd<2, false>(p, stream);
+        default: return drop ? launch_fwd<1, true>(p, stream) : launch_fwd<1, false>(p, stream);
     }
 }
 
 int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream) {
     if (!workspace) return fail(HS_ERR_INVALID_ARG, "the MFMA backward needs a workspace (hs_window_attn_bwd_workspace)");
+    const bool drop = p.drop_p > 0.f;
     switch (pick_head_group_bwd(p.nH)) {
-        case 2: return launch_bwd<2>(p, workspace, stream);
-        default: return launch_bwd<1>(p, workspace, stream);
+        case 2: return drop ? launch_bwd<2, true>(p, workspace, stream) : launch_bwd<2, false>(p, workspace, stream);
+        default: return drop ? launch_bwd<1, true>(p, workspace, stream) : launch_bwd<1, false>(p, workspace, stream);
     }
 }
 

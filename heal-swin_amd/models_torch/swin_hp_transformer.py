@@ -148,13 +148,12 @@ class WindowAttention(nn.Module):
 
     def attend(self, x, window_size, idx, roll, labels):
         """x: [B, N, C] in natural order -> attention branch output [B, N, C] in natural order."""
-        if self.training and self.attn_drop.p > 0.0:
-            raise NotImplementedError("attn_drop_rate > 0 in training mode is not implemented in the fused attention kernel")
+        drop = self.attn_drop.p if self.training else 0.0  # dropout on the attention probabilities (ref :169), in-kernel
         if self.rel_pos_bias is not None and window_size != self.window_size:
             raise AssertionError("relative position bias needs input_resolution >= window_size")  # ref quirk :243-251
         qkv = self.qkv(x)
         o = ops.window_attn_core(qkv, self.bias(), self.head_scale(), idx, roll, labels, self.num_heads, window_size,
-                                 self.use_cos_attn)
+                                 self.use_cos_attn, attn_drop=drop)
         return self.proj_drop(self.proj(o))
 
     def forward(self, x, mask=None):

@@ -83,7 +83,7 @@ class WindowAttnCoreFn(torch.autograd.Function):
     on the un-shifted qkv tensor (reference swin_hp_transformer.py:319-330 around :136-171)."""
 
     @staticmethod
-    def forward(ctx, qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine):
+    def forward(ctx, qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, attn_drop=0.0, seed=0):
         _require_gpu(qkv, bias, head_scale, idx, labels)
         B, N, C3 = qkv.shape
         C = C3 // 3
@@ -99,10 +99,12 @@ class WindowAttnCoreFn(torch.autograd.Function):
         # algorithmic traffic: q,k,v read + o written once; flops: QK^T and PV, 2*Ws*hd each per (row, head)
         with _timed("window_attn_fwd", qkv.device, 4 * B * N * C * qkv.element_size(), 4 * B * N * C * window_size):
             check(lib.hs_window_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(bias_c), ptr(hs), ptr(idx), int(roll), ptr(labels),
-                                         B, N, C, num_heads, window_size, flags, dt, stream_ptr(qkv.device)),
+                                         B, N, C, num_heads, window_size, flags, float(attn_drop), int(seed), dt,
+                                         stream_ptr(qkv.device)),
                   "hs_window_attn_fwd")
         ctx.save_for_backward(qkv, out, lse, bias_c, hs, idx, labels)
         ctx.args = (B, N, C, num_heads, window_size, flags, dt, int(roll))
+        ctx.drop = (float(attn_drop), int(seed))
         ctx.bias_dtype = None if bias is None else bias.dtype
         ctx.scale_meta = (head_scale.dtype, head_scale.shape)
         return out
@@ -121,16 +123,21 @@ class WindowAttnCoreFn(torch.autograd.Function):
         with _timed("window_attn_bwd", qkv.device, 8 * B * N * C * qkv.element_size(), 10 * B * N * C * ws):
             check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale), ptr(wsp),
                                          ptr(bias_c), ptr(hs), ptr(idx), roll, ptr(labels),
-                                         B, N, C, nh, ws, flags, dt, stream_ptr(qkv.device)),
+                                         B, N, C, nh, ws, flags, ctx.drop[0], ctx.drop[1], dt, stream_ptr(qkv.device)),
                   "hs_window_attn_bwd")
         dbias_out = None if dbias is None else dbias.to(ctx.bias_dtype)
         sdt, sshape = ctx.scale_meta
         dscale_out = dscale.to(sdt).reshape(sshape) if (flags & _lib.HS_ATTN_COSINE) else None
-        return dqkv, dbias_out, dscale_out, None, None, None, None, None, None
+        return dqkv, dbias_out, dscale_out, None, None, None, None, None, None, None, None
 
 
-def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine):
-    return WindowAttnCoreFn.apply(qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine)
+def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, attn_drop=0.0, seed=None):
+    """attn_drop > 0 applies the reference's dropout on the attention probabilities; `seed` (64-bit) fixes the mask,
+    by default it is drawn from torch's CPU generator (so torch.manual_seed makes runs repeatable)."""
+    if attn_drop > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return WindowAttnCoreFn.apply(qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine,
+                                  float(attn_drop), int(seed or 0))
 
 
 # ----------------------------------------------------------------------------- row LayerNorm (+ residual)

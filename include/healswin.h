@@ -115,6 +115,10 @@ int hs_rel_bias_scatter_grad(const float* dbias, const int32_t* rel_idx, float* 
  *                         (j + roll) mod N   (roll = 0: NoShift; roll = shift_size: NestRollShift)
  *   labels [dev] uint8[N] region labels in shifted order, or NULL (no mask; unshifted blocks)
  *   flags  HS_ATTN_COSINE or 0
+ *   attn_drop, seed  attention dropout of :169 (self.attn_drop on the probabilities): each probability is zeroed with
+ *                    probability attn_drop, survivors scaled by 1/(1-attn_drop); the mask is a pure function of
+ *                    (seed, image, head, query, key), so hs_window_attn_bwd called with the same seed reproduces it.
+ *                    attn_drop = 0 (eval mode / p = 0) disables it.
  * Supported: Ws in {4,16,64,256}, Ws <= N, N % Ws == 0, head_dim in {1,2,4,8,16,32,64,128}.
  * (Ws = 64, head_dim = 32, bf16 takes the MFMA path; everything else the fp32-VALU path.)
  */
@@ -122,7 +126,7 @@ int hs_window_attn_fwd(const void* qkv, void* out, float* lse,
                        const float* bias, const float* head_scale,
                        const int32_t* idx, int64_t roll, const uint8_t* labels,
                        int batch, int64_t n_tokens, int channels, int num_heads, int window_size,
-                       unsigned flags, int dtype, void* stream);
+                       unsigned flags, float attn_drop, uint64_t seed, int dtype, void* stream);
 
 /* Backward of the above.
  *   dout   [dev] dtype[B, N, C]   gradient w.r.t. `out`
@@ -140,7 +144,7 @@ int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
                        const float* bias, const float* head_scale,
                        const int32_t* idx, int64_t roll, const uint8_t* labels,
                        int batch, int64_t n_tokens, int channels, int num_heads, int window_size,
-                       unsigned flags, int dtype, void* stream);
+                       unsigned flags, float attn_drop, uint64_t seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Standalone shift along the nested pixel axis: out[b, j, :] = x[b, idx[j], :]  (idx NULL: roll,

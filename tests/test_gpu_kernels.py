@@ -277,3 +277,72 @@ def test_add_layernorm_vs_oracle(rows, width, dtype):
     assert torch.equal(ad.grad, bd.grad)
     assert_close(wd.grad, wr.grad, GRAD_TOL[dtype], "dgamma")
     assert_close(bed.grad, ber.grad, GRAD_TOL[dtype], "dbeta")
+
+
+# ----------------------------------------------------------------------------- attention dropout (ref :169)
+@pytest.mark.parametrize("dtype,C,nH,Ws", [(torch.bfloat16, 128, 4, 64), (torch.float32, 64, 2, 64), (torch.float32, 48, 3, 16)])
+def test_attention_dropout_statistics_and_adjoint(dtype, C, nH, Ws):
+    ops, _, _ = _mods()
+    B, N, p_drop, seed = 2, 4096, 0.25, 1234567
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(B, N, 3 * C, generator=g, device=DEV).to(dtype)
+    hs = torch.full((nH,), 0.2, device=DEV)
+    f = lambda t, s=seed, pd=p_drop: ops.window_attn_core(t, None, hs, None, 0, None, nH, Ws, False, attn_drop=pd, seed=s)
+    # 1. uniform probabilities (q = 0) and V = 1: every output is (#kept keys / Ws) / (1 - p)
+    u = qkv.clone()
+    u[:, :, :C] = 0
+    u[:, :, 2 * C:] = 1
+    o = f(u).float()
+    assert abs(float(o.mean()) - 1.0) < 0.01
+    expect_std = (p_drop / (Ws * (1 - p_drop))) ** 0.5
+    assert abs(float(o.std()) - expect_std) < 0.15 * expect_std + 5e-3
+    # 2. reproducible for a seed, different for another, and p = 0 is the plain op
+    assert torch.equal(f(qkv), f(qkv))
+    assert not torch.equal(f(qkv), f(qkv, seed + 1))
+    assert torch.equal(f(qkv, seed, 0.0), ops.window_attn_core(qkv, None, hs, None, 0, None, nH, Ws, False))
+    # 3. adjoint identity: out is linear in V for a fixed mask, so <dO, out(V)> == <dV, V> iff the backward regenerates
+    #    exactly the forward's mask
+    x = qkv.clone().requires_grad_(True)
+    out = f(x)
+    dO = torch.randn_like(out)
+    out.backward(dO)
+    lhs = float((dO.float() * out.float()).sum())
+    rhs = float((x.grad[:, :, 2 * C:].float() * qkv[:, :, 2 * C:].float()).sum())
+    assert abs(lhs - rhs) <= 2e-2 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert torch.isfinite(x.grad.float()).all()
+
+
+def test_attention_dropout_mask_is_path_independent():
+    """The MFMA kernels (bf16) and the fp32-VALU kernels draw the same mask for the same seed."""
+    ops, _, _ = _mods()
+    B, N, C, nH, Ws = 1, 2048, 64, 2, 64
+    g = torch.Generator(device=DEV).manual_seed(9)
+    qkv = torch.randn(B, N, 3 * C, generator=g, device=DEV).to(torch.bfloat16)
+    hs = torch.full((nH,), 0.2, device=DEV)
+    dO = torch.randn(B, N, C, device=DEV).to(torch.bfloat16)
+    res = []
+    for t in (qkv, qkv.float()):
+        x = t.clone().requires_grad_(True)
+        o = ops.window_attn_core(x, None, hs, None, 0, None, nH, Ws, False, attn_drop=0.3, seed=77)
+        o.backward(dO.to(t.dtype))
+        res.append((o.float(), x.grad.float()))
+    assert_close(res[0][0], res[1][0], 1e-2, "out")
+    assert_close(res[0][1], res[1][1], 3e-2, "dqkv")
+
+
+def test_window_attention_module_dropout_train_vs_eval():
+    _, M, _ = _mods()
+    torch.manual_seed(0)
+    wa = M.WindowAttention(96, 64, 3, rel_pos_bias="flat", attn_drop=0.1, proj_drop=0.0).to(DEV)
+    x = torch.randn(4, 64, 96, device=DEV)
+    wa.eval()
+    y_eval = wa(x)
+    wa2 = M.WindowAttention(96, 64, 3, rel_pos_bias="flat", attn_drop=0.0).to(DEV)
+    wa2.load_state_dict(wa.state_dict())
+    assert torch.equal(y_eval, wa2(x))  # eval mode: dropout is the identity
+    wa.train()
+    xt = x.clone().requires_grad_(True)
+    y = wa(xt)
+    assert not torch.equal(y, y_eval)
+    y.square().mean().backward()
+    assert torch.isfinite(xt.grad).all() and float(xt.grad.abs().sum()) > 0
