@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--paper-drop-rates", action="store_true",
+                    help="train with the paper's drop_rate = attn_drop_rate = drop_path_rate = 0.1 instead of 0")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="ignore the shipped TunableOp results for the library GEMMs")
     ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
     args = ap.parse_args()
@@ -198,6 +200,9 @@ def main():
     from heal_swin_amd.parallel import GradBucketAllReduce
 
     wl = WORKLOADS[args.workload]
+    if args.paper_drop_rates:
+        wl = dict(wl, cfg=dict(wl["cfg"], drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1),
+                  name=wl["name"] + " drop 0.1/0.1/0.1")
     model, cfg, spec = build_model(wl)
     model = model.to(dev).train()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
