@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (fwd + loss + bwd + Adam) in one HIP graph and replay it (single GPU, no "
+                         "dropout); removes host launch latency, which dominates the small workloads")
     ap.add_argument("--paper-drop-rates", action="store_true",
                     help="train with the paper's drop_rate = attn_drop_rate = drop_path_rate = 0.1 instead of 0")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="ignore the shipped TunableOp results for the library GEMMs")
@@ -208,7 +211,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.compute_dtype = dtype
     dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)  # reference: training/optimizer.py:57-66 (Adam)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=args.graph)  # ref: training/optimizer.py:57-66
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     imgs = torch.randint(0, 256, (args.batch, 3, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
@@ -231,6 +234,20 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if args.graph:
+        if world > 1 or args.paper_drop_rates:
+            raise SystemExit("--graph supports single-GPU runs without dropout (collectives / host-drawn dropout seeds are not captured)")
+        eager_step = step
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = eager_step()
+
+        def step():  # noqa: F811
+            graph.replay()
+            return static_loss
+
+        step()
+        sync()
     if not args.no_kernel_timing:
         ops.KERNEL_TIMINGS = []
     t0 = time.perf_counter()
@@ -254,6 +271,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
+                       "launch": "hip graph replay" if args.graph else "eager",
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2), "final_loss": loss_val,
                        "library_gemm_selection": "TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic"},
         }
