@@ -1,0 +1,173 @@
+// y = dropout(GELU(x)) and its backward, elementwise over the MLP hidden tensor (exact erf GELU: nn.GELU default, reference
+// Mlp.forward, models_torch/swin_hp_transformer.py:39-41: fc1 -> act -> drop).  HBM-bound: one read + one write forward,
+// two reads + one write backward, 16-byte vectors; the dropout mask (train mode, drop_rate > 0) is a pure function of
+// (seed, element index) and is regenerated in the backward, so it costs no extra pass and no mask tensor.
+#include "hs_device.h"
+
+namespace hs {
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+struct ElemRng {
+    uint32_t key_lo, key_hi, thresh;
+    float keep_scale;
+    __device__ __forceinline__ ElemRng(float p, uint64_t seed) {
+        key_lo = (uint32_t)seed;
+        key_hi = (uint32_t)(seed >> 32);
+        thresh = p >= 1.f ? 0xffffffffu : (uint32_t)(p * 4294967296.f);
+        keep_scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
+    }
+    __device__ __forceinline__ float mult(int64_t i) const {
+        const uint32_t h = mix32((uint32_t)i ^ key_lo ^ mix32((uint32_t)((uint64_t)i >> 32) ^ key_hi));
+        return h >= thresh ? keep_scale : 0.f;
+    }
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+
+template <typename T>
+struct vec;
+template <>
+struct vec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const void* p, int64_t i, float* v) {
+        const uint4 t = *(const uint4*)((const uint16_t*)p + i);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(w[k] << 16);
+            v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(void* p, int64_t i, const float* v) {
+        *(uint4*)((uint16_t*)p + i) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                 pack_bf16x2(v[6], v[7]));
+    }
+};
+template <>
+struct vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const void* p, int64_t i, float* v) {
+        const float4 t = *(const float4*)((const float*)p + i);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(void* p, int64_t i, const float* v) {
+        *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
+template <typename T, bool DROP>
+__global__ void __launch_bounds__(256) gelu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n, float p,
+                                                       uint64_t seed) {
+    constexpr int V = vec<T>::N;
+    const ElemRng rng(p, seed);
+    const int64_t nvec = n / V;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nvec; c += (int64_t)gridDim.x * blockDim.x) {
+        float v[V];
+        vec<T>::load(x, c * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            v[k] = gelu_f(v[k]);
+            if (DROP) v[k] *= rng.mult(c * V + k);
+        }
+        vec<T>::store(y, c * V, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * V) {  // tail (n not a multiple of the vector width)
+        const int64_t i = nvec * V + threadIdx.x;
+        float g = gelu_f(io<T>::load(x, i));
+        if (DROP) g *= rng.mult(i);
+        io<T>::store(y, i, g);
+    }
+}
+
+template <typename T, bool DROP>
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                       void* __restrict__ dx, int64_t n, float p, uint64_t seed) {
+    constexpr int V = vec<T>::N;
+    const ElemRng rng(p, seed);
+    const int64_t nvec = n / V;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nvec; c += (int64_t)gridDim.x * blockDim.x) {
+        float v[V], g[V];
+        vec<T>::load(x, c * V, v);
+        vec<T>::load(dy, c * V, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float d = g[k] * gelu_grad_f(v[k]);
+            if (DROP) d *= rng.mult(c * V + k);
+            v[k] = d;
+        }
+        vec<T>::store(dx, c * V, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * V) {
+        const int64_t i = nvec * V + threadIdx.x;
+        float d = io<T>::load(dy, i) * gelu_grad_f(io<T>::load(x, i));
+        if (DROP) d *= rng.mult(i);
+        io<T>::store(dx, i, d);
+    }
+}
+
+inline unsigned grid_for(int64_t n, int v) {
+    int64_t b = (n / v + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+}  // namespace hs
+
+extern "C" {
+
+int hs_gelu_fwd(const void* x, void* y, int64_t n, float drop_p, uint64_t seed, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(x && y && n >= 0, "bad arguments");
+    HS_CHECK_ARG(drop_p >= 0.f && drop_p <= 1.f, "drop_p must be in [0, 1]");
+    HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
+    HS_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "buffers must be 16-byte aligned");
+    if (n == 0) return HS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool drop = drop_p > 0.f;
+    if (dtype == HS_BF16) {
+        if (drop) hipLaunchKernelGGL((gelu_fwd_kernel<bf16_t, true>), dim3(grid_for(n, 8)), dim3(256), 0, s, x, y, n, drop_p, seed);
+        else hipLaunchKernelGGL((gelu_fwd_kernel<bf16_t, false>), dim3(grid_for(n, 8)), dim3(256), 0, s, x, y, n, drop_p, seed);
+    } else {
+        if (drop) hipLaunchKernelGGL((gelu_fwd_kernel<float, true>), dim3(grid_for(n, 4)), dim3(256), 0, s, x, y, n, drop_p, seed);
+        else hipLaunchKernelGGL((gelu_fwd_kernel<float, false>), dim3(grid_for(n, 4)), dim3(256), 0, s, x, y, n, drop_p, seed);
+    }
+    HS_LAUNCH_CHECK("gelu_fwd");
+    return HS_OK;
+}
+
+int hs_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, float drop_p, uint64_t seed, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(dy && x && dx && n >= 0, "bad arguments");
+    HS_CHECK_ARG(drop_p >= 0.f && drop_p <= 1.f, "drop_p must be in [0, 1]");
+    HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
+    HS_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0), "buffers must be 16-byte aligned");
+    if (n == 0) return HS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool drop = drop_p > 0.f;
+    if (dtype == HS_BF16) {
+        if (drop) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, true>), dim3(grid_for(n, 8)), dim3(256), 0, s, dy, x, dx, n, drop_p, seed);
+        else hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, false>), dim3(grid_for(n, 8)), dim3(256), 0, s, dy, x, dx, n, drop_p, seed);
+    } else {
+        if (drop) hipLaunchKernelGGL((gelu_bwd_kernel<float, true>), dim3(grid_for(n, 4)), dim3(256), 0, s, dy, x, dx, n, drop_p, seed);
+        else hipLaunchKernelGGL((gelu_bwd_kernel<float, false>), dim3(grid_for(n, 4)), dim3(256), 0, s, dy, x, dx, n, drop_p, seed);
+    }
+    HS_LAUNCH_CHECK("gelu_bwd");
+    return HS_OK;
+}
+
+}  // extern "C"

@@ -89,7 +89,13 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        h = self.fc1(x)
+        if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
+            # activation and the dropout behind it in one HIP pass (mask regenerated in backward)
+            a = ops.gelu_dropout(h, self.drop.p if self.training else 0.0)
+        else:
+            a = self.drop(self.act(h))
+        return self.drop(self.fc2(a))
 
 
 # ----------------------------------------------------------------------------- attention

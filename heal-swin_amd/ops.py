@@ -227,6 +227,42 @@ def add_layer_norm(a, b, weight, bias):
     return AddLayerNormFn.apply(a, b, weight, bias)
 
 
+# ----------------------------------------------------------------------------- GELU (+ dropout)
+def _draw_seed():
+    """64-bit seed from torch's CPU generator (repeatable under torch.manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class GeluDropoutFn(torch.autograd.Function):
+    """y = dropout(gelu(x), p) in one pass; the backward regenerates the mask from the seed (reference Mlp :39-41)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        dt = _lib.dtype_code(x.dtype)
+        check(lib.hs_gelu_fwd(ptr(x), ptr(y), x.numel(), float(p), int(seed), dt, stream_ptr(x.device)), "hs_gelu_fwd")
+        ctx.save_for_backward(x)
+        ctx.meta = (float(p), int(seed), dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        p, seed, dt = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.hs_gelu_bwd(ptr(dy), ptr(x), ptr(dx), x.numel(), p, seed, dt, stream_ptr(x.device)), "hs_gelu_bwd")
+        return dx, None, None
+
+
+def gelu_dropout(x, p=0.0, seed=None):
+    if p > 0.0 and seed is None:
+        seed = _draw_seed()
+    return GeluDropoutFn.apply(x, float(p), int(seed or 0))
+
+
 # ----------------------------------------------------------------------------- Linear with HIP weight gradient
 class AsyncWgrad:
     """Opt-in: run the weight/bias-gradient kernels of every Linear on a SIDE stream and deposit their results straight

@@ -192,6 +192,15 @@ int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, cons
                          int64_t rows, int width, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * y = dropout(GELU(x)) (exact erf GELU) and its backward dx = dy * mask/(1-p) * GELU'(x): the activation and the
+ * dropout behind it in Mlp.forward (models_torch/swin_hp_transformer.py:39-41) in one pass.  drop_p = 0 (eval) is plain
+ * GELU.  The mask is a pure function of (seed, element index): pass the forward's seed to the backward.
+ * x, y, dy, dx [dev] dtype[n], 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_gelu_fwd(const void* x, void* y, int64_t n, float drop_p, uint64_t seed, int dtype, void* stream);
+int hs_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, float drop_p, uint64_t seed, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Weight / bias gradient of the path's Linear layers (autograd of nn.Linear at
  * models_torch/swin_hp_transformer.py:33,:35 (Mlp), :116,:118 (qkv, proj), :375 (PatchMerging.reduction), :415-416
  * (PatchExpand.expand), :438, :717 (concat_back_dim)):
