@@ -7,30 +7,6 @@
 namespace hs {
 namespace {
 
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x7feb352dU;
-    x ^= x >> 15;
-    x *= 0x846ca68bU;
-    x ^= x >> 16;
-    return x;
-}
-
-struct ElemRng {
-    uint32_t key_lo, key_hi, thresh;
-    float keep_scale;
-    __device__ __forceinline__ ElemRng(float p, uint64_t seed) {
-        key_lo = (uint32_t)seed;
-        key_hi = (uint32_t)(seed >> 32);
-        thresh = p >= 1.f ? 0xffffffffu : (uint32_t)(p * 4294967296.f);
-        keep_scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
-    }
-    __device__ __forceinline__ float mult(int64_t i) const {
-        const uint32_t h = mix32((uint32_t)i ^ key_lo ^ mix32((uint32_t)((uint64_t)i >> 32) ^ key_hi));
-        return h >= thresh ? keep_scale : 0.f;
-    }
-};
-
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));

@@ -36,6 +36,32 @@ struct io<bf16_t> {
     static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = float_to_bf16(v); }
 };
 
+// Counter-based dropout mask shared by the elementwise kernels: the keep decision of element i is a pure function of
+// (seed, i), so a backward pass regenerates the forward's mask instead of reading a mask tensor.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // "lowbias32" integer finaliser
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+struct ElemRng {
+    uint32_t key_lo, key_hi, thresh;
+    float keep_scale;
+    __device__ __forceinline__ ElemRng(float p, uint64_t seed) {
+        key_lo = (uint32_t)seed;
+        key_hi = (uint32_t)(seed >> 32);
+        thresh = p >= 1.f ? 0xffffffffu : (uint32_t)(p * 4294967296.f);
+        keep_scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
+    }
+    // multiplier of element i: 0 (dropped) or 1/(1-p)
+    __device__ __forceinline__ float mult(int64_t i) const {
+        const uint32_t h = mix32((uint32_t)i ^ key_lo ^ mix32((uint32_t)((uint64_t)i >> 32) ^ key_hi));
+        return h >= thresh ? keep_scale : 0.f;
+    }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -70,7 +70,14 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             void* __restrict__ y, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int64_t rows, int width,
-                                                            const void* __restrict__ add_in, void* __restrict__ sum_out) {
+                                                            const void* __restrict__ add_in, void* __restrict__ sum_out,
+                                                            const float* __restrict__ row_scale, int64_t rows_per_sample,
+                                                            float drop_p, uint64_t seed) {
+    // Stochastic extras (train mode).  With add_in (v1):  s = x + rs * drop(add_in),  y = LN(s).
+    // Without (v2 / plain):                               y = [residual +] rs * LN(drop(x)).
+    // rs = row_scale[row / rows_per_sample] is the per-sample DropPath factor, drop() the counter-based dropout mask.
+    const bool dropping = drop_p > 0.f;
+    const ElemRng rng(drop_p, seed);
     constexpr int RPW = 64 / LPR;  // rows per wave
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsub = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -81,6 +88,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
         const int64_t row = row0 + rsub;
         const bool live = row < rows;
         const int64_t base = row * width;
+        const float rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
         float v[ITERS][VEC];
         float sum = 0.f;
 #pragma unroll
@@ -88,12 +96,19 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, v[it]);
-                if (add_in) {  // s = x + add_in, rounded to the activation dtype exactly as a separate add would store it
+                if (add_in) {  // s = x + rs*drop(add_in), rounded to the activation dtype exactly as a separate add would store it
                     float a2[VEC];
                     vec_io<T, VEC>::load(add_in, base + (int64_t)c * VEC, a2);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) v[it][k] = round_to<T>(v[it][k] + a2[k]);
+                    for (int k = 0; k < VEC; ++k) {
+                        float add = a2[k] * rs;
+                        if (dropping) add *= rng.mult(base + (int64_t)c * VEC + k);
+                        v[it][k] = round_to<T>(v[it][k] + add);
+                    }
                     vec_io<T, VEC>::store(sum_out, base + (int64_t)c * VEC, v[it]);
+                } else if (dropping) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) v[it][k] *= rng.mult(base + (int64_t)c * VEC + k);
                 }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) sum += v[it][k];
@@ -128,6 +143,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     o[k] = fmaf((v[it][k] - mean) * rstd, g[k], b[k]);
+                    if (!add_in) o[k] *= rs;  // v2: DropPath scales the normalised branch
                     if (residual) o[k] += r[k];
                 }
                 vec_io<T, VEC>::store(y, base + (int64_t)c * VEC, o);
@@ -148,7 +164,14 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, void* __restrict__ dx,
                                                             float* __restrict__ partials, int64_t rows, int width,
-                                                            const void* __restrict__ dres_in) {
+                                                            const void* __restrict__ dres_in, void* __restrict__ dadd_out,
+                                                            const float* __restrict__ row_scale, int64_t rows_per_sample,
+                                                            float drop_p, uint64_t seed, int v1_mode) {
+    // v1_mode (fused add + LN, `x` is the saved sum s):  g = LN_bwd(dy) + dres_in;  dx = g;  dadd_out = rs * mask * g.
+    // otherwise (`x` is the raw input, LN saw u = mask * x, the output was rs * LN(u)):
+    //            dy_eff = rs * dy;  dx = mask * LN_bwd(dy_eff)  (dgamma / dbeta use dy_eff).
+    const bool dropping = drop_p > 0.f;
+    const ElemRng rng(drop_p, seed);
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][width]
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -173,6 +196,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
         const bool live = row < rows;
         const int64_t base = row * width;
         const float mean = live ? mean_in[row] : 0.f, rstd = live ? rstd_in[row] : 0.f;
+        const float rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
         float xh[ITERS][VEC], g[ITERS][VEC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -184,6 +208,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
                 vec_io<T, VEC>::load(dy, base + (int64_t)c * VEC, dyv);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
+                    if (!v1_mode) {
+                        dyv[k] *= rs;
+                        if (dropping) xh[it][k] *= rng.mult(base + (int64_t)c * VEC + k);
+                    }
                     xh[it][k] = (xh[it][k] - mean) * rstd;
                     g[it][k] = dyv[k] * gm[it][k];
                     s1 += g[it][k];
@@ -207,7 +235,24 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) o[k] += d2[k];
                 }
-                vec_io<T, VEC>::store(dx, base + (int64_t)c * VEC, o);
+                if (v1_mode) {
+                    vec_io<T, VEC>::store(dx, base + (int64_t)c * VEC, o);
+                    if (dadd_out) {  // gradient of the added operand: through DropPath scale and dropout mask
+                        float o2[VEC];
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            o2[k] = o[k] * rs;
+                            if (dropping) o2[k] *= rng.mult(base + (int64_t)c * VEC + k);
+                        }
+                        vec_io<T, VEC>::store(dadd_out, base + (int64_t)c * VEC, o2);
+                    }
+                } else {
+                    if (dropping) {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) o[k] *= rng.mult(base + (int64_t)c * VEC + k);
+                    }
+                    vec_io<T, VEC>::store(dx, base + (int64_t)c * VEC, o);
+                }
             }
         }
     }
@@ -287,26 +332,35 @@ int bwd_blocks(int64_t rows) {
     return (int)(want < 1 ? 1 : want);
 }
 
+struct LnExtra {  // stochastic extras, all optional
+    const float* row_scale = nullptr;
+    int64_t rows_per_sample = 1;
+    float drop_p = 0.f;
+    uint64_t seed = 0;
+};
+
 template <typename T, int VEC, int LPR, int ITERS>
 int run_fwd(const void* x, const void* res, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t rows,
-            int width, hipStream_t s, const void* add_in, void* sum_out) {
+            int width, hipStream_t s, const void* add_in, void* sum_out, const LnExtra& ex) {
     constexpr int rows_per_block = 4 * (64 / LPR);
     int64_t blocks = (rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, VEC, LPR, ITERS>), dim3((unsigned)blocks), dim3(256), 0, s, x, res, g, b, y,
-                       mean, rstd, rows, width, add_in, sum_out);
+                       mean, rstd, rows, width, add_in, sum_out, ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed);
     HS_LAUNCH_CHECK("layernorm_fwd");
     return HS_OK;
 }
 
 template <typename T, int VEC, int LPR, int ITERS>
 int run_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
-            float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in) {
+            float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in, void* dadd_out,
+            const LnExtra& ex, int v1_mode) {
     const int blocks = bwd_blocks(rows);
     const size_t smem = (size_t)3 * 2 * width * sizeof(float);
     auto kern = layernorm_bwd_kernel<T, VEC, LPR, ITERS>;
     if (smem > 48 * 1024) HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in, dadd_out,
+                       ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed, v1_mode);
     HS_LAUNCH_CHECK("layernorm_bwd");
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
                        width);
@@ -337,41 +391,59 @@ int with_shape(int width, F&& f) {
 
 namespace {
 
+int check_extra(const hs::LnExtra& ex, int64_t rows) {
+    HS_CHECK_ARG(ex.drop_p >= 0.f && ex.drop_p <= 1.f, "drop_p must be in [0, 1]");
+    HS_CHECK_ARG(!ex.row_scale || (ex.rows_per_sample > 0 && rows % ex.rows_per_sample == 0), "rows must be a multiple of rows_per_sample");
+    return HS_OK;
+}
+
 int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                int64_t rows, int width, int dtype, void* stream, const void* add_in, void* sum_out) {
+                int64_t rows, int width, int dtype, void* stream, const void* add_in, void* sum_out, const hs::LnExtra& ex) {
     using namespace hs;
     HS_CHECK_ARG(x && gamma && beta && y, "null pointer");
     HS_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "mean and rstd must both be given or both be null");
     HS_CHECK_ARG((add_in == nullptr) == (sum_out == nullptr), "add_in and sum_out go together");
     HS_CHECK_ARG(rows >= 0 && width > 0, "bad shape");
     HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
+    if (int st = check_extra(ex, rows)) return st;
     if (rows == 0) return HS_OK;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
         if (width % 8 == 0)
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
-        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
+        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
     }
     if (width % 4 == 0)
-        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd<float, 4, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
-    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_fwd<float, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd<float, 4, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
+    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_fwd<float, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
 }
 
 int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
-                float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream, const void* dres_in) {
+                float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream, const void* dres_in,
+                void* dadd_out, const hs::LnExtra& ex, int v1_mode) {
     using namespace hs;
     HS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && width > 0, "bad shape");
     HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
+    if (int st = check_extra(ex, rows)) return st;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
         if (width % 8 == 0)
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
-        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
+        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
     }
     if (width % 4 == 0)
-        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd<float, 4, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
-    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_bwd<float, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd<float, 4, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
+    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_bwd<float, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
+}
+
+hs::LnExtra make_extra(const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed) {
+    hs::LnExtra ex;
+    ex.row_scale = row_scale;
+    ex.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+    ex.drop_p = drop_p;
+    ex.seed = seed;
+    return ex;
 }
 
 }  // namespace
@@ -380,26 +452,60 @@ extern "C" {
 
 int hs_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, float* mean,
                      float* rstd, int64_t rows, int width, int dtype, void* stream) {
-    return ln_fwd_impl(x, residual, gamma, beta, y, mean, rstd, rows, width, dtype, stream, nullptr, nullptr);
+    return ln_fwd_impl(x, residual, gamma, beta, y, mean, rstd, rows, width, dtype, stream, nullptr, nullptr, hs::LnExtra{});
 }
 
 int hs_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* sum_out, void* y,
                          float* mean, float* rstd, int64_t rows, int width, int dtype, void* stream) {
     HS_CHECK_ARG(b && sum_out, "null pointer");
-    return ln_fwd_impl(a, nullptr, gamma, beta, y, mean, rstd, rows, width, dtype, stream, b, sum_out);
+    return ln_fwd_impl(a, nullptr, gamma, beta, y, mean, rstd, rows, width, dtype, stream, b, sum_out, hs::LnExtra{});
 }
 
 int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) { return (int64_t)hs::bwd_blocks(rows) * 2 * width; }
 
 int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream) {
-    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, nullptr);
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, nullptr, nullptr,
+                       hs::LnExtra{}, 0);
 }
 
 int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
                          const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows, int width,
                          int dtype, void* stream) {
-    return ln_bwd_impl(dy, sum, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, dsum);
+    return ln_bwd_impl(dy, sum, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, dsum, nullptr,
+                       hs::LnExtra{}, 1);
+}
+
+/* train-mode variants: dropout (drop_p, seed) and per-sample DropPath scale (row_scale[rows / rows_per_sample]) fused in */
+int hs_layernorm_drop_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, float* mean,
+                          float* rstd, const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed,
+                          int64_t rows, int width, int dtype, void* stream) {
+    return ln_fwd_impl(x, residual, gamma, beta, y, mean, rstd, rows, width, dtype, stream, nullptr, nullptr,
+                       make_extra(row_scale, rows_per_sample, drop_p, seed));
+}
+
+int hs_layernorm_drop_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                          float* dgamma, float* dbeta, float* workspace, const float* row_scale, int64_t rows_per_sample,
+                          float drop_p, uint64_t seed, int64_t rows, int width, int dtype, void* stream) {
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, nullptr, nullptr,
+                       make_extra(row_scale, rows_per_sample, drop_p, seed), 0);
+}
+
+int hs_add_layernorm_drop_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* sum_out, void* y,
+                              float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample, float drop_p,
+                              uint64_t seed, int64_t rows, int width, int dtype, void* stream) {
+    HS_CHECK_ARG(b && sum_out, "null pointer");
+    return ln_fwd_impl(a, nullptr, gamma, beta, y, mean, rstd, rows, width, dtype, stream, b, sum_out,
+                       make_extra(row_scale, rows_per_sample, drop_p, seed));
+}
+
+int hs_add_layernorm_drop_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
+                              const float* rstd, void* da, void* db, float* dgamma, float* dbeta, float* workspace,
+                              const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed, int64_t rows,
+                              int width, int dtype, void* stream) {
+    HS_CHECK_ARG(db, "null pointer");
+    return ln_bwd_impl(dy, sum, gamma, mean, rstd, da, dgamma, dbeta, workspace, rows, width, dtype, stream, dsum, db,
+                       make_extra(row_scale, rows_per_sample, drop_p, seed), 1);
 }
 
 }  // extern "C"

@@ -39,20 +39,13 @@ EMIT_REFERENCE_BUFFERS = True  # state_dict() carries the reference's `attn_mask
 class HSLayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters, HIP kernel arithmetic (`hs_layernorm_fwd/bwd`)."""
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, row_scale=None, drop_p=0.0):
         assert self.elementwise_affine and len(self.normalized_shape) == 1 and abs(self.eps - 1e-5) < 1e-12
-        return ops.layer_norm(x, self.weight, self.bias, residual)
+        return ops.layer_norm(x, self.weight, self.bias, residual, row_scale=row_scale, drop_p=drop_p)
 
 
 def _make_norm(norm_layer, dim):
     return HSLayerNorm(dim) if norm_layer is nn.LayerNorm else norm_layer(dim)
-
-
-def _norm_plus(norm, x, residual):
-    """residual + norm(x): one fused kernel for the HIP LayerNorm, two steps for foreign norm layers."""
-    if isinstance(norm, HSLayerNorm):
-        return norm(x, residual=residual)
-    return residual + norm(x)
 
 
 class HSLinear(nn.Linear):
@@ -70,12 +63,18 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
 
-    def forward(self, x):
+    def sample_scale(self, batch, device):
+        """Per-sample factor (0 or 1/keep) of one application, or None when inactive; the fused kernels take it as a [B] vector."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
+            return None
         keep = 1.0 - self.drop_prob
-        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
-        return x * (mask / keep)
+        return torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
+    def forward(self, x):
+        rs = self.sample_scale(x.shape[0], x.device)
+        if rs is None:
+            return x
+        return x * rs.to(x.dtype).view((x.shape[0],) + (1,) * (x.dim() - 1))
 
 
 class Mlp(nn.Module):
@@ -88,14 +87,15 @@ class Mlp(nn.Module):
         self.fc2 = HSLinear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x):
+    def forward(self, x, apply_out_drop=True):
         h = self.fc1(x)
         if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
             # activation and the dropout behind it in one HIP pass (mask regenerated in backward)
             a = ops.gelu_dropout(h, self.drop.p if self.training else 0.0)
         else:
             a = self.drop(self.act(h))
-        return self.drop(self.fc2(a))
+        y = self.fc2(a)
+        return self.drop(y) if apply_out_drop else y  # the caller fuses the output dropout into the next norm kernel
 
 
 # ----------------------------------------------------------------------------- attention
@@ -152,7 +152,7 @@ class WindowAttention(nn.Module):
             return None
         return ops.RelPosBiasFn.apply(self.relative_position_bias_table, self._rel_idx32, self.window_size)
 
-    def attend(self, x, window_size, idx, roll, labels):
+    def attend(self, x, window_size, idx, roll, labels, apply_proj_drop=True):
         """x: [B, N, C] in natural order -> attention branch output [B, N, C] in natural order."""
         drop = self.attn_drop.p if self.training else 0.0  # dropout on the attention probabilities (ref :169), in-kernel
         if self.rel_pos_bias is not None and window_size != self.window_size:
@@ -160,7 +160,8 @@ class WindowAttention(nn.Module):
         qkv = self.qkv(x)
         o = ops.window_attn_core(qkv, self.bias(), self.head_scale(), idx, roll, labels, self.num_heads, window_size,
                                  self.use_cos_attn, attn_drop=drop)
-        return self.proj_drop(self.proj(o))
+        y = self.proj(o)
+        return self.proj_drop(y) if apply_proj_drop else y  # the caller fuses proj_drop into the next norm kernel
 
     def forward(self, x, mask=None):
         """Reference-compatible entry: x [num_windows*B, Ws, C], mask [nW, Ws, Ws] in {0,-100} or None."""
@@ -229,42 +230,67 @@ class SwinTransformerBlock(nn.Module):
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "
                 f"window_size={self.window_size}, shift_size={self.shift_size}, mlp_ratio={self.mlp_ratio}")
 
-    def _attention_branch(self, x):
+    def _attention_branch(self, x, apply_proj_drop=True):
         if not self._shifted:
-            return self.attn.attend(x, self.window_size, None, 0, None)
+            return self.attn.attend(x, self.window_size, None, 0, None, apply_proj_drop)
         idx, _, labels = self.shifter.tables(x.device)
         if self._is_roll:  # modular offset instead of a table
-            return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels)
-        return self.attn.attend(x, self.window_size, idx, 0, labels)
+            return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels, apply_proj_drop)
+        return self.attn.attend(x, self.window_size, idx, 0, labels, apply_proj_drop)
+
+    def _hs_norms(self):
+        return isinstance(self.norm1, HSLayerNorm) and isinstance(self.norm2, HSLayerNorm)
+
+    def _path_scale(self, x):
+        """per-sample DropPath factor of one branch ([B] tensor) or None"""
+        return self.drop_path.sample_scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
 
     def can_defer(self):
-        """v1 placement without active stochastic depth: both residual adds can be fused into the following LayerNorm."""
-        return (not self.use_v2_norm_placement and isinstance(self.norm1, HSLayerNorm) and isinstance(self.norm2, HSLayerNorm)
-                and (isinstance(self.drop_path, nn.Identity) or not self.training))
+        """v1 placement with the HIP norms: both residual adds -- together with the dropout / DropPath on the added branch --
+        ride on the LayerNorm kernel that consumes the sum."""
+        return not self.use_v2_norm_placement and self._hs_norms()
 
     def forward_deferred(self, x, pending):
-        """v1 block on the input `x + pending` (pending may be None); returns (x1, m) with the block output = x1 + m.
-        Every residual add rides on the LayerNorm kernel that consumes its result (ref :337-338, :316)."""
+        """v1 block on the input `x + rs*drop(p)` for pending = (p, rs, drop_p) (or None); returns (x1, pending') with the
+        block output = x1 + rs'*drop(m) (ref :337-338 and :316 of the next block)."""
+        train = self.training
         if pending is None:
             n1 = self.norm1(x)
         else:
-            x, n1 = ops.add_layer_norm(x, pending, self.norm1.weight, self.norm1.bias)
-        a = self._attention_branch(n1)
-        x1, n2 = ops.add_layer_norm(x, a, self.norm2.weight, self.norm2.bias)
-        return x1, self.mlp(n2)
+            t, rs, dp = pending
+            x, n1 = ops.add_layer_norm(x, t, self.norm1.weight, self.norm1.bias, row_scale=rs, drop_p=dp)
+        a = self._attention_branch(n1, apply_proj_drop=False)
+        x1, n2 = ops.add_layer_norm(x, a, self.norm2.weight, self.norm2.bias, row_scale=self._path_scale(x),
+                                    drop_p=self.attn.proj_drop.p if train else 0.0)
+        m = self.mlp(n2, apply_out_drop=False)
+        return x1, (m, self._path_scale(x), self.mlp.drop.p if train else 0.0)
+
+    @staticmethod
+    def resolve_pending(x, pending):
+        """x + rs*drop(p): the standalone form of a deferred residual (end of a stage)."""
+        if pending is None:
+            return x
+        t, rs, dp = pending
+        if dp:
+            t = F.dropout(t, dp, True)
+        if rs is not None:
+            t = t * rs.to(t.dtype).view(-1, 1, 1)
+        return x + t
 
     def forward(self, x):
         B, N, C = x.shape
         assert N == self.input_resolution, f"expected {self.input_resolution} tokens, got {N}"
         if self.can_defer():
-            x1, m = self.forward_deferred(x, None)
-            return x1 + m
-        plain_path = isinstance(self.drop_path, nn.Identity) or not self.training
-        if self.use_v2_norm_placement:  # ref :334-335
-            a = self._attention_branch(x)
-            x = _norm_plus(self.norm1, a, x) if plain_path else x + self.drop_path(self.norm1(a))
-            m = self.mlp(x)
-            return _norm_plus(self.norm2, m, x) if plain_path else x + self.drop_path(self.norm2(m))
+            return self.resolve_pending(*self.forward_deferred(x, None))
+        train = self.training
+        if self.use_v2_norm_placement and self._hs_norms():  # ref :334-335: x + drop_path(norm(branch)), fused per branch
+            a = self._attention_branch(x, apply_proj_drop=False)
+            x = self.norm1(a, residual=x, row_scale=self._path_scale(x), drop_p=self.attn.proj_drop.p if train else 0.0)
+            m = self.mlp(x, apply_out_drop=False)
+            return self.norm2(m, residual=x, row_scale=self._path_scale(x), drop_p=self.mlp.drop.p if train else 0.0)
+        if self.use_v2_norm_placement:  # foreign norm layers
+            x = x + self.drop_path(self.norm1(self._attention_branch(x)))
+            return x + self.drop_path(self.norm2(self.mlp(x)))
         # ref :315-316, :337-338
         x = x + self.drop_path(self._attention_branch(self.norm1(x)))
         return x + self.drop_path(self.mlp(self.norm2(x)))
@@ -336,12 +362,11 @@ class _Stage(nn.Module):
         pending = None  # second residual branch of the previous block, added inside the next block's first LayerNorm
         for blk in self.blocks:
             if self.use_checkpoint or not blk.can_defer():
-                if pending is not None:
-                    x, pending = x + pending, None
+                x, pending = SwinTransformerBlock.resolve_pending(x, pending), None
                 x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
             else:
                 x, pending = blk.forward_deferred(x, pending)
-        return x if pending is None else x + pending
+        return SwinTransformerBlock.resolve_pending(x, pending)
 
     def extra_repr(self):
         return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"

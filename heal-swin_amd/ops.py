@@ -48,6 +48,11 @@ def _f32(t):
     return None if t is None else t.detach().to(torch.float32).contiguous()
 
 
+def _draw_seed():
+    """64-bit seed from torch's CPU generator (repeatable under torch.manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 # ----------------------------------------------------------------------------- rel-pos bias
 class RelPosBiasFn(torch.autograd.Function):
     """bias[h,i,j] = table[rel_idx[i,j], h]   (reference swin_hp_transformer.py:152-159)"""
@@ -140,12 +145,28 @@ def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window
                                   float(attn_drop), int(seed or 0))
 
 
-# ----------------------------------------------------------------------------- row LayerNorm (+ residual)
+# ----------------------------------------------------------------------------- row LayerNorm (+ residual, + train-mode extras)
+def _extras(x, row_scale, drop_p, seed):
+    """(row_scale fp32 or None, rows_per_sample, drop_p, seed) for the *_drop_* kernels; None if nothing stochastic is on."""
+    if row_scale is None and not drop_p:
+        return None
+    rows = x.numel() // x.shape[-1]
+    rs, rps = None, 1
+    if row_scale is not None:
+        rs = row_scale.detach().to(torch.float32).contiguous()
+        assert rows % rs.numel() == 0
+        rps = rows // rs.numel()
+    if drop_p and seed is None:
+        seed = _draw_seed()
+    return rs, rps, float(drop_p or 0.0), int(seed or 0)
+
+
 class LayerNormFn(torch.autograd.Function):
-    """y = [residual +] LayerNorm(x) over the last dimension (eps 1e-5), statistics in fp32."""
+    """y = [residual +] rs * LayerNorm(drop(x)) over the last dimension (eps 1e-5), statistics in fp32; rs / drop are the
+    optional per-sample DropPath factor and dropout mask (train mode), absent in eval."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual):
+    def forward(ctx, x, weight, bias, residual, extras):
         _require_gpu(x, weight, bias, residual)
         x = x.contiguous()
         width = x.shape[-1]
@@ -159,35 +180,47 @@ class LayerNormFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:3])
         mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
-        check(lib.hs_layernorm_fwd(ptr(x), ptr(res), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, width, dt,
-                                   stream_ptr(x.device)), "hs_layernorm_fwd")
-        ctx.save_for_backward(x, g, mean, rstd)
-        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype, residual is not None)
+        if extras is None:
+            check(lib.hs_layernorm_fwd(ptr(x), ptr(res), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, width, dt,
+                                       stream_ptr(x.device)), "hs_layernorm_fwd")
+        else:
+            rs, rps, p, seed = extras
+            check(lib.hs_layernorm_drop_fwd(ptr(x), ptr(res), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), ptr(rs), rps, p, seed,
+                                            rows, width, dt, stream_ptr(x.device)), "hs_layernorm_drop_fwd")
+        ctx.save_for_backward(x, g, mean, rstd, None if extras is None else extras[0])
+        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype, residual is not None, extras)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, g, mean, rstd = ctx.saved_tensors
-        rows, width, dt, wdt, bdt, has_res = ctx.meta
+        x, g, mean, rstd, rs = ctx.saved_tensors
+        rows, width, dt, wdt, bdt, has_res, extras = ctx.meta
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma = torch.empty(width, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(width, dtype=torch.float32, device=x.device)
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=x.device)
-        check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                   rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
-        return dx, dgamma.to(wdt), dbeta.to(bdt), (dy if has_res else None)
+        if extras is None:
+            check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                       rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
+        else:
+            _, rps, p, seed = extras
+            check(lib.hs_layernorm_drop_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                            ptr(ws), ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
+                  "hs_layernorm_drop_bwd")
+        return dx, dgamma.to(wdt), dbeta.to(bdt), (dy if has_res else None), None
 
 
-def layer_norm(x, weight, bias, residual=None):
-    return LayerNormFn.apply(x, weight, bias, residual)
+def layer_norm(x, weight, bias, residual=None, row_scale=None, drop_p=0.0, seed=None):
+    return LayerNormFn.apply(x, weight, bias, residual, _extras(x, row_scale, drop_p, seed))
 
 
 class AddLayerNormFn(torch.autograd.Function):
-    """(s, y) = (a + b, LayerNorm(a + b)) in one pass; backward folds the residual-path gradient into the LN backward."""
+    """(s, y) = (a + rs * drop(b), LayerNorm(s)) in one pass; backward folds the residual-path gradient into the LN backward
+    and routes the gradient of b through the same DropPath factor / dropout mask."""
 
     @staticmethod
-    def forward(ctx, a, b, weight, bias):
+    def forward(ctx, a, b, weight, bias, extras):
         _require_gpu(a, b, weight, bias)
         a, b = a.contiguous(), b.contiguous()
         assert a.shape == b.shape and a.dtype == b.dtype
@@ -199,40 +232,50 @@ class AddLayerNormFn(torch.autograd.Function):
         y = torch.empty_like(a)
         mean = torch.empty(rows, dtype=torch.float32, device=a.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
-        check(lib.hs_add_layernorm_fwd(ptr(a), ptr(b), ptr(g), ptr(be), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, width, dt,
-                                       stream_ptr(a.device)), "hs_add_layernorm_fwd")
-        ctx.save_for_backward(s, g, mean, rstd)
-        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype)
+        if extras is None:
+            check(lib.hs_add_layernorm_fwd(ptr(a), ptr(b), ptr(g), ptr(be), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, width,
+                                           dt, stream_ptr(a.device)), "hs_add_layernorm_fwd")
+        else:
+            rs, rps, p, seed = extras
+            check(lib.hs_add_layernorm_drop_fwd(ptr(a), ptr(b), ptr(g), ptr(be), ptr(s), ptr(y), ptr(mean), ptr(rstd), ptr(rs),
+                                                rps, p, seed, rows, width, dt, stream_ptr(a.device)), "hs_add_layernorm_drop_fwd")
+        ctx.save_for_backward(s, g, mean, rstd, None if extras is None else extras[0])
+        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype, extras)
         return s, y
 
     @staticmethod
     def backward(ctx, ds, dy):
-        s, g, mean, rstd = ctx.saved_tensors
-        rows, width, dt, wdt, bdt = ctx.meta
+        s, g, mean, rstd, rs = ctx.saved_tensors
+        rows, width, dt, wdt, bdt, extras = ctx.meta
         if dy is None:  # only the sum was used downstream
-            return ds, ds, None, None
+            if extras is None:
+                return ds, ds, None, None, None
+            dy = torch.zeros_like(s)
         dy = dy.contiguous()
         ds_c = None if ds is None else ds.contiguous()
-        dx = torch.empty_like(s)
+        da = torch.empty_like(s)
         dgamma = torch.empty(width, dtype=torch.float32, device=s.device)
         dbeta = torch.empty(width, dtype=torch.float32, device=s.device)
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=s.device)
-        check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
-                                       ptr(ws), rows, width, dt, stream_ptr(s.device)), "hs_add_layernorm_bwd")
-        return dx, dx, dgamma.to(wdt), dbeta.to(bdt)
+        if extras is None:
+            check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(da), ptr(dgamma),
+                                           ptr(dbeta), ptr(ws), rows, width, dt, stream_ptr(s.device)), "hs_add_layernorm_bwd")
+            db = da
+        else:
+            _, rps, p, seed = extras
+            db = torch.empty_like(s)
+            check(lib.hs_add_layernorm_drop_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(da), ptr(db),
+                                                ptr(dgamma), ptr(dbeta), ptr(ws), ptr(rs), rps, p, seed, rows, width, dt,
+                                                stream_ptr(s.device)), "hs_add_layernorm_drop_bwd")
+        return da, db, dgamma.to(wdt), dbeta.to(bdt), None
 
 
-def add_layer_norm(a, b, weight, bias):
-    """returns (a + b, LayerNorm(a + b))"""
-    return AddLayerNormFn.apply(a, b, weight, bias)
+def add_layer_norm(a, b, weight, bias, row_scale=None, drop_p=0.0, seed=None):
+    """returns (a + rs*drop(b), LayerNorm(a + rs*drop(b)))"""
+    return AddLayerNormFn.apply(a, b, weight, bias, _extras(a, row_scale, drop_p, seed))
 
 
 # ----------------------------------------------------------------------------- GELU (+ dropout)
-def _draw_seed():
-    """64-bit seed from torch's CPU generator (repeatable under torch.manual_seed)."""
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
-
-
 class GeluDropoutFn(torch.autograd.Function):
     """y = dropout(gelu(x), p) in one pass; the backward regenerates the mask from the seed (reference Mlp :39-41)."""
 

@@ -191,6 +191,28 @@ int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, cons
                          const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
                          int64_t rows, int width, int dtype, void* stream);
 
+/* Train-mode variants with the block's stochastic regularisers fused in (models_torch/swin_hp_transformer.py:173 proj_drop,
+ * :43 Mlp output dropout, :334-338 DropPath): drop() is a counter-based dropout mask (drop_p, seed; regenerated by the
+ * backward called with the same seed), rs = row_scale[row / rows_per_sample] the per-sample DropPath factor
+ * (0 or 1/keep; row_scale [dev] f32[rows / rows_per_sample], may be NULL = 1).
+ *   hs_layernorm_drop_*      (v2 placement):  y = [residual +] rs * LN(drop(x));        dx = mask * LN_bwd(rs * dy)
+ *   hs_add_layernorm_drop_*  (v1 placement):  sum = a + rs * drop(b),  y = LN(sum);     da = g, db = rs * mask * g
+ *                                             with g = LN_bwd(dy) + dsum */
+int hs_layernorm_drop_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y,
+                          float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample, float drop_p,
+                          uint64_t seed, int64_t rows, int width, int dtype, void* stream);
+int hs_layernorm_drop_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                          void* dx, float* dgamma, float* dbeta, float* workspace, const float* row_scale,
+                          int64_t rows_per_sample, float drop_p, uint64_t seed, int64_t rows, int width, int dtype,
+                          void* stream);
+int hs_add_layernorm_drop_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* sum_out, void* y,
+                              float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample, float drop_p,
+                              uint64_t seed, int64_t rows, int width, int dtype, void* stream);
+int hs_add_layernorm_drop_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
+                              const float* rstd, void* da, void* db, float* dgamma, float* dbeta, float* workspace,
+                              const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed,
+                              int64_t rows, int width, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * y = dropout(GELU(x)) (exact erf GELU) and its backward dx = dy * mask/(1-p) * GELU'(x): the activation and the
  * dropout behind it in Mlp.forward (models_torch/swin_hp_transformer.py:39-41) in one pass.  drop_p = 0 (eval) is plain

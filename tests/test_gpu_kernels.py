@@ -388,3 +388,85 @@ def test_gelu_dropout_mask_consistency():
     assert float(x.grad[dropped].abs().max()) == 0.0 and float(x.grad[kept].abs().sum()) > 0
     assert torch.equal(ops.gelu_dropout(x.detach(), p, seed=42), y.detach())
     assert not torch.equal(ops.gelu_dropout(x.detach(), p, seed=43), y.detach())
+
+
+# ----------------------------------------------------------------------------- norm kernels with fused dropout / DropPath
+@pytest.mark.parametrize("rows_per_sample,width", [(64, 128), (256, 96), (16, 512)])
+def test_stochastic_norm_variants_vs_explicit_formula(rows_per_sample, width):
+    """Recover the kernel's effective multiplier M = rs * mask/(1-p) from the fused-add output in fp32, then check
+    s, y and every gradient of both variants (v1: LN(a + M*b); v2: res + rs*LN(mask*x)) against autograd on the formula."""
+    ops, _, _ = _mods()
+    from oracle import model as OM
+    B, p, seed = 4, 0.2, 987654321
+    rows = B * rows_per_sample
+    g = torch.Generator().manual_seed(width)
+    a, b = torch.randn(rows, width, generator=g), torch.randn(rows, width, generator=g) + 3.0  # b != 0 everywhere
+    w, be = 1 + 0.3 * torch.randn(width, generator=g), 0.2 * torch.randn(width, generator=g)
+    rs = torch.tensor([0.0, 1.25, 1.25, 1.25])
+    ds, dy = torch.randn(rows, width, generator=g), torch.randn(rows, width, generator=g)
+
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    wd, bed = w.to(DEV).requires_grad_(True), be.to(DEV).requires_grad_(True)
+    s, y = ops.add_layer_norm(ad, bd, wd, bed, row_scale=rs.to(DEV), drop_p=p, seed=seed)
+    M = ((s.detach().cpu() - a) / b)
+    mask = M.clone()
+    mask[rows_per_sample:] /= 1.25  # rows of sample 0 carry rs = 0: their mask is not observable (and irrelevant)
+    vals = mask[rows_per_sample:].round(decimals=4).unique()
+    assert set(vals.tolist()) <= {0.0, 1.25} and abs(float((mask[rows_per_sample:] > 0).float().mean()) - (1 - p)) < 0.02
+    assert float(M[:rows_per_sample].abs().max()) == 0.0  # dropped sample: the branch vanishes
+    Mfix = torch.where(M.abs() > 0, torch.full_like(M, 1.25 * 1.25), torch.zeros_like(M))
+    Mfix[:rows_per_sample] = 0
+
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    wr, ber = w.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    s_ref = ar + Mfix * br
+    y_ref = OM.layer_norm(s_ref, wr, ber)
+    torch.autograd.backward([s_ref, y_ref], [ds, dy])
+    assert_close(s, s_ref, 1e-5, "sum")
+    assert_close(y, y_ref, 1e-4, "y")
+    torch.autograd.backward([s, y], [ds.to(DEV), dy.to(DEV)])
+    assert_close(ad.grad, ar.grad, 1e-4, "da")
+    assert_close(bd.grad, br.grad, 1e-4, "db")
+    assert_close(wd.grad, wr.grad, 1e-4, "dgamma")
+    assert_close(bed.grad, ber.grad, 1e-4, "dbeta")
+
+    # v2 form on the same shape and seed (same element indexing -> same mask): y = res + rs * LN(mask * x)
+    keep = torch.where(M.abs() > 0, torch.full_like(M, 1.25), torch.zeros_like(M))
+    # sample 0's mask is unobservable above; use samples 1.. only
+    sl = slice(rows_per_sample, None)
+    xd = b.to(DEV).requires_grad_(True)
+    rd = a.to(DEV).requires_grad_(True)
+    wd2, bed2 = w.to(DEV).requires_grad_(True), be.to(DEV).requires_grad_(True)
+    y2 = ops.layer_norm(xd, wd2, bed2, residual=rd, row_scale=rs.to(DEV), drop_p=p, seed=seed)
+    xr, rr = b.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    wr2, ber2 = w.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    y2_ref = rr[sl] + 1.25 * OM.layer_norm(keep[sl] * xr[sl], wr2, ber2)
+    y2_ref.backward(dy[sl])
+    assert_close(y2[sl], y2_ref, 1e-4, "v2 y")
+    assert_close(y2[:rows_per_sample], a[:rows_per_sample], 1e-6, "v2 dropped sample = residual")
+    (y2[sl] * dy[sl].to(DEV)).sum().backward()
+    assert_close(xd.grad[sl], xr.grad[sl], 1e-4, "v2 dx")
+    assert_close(rd.grad[sl], rr.grad[sl], 1e-6, "v2 dres")
+    assert_close(wd2.grad, wr2.grad, 1e-4, "v2 dgamma")
+    assert_close(bed2.grad, ber2.grad, 1e-4, "v2 dbeta")
+
+
+@pytest.mark.parametrize("v2", [False, True])
+def test_block_with_paper_drop_rates_runs_and_is_identity_in_eval(v2):
+    _, M, _ = _mods()
+    torch.manual_seed(1)
+    kw = dict(window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", use_v2_norm_placement=v2, use_cos_attn=v2)
+    blk = M.SwinTransformerBlock(64, 768, 12, 2, drop=0.1, attn_drop=0.1, drop_path=0.1, **kw).to(DEV)
+    ref = M.SwinTransformerBlock(64, 768, 12, 2, **kw).to(DEV)
+    ref.load_state_dict(blk.state_dict())
+    x = torch.randn(8, 768, 64, device=DEV).to(torch.bfloat16)
+    blk.eval(), ref.eval()
+    assert torch.equal(blk(x), ref(x))  # every stochastic element is the identity in eval mode
+    blk.train()
+    xt = x.clone().requires_grad_(True)
+    y = blk(xt)
+    assert not torch.equal(y, ref(x))
+    y.float().square().mean().backward()
+    assert torch.isfinite(xt.grad.float()).all()
+    for n, prm in blk.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), n
