@@ -183,3 +183,40 @@ def test_direct_and_async_wgrad_match_autograd_path():
     w = dict(model.named_parameters())["layers.0.blocks.0.mlp.fc1.weight"]
     assert_close(w.grad, 2 * grads["autograd"]["layers.0.blocks.0.mlp.fc1.weight"], 1e-5, "accumulate")
     dp.remove()
+
+
+def test_depth_head_fp32_full_T_architecture_vs_oracle():
+    """BASELINE config 5 at a size the CPU oracle finishes in seconds: HEAL-SWIN-T (embed 96, depths [2,2,6,2], heads
+    [3,6,12,24], window 64), 8 base pixels, nside 128, f_out = 1, fp32.  Logits within 1e-3 of the oracle (north_star
+    fp32 tolerance) and the masked L1 loss / its input gradient equal."""
+    M = _M()
+    from heal_swin_amd import losses as L
+    from heal_swin_amd.data_spec import DataSpec
+    from oracle import model as OM
+    cfg = dict(patch_size=4, window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", embed_dim=96,
+               depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], mlp_ratio=4.0, qkv_bias=True, qk_scale=None, use_cos_attn=False,
+               drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, use_v2_norm_placement=False, ape=False)
+    spec = dict(dim_in=8 * 128 * 128, f_in=3, f_out=1, base_pix=8, class_names=[])
+    torch.manual_seed(0)
+    model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), DataSpec(**spec))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("relative_position_bias_table"):
+                p.normal_(0, 0.3)
+    sd = {k: v.clone() for k, v in model.state_dict().items() if not k.endswith("attn_mask")}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (1, 3, spec["dim_in"]), generator=g).float()
+    target = torch.randn(1, spec["dim_in"], generator=g).abs() * 10
+    target[torch.rand(1, spec["dim_in"], generator=g) < 0.04] = float("inf")
+    torch.set_num_threads(16)
+    y_ref = OM.forward(sd, ns(cfg), ns(spec), x)
+    loss_ref = OM.depth_l1_loss(y_ref, target)
+    model = model.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = model(xg)
+    assert y.dtype == torch.float32 and y.shape == (1, 1, spec["dim_in"])
+    assert_close(y, y_ref, 1e-3, "depth logits fp32")
+    loss = L.depth_l1_loss(y, target.to(DEV))
+    assert abs(float(loss) - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref)))
+    loss.backward()
+    assert torch.isfinite(xg.grad).all()
