@@ -14,11 +14,14 @@ import torch.distributed as dist
 
 
 class GradBucketAllReduce:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, async_wgrad=False, direct_wgrad=True):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, async_wgrad=False, direct_wgrad=True,
+                 exchange_single_rank=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.async_wgrad = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # a one-rank group normally skips the collectives; exchange_single_rank keeps them (exercises the RCCL path on one GPU)
+        self._exchange = self.world > 1 or (exchange_single_rank and dist.is_initialized())
         self.buckets = []       # flat fp32 tensors
         self._pending = []      # per bucket: number of grads still missing this step
         self._counts = []
@@ -27,7 +30,7 @@ class GradBucketAllReduce:
         self._seen = set()      # parameters already counted in this step
         self._build(bucket_bytes)
         self._hooks = []
-        if self.world > 1:
+        if self._exchange:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._direct = False
@@ -35,13 +38,13 @@ class GradBucketAllReduce:
             # Linear weight/bias gradients are accumulated by the wgrad kernel straight into the bucket views
             from . import ops
 
-            ops.GRAD_SINK = self._on_grad if self.world > 1 else True
+            ops.GRAD_SINK = self._on_grad if self._exchange else True
             self._direct = True
         if async_wgrad and self.params and self.params[0].is_cuda:
             # Linear weight/bias gradients are produced on a side stream straight into the bucket views (ops.AsyncWgrad)
             from . import ops
 
-            self.async_wgrad = ops.AsyncWgrad(self.params[0].device, sink=self._on_grad if self.world > 1 else None)
+            self.async_wgrad = ops.AsyncWgrad(self.params[0].device, sink=self._on_grad if self._exchange else None)
             ops.ASYNC_WGRAD = self.async_wgrad
 
     def _build(self, bucket_bytes):
@@ -95,7 +98,7 @@ class GradBucketAllReduce:
         """Wait for every in-flight bucket; call after backward(), before optimizer.step()."""
         if self.async_wgrad is not None:
             self.async_wgrad.sync()
-        if self.world > 1:
+        if self._exchange:
             # parameters that received no gradient this step (unused) still need their bucket exchanged
             for b, left in enumerate(self._pending):
                 if left not in (0, ) and left != self._counts[b]:

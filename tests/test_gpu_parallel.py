@@ -97,3 +97,49 @@ def test_two_rank_dp_equals_single_process(kw):
     for a, b in zip(res[0], ref):
         worst = max(worst, float(np.abs(a - b).max()) / max(1e-3, float(np.abs(b).max())))
     assert worst < 2e-2, worst  # bf16 activations: half-batch vs full-batch reduction order differs
+
+
+def _rccl_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sys.path.insert(0, ROOT)
+    from heal_swin_amd.parallel import GradBucketAllReduce
+    model = _build()
+    x, y = _data()
+    dp = GradBucketAllReduce(model.parameters(), bucket_bytes=256 << 10, exchange_single_rank=True)
+    assert len(dp.buckets) > 1 and dp._exchange
+    launched = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (launched.append(1), real(*a, **k))[1]
+    out = _train(model, dp, x, y)
+    dist.all_reduce = real
+    assert len(launched) == 2 * len(dp.buckets), (len(launched), len(dp.buckets))  # every bucket, both steps
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_matches_local():
+    """The RCCL ("nccl") code path of bench.py --gpus N: asynchronous bucket all-reduces on RCCL's stream, launched while
+    the backward is still depositing later buckets.  One rank is all a 1-GPU box allows; the result must equal the
+    process-group-free run bit for bit (sum over one rank, scale 1)."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from heal_swin_amd.parallel import GradBucketAllReduce
+    model = _build()
+    x, y = _data()
+    dp = GradBucketAllReduce(model.parameters(), bucket_bytes=256 << 10)
+    ref = _train(model, dp, x, y)
+    dp.remove()
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
