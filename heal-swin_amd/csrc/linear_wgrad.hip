@@ -16,6 +16,9 @@
 //     L2, not from HBM: HBM traffic stays at one pass over dY and X;
 //   * the bias gradient falls out of the dY staging loads (column sums in registers), only in the k-tile-0 workgroups.
 // Roofline: flop/byte = N*K/(N+K): HBM-bound at C <= 256 (stage 0/1), MFMA-bound from C = 512.
+#include <cstdlib>
+#include <type_traits>
+
 #include "hs_device.h"
 
 namespace hs {
@@ -210,6 +213,224 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
     }
 }
 
+// LDS-DMA variant of the kernel above: the token tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), three
+// stages deep, so two stages (48 KB per workgroup) are in flight while one is multiplied: the register-staged kernel
+// can only keep ONE stage in flight and is bound by the L2/HBM round trip of that single prefetch, not by MFMA or LDS.
+//   * LDS image: unpadded row-major tiles; the DMA writes wave-uniform base + lane * 16 B, so the bank skew comes from
+//     an XOR on the 16-byte chunk index (chunk ^ ((row & 3) << 2)), applied to the per-lane SOURCE address on the way in
+//     and to the transposing reads on the way out;
+//   * buffer descriptors spanning exactly the slice's rows: token rows past the end read as zeros (ragged last stage);
+//     column overrun of a partial tile reads the next row / zeros and only ever reaches accumulators that are not stored;
+//   * per stage: s_waitcnt vmcnt(own loads of the NEXT stage) -> s_barrier -> issue stage t+2 -> fragments + MFMA.
+//     The barrier both publishes stage t and retires every wave's reads of the buffer that stage t+2 overwrites.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// one MFMA operand (8 tokens x 1 column per lane) by two transposing reads issued from inline asm; a = LDS byte address of
+// the lane's first 4-row group, ks = 16-token half of the stage
+template <int RB>
+__device__ __forceinline__ s16x8 tr_frag_asm(uint32_t a, int ks) {
+    s16x4 lo, hi;
+    if (ks == 0) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(4 * RB));
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(16 * RB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(20 * RB));
+    }
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                           float* __restrict__ part_w, float* __restrict__ part_b,
+                                                           int64_t rows, int n_out, int k_in, Geometry g) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource / LDS-DMA builtins exist in the device pass only
+    constexpr int TN = 64 * NB;
+    constexpr int YRB = TN * 2, XRB = kTileK * 2;    // bytes of one staged dY / X tile row
+    constexpr int YB = kTok * YRB, XB = kTok * XRB;  // bytes of one staged dY / X tile
+    constexpr int STAGE = YB + XB, NSTAGE = 3;
+    constexpr int YI = YB / 1024 / 4, XI = XB / 1024 / 4;  // 1-KB DMA instructions per wave and stage
+    constexpr int YCH = YRB / 16;                          // 16-byte chunks per dY tile row
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+    float* bred = (float*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    int slice, tile;
+    {
+        const int b = blockIdx.x;
+        if (g.slices % 8 == 0) {
+            const int xcd = b & 7, local = b >> 3;
+            slice = xcd + 8 * (local / g.tiles);
+            tile = local % g.tiles;
+        } else {
+            slice = b / g.tiles;
+            tile = b % g.tiles;
+        }
+    }
+    const int tn = tile / g.tiles_k, tk = tile % g.tiles_k;
+    const int n0 = tn * TN, k0 = tk * kTileK;
+    const int64_t m_begin = (int64_t)slice * g.rows_per_slice;
+    int64_t m_end = m_begin + g.rows_per_slice;
+    if (m_end > rows) m_end = rows;
+    const int m_len = m_end > m_begin ? (int)(m_end - m_begin) : 0;
+    const int nst = (m_len + kTok - 1) / kTok;
+    const bool do_bias = part_b != nullptr && tk == 0;
+
+    // descriptors over [m_begin, m_end) x the full row; raw (stride 0) buffers return 0 past num_records
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + m_begin * n_out), 0, m_len * n_out * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + m_begin * k_in), 0, m_len * k_in * 2, 0x00020000);
+    // DMA instruction q of a tile fills LDS bytes [q KB, q KB + 1 KB): position p = 64 q + lane -> (row, physical chunk)
+    int voff_y[YI], voff_x[XI];
+#pragma unroll
+    for (int j = 0; j < YI; ++j) {
+        const int p = (wave * YI + j) * 64 + lane, row = p / YCH, pc = p % YCH;
+        voff_y[j] = row * n_out * 2 + n0 * 2 + ((pc ^ ((row & 3) << 2)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int p = (wave * XI + j) * 64 + lane, row = p >> 4, pc = p & 15;
+        voff_x[j] = row * k_in * 2 + k0 * 2 + ((pc ^ ((row & 3) << 2)) << 4);
+    }
+    const int ystep = kTok * n_out * 2, xstep = kTok * k_in * 2;
+    auto issue = [&](int b) {
+        unsigned char* base = smem + b * STAGE;
+#pragma unroll
+        for (int j = 0; j < YI; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void*)(base + (wave * YI + j) * 1024), 16, voff_y[j], 0, 0, 0);
+            voff_y[j] += ystep;
+        }
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(base + YB + (wave * XI + j) * 1024), 16, voff_x[j], 0, 0, 0);
+            voff_x[j] += xstep;
+        }
+    };
+
+    // transposing fragment reads: lane -> (row L/4 of a 4-row group, 4 columns) ; swizzled chunk = chunk ^ (row_in << 2)
+    const int L = lane & 15, nblk = (lane >> 4) & 1, row_in = L >> 2;
+    const int lane_lo = (nblk * 2 + ((L & 3) >> 1)) * 16 + (L & 1) * 8;
+    int yoff[NB], xoff[2];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) yoff[i] = (8 * half + row_in) * YRB + ((((wn * NB + i) ^ row_in) << 2) << 4) + lane_lo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xoff[j] = YB + (8 * half + row_in) * XRB + ((((wk * 2 + j) ^ row_in) << 2) << 4) + lane_lo;
+    // The transposing reads go through inline asm: behind the ds_read_tr16 builtin hipcc (ROCm 7.2) drains every LDS-DMA in
+    // flight (s_waitcnt vmcnt(0)) before the first read of a stage, which serialises the pipeline.  The compiler does not
+    // count asm reads, so their completion is awaited by the explicit lgkmcnt waits below (LDS operations return in order).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // bias partial sums: thread -> (row group tid / YCH, logical chunk tid % YCH)
+    const int yr = tid / YCH, yc = tid % YCH;
+    const int boff = yr * YRB + ((yc ^ ((yr & 3) << 2)) << 4);  // rows yr + (256 / YCH) * ps share (row & 3)
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    f32x16 acc[NB][2];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
+
+    // one stage; the buffer indices are compile-time constants (loop unrolled by NSTAGE) so that the compiler can tell the
+    // DMA's destination buffer from the one being read: with run-time indices it orders them with an s_waitcnt vmcnt(0)
+    auto stage = [&](int t, auto buf_c, auto nbuf_c) {
+        constexpr int buf = decltype(buf_c)::value, nbuf = decltype(nbuf_c)::value;
+        if (t + 1 < nst)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YI + XI) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nst) issue(nbuf);
+        s16x8 af[2][NB], bf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[ks][j] = tr_frag_asm<XRB>(lds0 + buf * STAGE + xoff[j], ks);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) af[ks][i] = tr_frag_asm<YRB>(lds0 + buf * STAGE + yoff[i], ks);
+        }
+        // first half landed once at most the second half's 2 * (NB + 2) reads are outstanding
+        if constexpr (NB == 4) {
+            asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(af[0][0]), "+v"(af[0][1]));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[0][i]), __builtin_bit_cast(bf16x8, bf[0][j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the first half's MFMAs ahead of the second wait
+        if constexpr (NB == 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(af[1][0]), "+v"(af[1][1]));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[1][i]), __builtin_bit_cast(bf16x8, bf[1][j]), acc[i][j], 0, 0, 0);
+        if (do_bias) {  // column sums of the staged dY tile (also asm reads: a plain LDS load would drain the DMA queue)
+            constexpr int PS = kTok / (256 / YCH);
+            u32x4 v[PS];
+            const uint32_t ba = lds0 + buf * STAGE + boff;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(ba));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[1]) : "v"(ba), "n"((256 / YCH) * YRB));
+            if constexpr (PS == 4) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[2]) : "v"(ba), "n"(2 * (256 / YCH) * YRB));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[3]) : "v"(ba), "n"(3 * (256 / YCH) * YRB));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
+            }
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bsum[2 * i] += __uint_as_float(v[ps][i] << 16);
+                    bsum[2 * i + 1] += __uint_as_float(v[ps][i] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    if (nst > 0) issue(0);
+    if (nst > 1) issue(1);
+    for (int t = 0; t < nst; t += NSTAGE) {
+        stage(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        if (t + 2 < nst) stage(t + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    }
+
+    float* dst = part_w + (int64_t)slice * ((int64_t)n_out * k_in + n_out);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + wn * 32 * NB + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (nn < n_out && kk < k_in) dst[(int64_t)nn * k_in + kk] = acc[i][j][r];
+            }
+        }
+    if (do_bias) {
+        __syncthreads();  // every wave is done with the stage buffers
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bred[yr * TN + yc * 8 + i] = bsum[i];
+        __syncthreads();
+        if (tid < TN) {
+            float t = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 256 / YCH; ++rg) t += bred[rg * TN + tid];
+            if (n0 + tid < n_out) part_b[(int64_t)slice * ((int64_t)n_out * k_in + n_out) + n0 + tid] = t;
+        }
+    }
+#endif
+}
+
 // Sums the slices of chunk blockIdx.y of the partial records part[s * in_stride + 0..count) (n_w weight entries followed
 // by bias entries).  Intermediate pass (final_pass == 0): out[chunk * count + 0..count).  Final pass: weights to dw, bias
 // to db (skipped if null), added to the existing contents when accumulate != 0.
@@ -264,7 +485,16 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     float* mid = workspace + (int64_t)g.slices * rec;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.slices * g.tiles));
-    if (g.tile_n == 256)
+    static const int variant = getenv("HS_WGRAD_VARIANT") ? atoi(getenv("HS_WGRAD_VARIANT")) : 1;
+    const bool dma_ok = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * 2 < (int64_t)1 << 31;
+    if (variant == 1 && dma_ok) {
+        if (g.tile_n == 256)
+            hipLaunchKernelGGL(wgrad_dma_kernel<4>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b,
+                               rows, n_out, k_in, g);
+        else
+            hipLaunchKernelGGL(wgrad_dma_kernel<2>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b,
+                               rows, n_out, k_in, g);
+    } else if (g.tile_n == 256)
         hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b, rows,
                            n_out, k_in, g);
     else
