@@ -48,28 +48,39 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int tok0, i
 }
 
 struct Geometry {
-    int tile_n, tiles_n, tiles_k, tiles, slices, chunks;
+    int tile_n, tiles_n, tiles_k, tiles, slices, chunks, per_xcd;
     int64_t rows_per_slice;
 };
 
-__host__ __device__ inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
+inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
     Geometry g;
     g.tile_n = (n_out % 256 == 0 || n_out >= 512) ? 256 : 128;
     g.tiles_n = (n_out + g.tile_n - 1) / g.tile_n;
     g.tiles_k = (k_in + kTileK - 1) / kTileK;
     g.tiles = g.tiles_n * g.tiles_k;
-    // ~4 workgroups per CU over the chip, at least 512 tokens per slice, slices a multiple of 8 (one per XCD)
-    int64_t want = (256 * 4 + g.tiles - 1) / g.tiles;
+    // one resident round: 2 workgroups per CU (LDS / VGPR bound) x 256 CUs, all of equal length; at least 512 tokens per slice
+    static const int wgs_per_cu = getenv("HS_WGRAD_WGS_PER_CU") ? atoi(getenv("HS_WGRAD_WGS_PER_CU")) : 2;
+    int64_t want = (256 * wgs_per_cu) / g.tiles;
     int64_t max_by_rows = (rows + 511) / 512;
     if (want > max_by_rows) want = max_by_rows;
     if (want > kMaxSlices) want = kMaxSlices;
     if (want < 1) want = 1;
-    if (want >= 8) want = (want / 8) * 8;
     g.slices = (int)want;
     int64_t rps = (rows + g.slices - 1) / g.slices;
     g.rows_per_slice = ((rps + kTok - 1) / kTok) * kTok;
     g.chunks = g.slices > 2 * kReduceChunks ? kReduceChunks : 1;
+    g.per_xcd = (g.slices * g.tiles + 7) / 8;
     return g;
+}
+
+// block id -> (slice, tile).  The dispatcher places block b on XCD b % 8; XCD x takes the contiguous range
+// [x * per_xcd, (x + 1) * per_xcd) of slice-major work ids, so the tiles of one token slice run on one XCD (two at a range
+// boundary) and re-read that slice's dY / X rows from its L2 rather than from HBM.  Returns false for the padding blocks.
+__device__ __forceinline__ bool block_to_work(const Geometry& g, int b, int& slice, int& tile) {
+    const int v = (b & 7) * g.per_xcd + (b >> 3);
+    slice = v / g.tiles;
+    tile = v % g.tiles;
+    return (b >> 3) < g.per_xcd && v < g.slices * g.tiles;
 }
 
 // NB = 32-row blocks per wave along n: the workgroup tile is (64*NB) x 128, waves in 2 x 2, each (32*NB) x 64
@@ -90,19 +101,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const uint16_t* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;  // wave's (32*NB) x 64 sub-tile inside the tile
 
-    // block id -> (slice, tile): all tiles of a slice are consecutive on one XCD (dispatch places block b on XCD b % 8)
     int slice, tile;
-    {
-        const int b = blockIdx.x;
-        if (g.slices % 8 == 0) {
-            const int xcd = b & 7, local = b >> 3;
-            slice = xcd + 8 * (local / g.tiles);
-            tile = local % g.tiles;
-        } else {
-            slice = b / g.tiles;
-            tile = b % g.tiles;
-        }
-    }
+    if (!block_to_work(g, blockIdx.x, slice, tile)) return;
     const int tn = tile / g.tiles_k, tk = tile % g.tiles_k;
     const int n0 = tn * TN, k0 = tk * kTileK;
     const int64_t m_begin = (int64_t)slice * g.rows_per_slice;
@@ -258,17 +258,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const uint16_t* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;
     int slice, tile;
-    {
-        const int b = blockIdx.x;
-        if (g.slices % 8 == 0) {
-            const int xcd = b & 7, local = b >> 3;
-            slice = xcd + 8 * (local / g.tiles);
-            tile = local % g.tiles;
-        } else {
-            slice = b / g.tiles;
-            tile = b % g.tiles;
-        }
-    }
+    if (!block_to_work(g, blockIdx.x, slice, tile)) return;
     const int tn = tile / g.tiles_k, tk = tile % g.tiles_k;
     const int n0 = tn * TN, k0 = tk * kTileK;
     const int64_t m_begin = (int64_t)slice * g.rows_per_slice;
@@ -484,7 +474,7 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     float* part_b = dbias ? workspace + n : nullptr;  // bias partials live behind each slice's weight partial
     float* mid = workspace + (int64_t)g.slices * rec;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)(g.slices * g.tiles));
+    const dim3 grid((unsigned)(8 * g.per_xcd));
     static const int variant = getenv("HS_WGRAD_VARIANT") ? atoi(getenv("HS_WGRAD_VARIANT")) : 1;
     const bool dma_ok = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * 2 < (int64_t)1 << 31;
     if (variant == 1 && dma_ok) {
