@@ -301,10 +301,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
     }
 }
 
-// sums the per-workgroup partial rows: 16 columns x 16 row slices per workgroup
+// sums the per-workgroup partial rows: 16 columns x 16 row slices per workgroup (accumulate: adds to dgamma / dbeta)
 __global__ void __launch_bounds__(256) layernorm_param_reduce_kernel(const float* __restrict__ partials,
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                     int nblocks, int width) {
+                                                                     int nblocks, int width, int accumulate) {
     __shared__ float part[16][17];
     const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;  // over 2*width
@@ -317,8 +317,8 @@ __global__ void __launch_bounds__(256) layernorm_param_reduce_kernel(const float
         float tot = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) tot += part[s2][cl];
-        if (col < width) dgamma[col] = tot;
-        else dbeta[col - width] = tot;
+        float* dst = col < width ? dgamma + col : dbeta + (col - width);
+        *dst = accumulate ? *dst + tot : tot;
     }
 }
 
@@ -354,7 +354,7 @@ int run_fwd(const void* x, const void* res, const float* g, const float* b, void
 template <typename T, int VEC, int LPR, int ITERS>
 int run_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
             float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in, void* dadd_out,
-            const LnExtra& ex, int v1_mode) {
+            const LnExtra& ex, int v1_mode, int accumulate) {
     const int blocks = bwd_blocks(rows);
     const size_t smem = (size_t)3 * 2 * width * sizeof(float);
     auto kern = layernorm_bwd_kernel<T, VEC, LPR, ITERS>;
@@ -363,7 +363,7 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
                        ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed, v1_mode);
     HS_LAUNCH_CHECK("layernorm_bwd");
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
-                       width);
+                       width, accumulate);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
     return HS_OK;
 }
@@ -420,7 +420,7 @@ int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const f
 
 int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
                 float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream, const void* dres_in,
-                void* dadd_out, const hs::LnExtra& ex, int v1_mode) {
+                void* dadd_out, const hs::LnExtra& ex, int v1_mode, int accumulate) {
     using namespace hs;
     HS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && width > 0, "bad shape");
@@ -429,12 +429,12 @@ int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
         if (width % 8 == 0)
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
-        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
+        return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
     }
     if (width % 4 == 0)
-        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd<float, 4, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
-    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_bwd<float, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd<float, 4, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
+    return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_bwd<float, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
 }
 
 hs::LnExtra make_extra(const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed) {
@@ -464,16 +464,17 @@ int hs_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const
 int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) { return (int64_t)hs::bwd_blocks(rows) * 2 * width; }
 
 int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                     float* dgamma, float* dbeta, float* workspace, int64_t rows, int width, int dtype, void* stream) {
+                     float* dgamma, float* dbeta, float* workspace, int accumulate, int64_t rows, int width, int dtype,
+                     void* stream) {
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, nullptr, nullptr,
-                       hs::LnExtra{}, 0);
+                       hs::LnExtra{}, 0, accumulate);
 }
 
 int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
-                         const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows, int width,
-                         int dtype, void* stream) {
+                         const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace, int accumulate, int64_t rows,
+                         int width, int dtype, void* stream) {
     return ln_bwd_impl(dy, sum, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, dsum, nullptr,
-                       hs::LnExtra{}, 1);
+                       hs::LnExtra{}, 1, accumulate);
 }
 
 /* train-mode variants: dropout (drop_p, seed) and per-sample DropPath scale (row_scale[rows / rows_per_sample]) fused in */
@@ -485,10 +486,10 @@ int hs_layernorm_drop_fwd(const void* x, const void* residual, const float* gamm
 }
 
 int hs_layernorm_drop_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                          float* dgamma, float* dbeta, float* workspace, const float* row_scale, int64_t rows_per_sample,
-                          float drop_p, uint64_t seed, int64_t rows, int width, int dtype, void* stream) {
+                          float* dgamma, float* dbeta, float* workspace, int accumulate, const float* row_scale,
+                          int64_t rows_per_sample, float drop_p, uint64_t seed, int64_t rows, int width, int dtype, void* stream) {
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, nullptr, nullptr,
-                       make_extra(row_scale, rows_per_sample, drop_p, seed), 0);
+                       make_extra(row_scale, rows_per_sample, drop_p, seed), 0, accumulate);
 }
 
 int hs_add_layernorm_drop_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* sum_out, void* y,
@@ -501,11 +502,11 @@ int hs_add_layernorm_drop_fwd(const void* a, const void* b, const float* gamma, 
 
 int hs_add_layernorm_drop_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
                               const float* rstd, void* da, void* db, float* dgamma, float* dbeta, float* workspace,
-                              const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed, int64_t rows,
-                              int width, int dtype, void* stream) {
+                              int accumulate, const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed,
+                              int64_t rows, int width, int dtype, void* stream) {
     HS_CHECK_ARG(db, "null pointer");
     return ln_bwd_impl(dy, sum, gamma, mean, rstd, da, dgamma, dbeta, workspace, rows, width, dtype, stream, dsum, db,
-                       make_extra(row_scale, rows_per_sample, drop_p, seed), 1);
+                       make_extra(row_scale, rows_per_sample, drop_p, seed), 1, accumulate);
 }
 
 }  // extern "C"

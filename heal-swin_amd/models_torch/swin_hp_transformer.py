@@ -589,6 +589,23 @@ class SwinHPTransformerSys(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("SwinHPTransformerSys (heal_swin_amd) runs only on an MI355X (HIP) device; there is no CPU path")
         dt = self._activation_dtype(x)
-        with torch.autocast(device_type="cuda", enabled=False):
-            x, x_downsample = self.forward_features(x.to(dt))
-            return self.decoder(x, x_downsample)
+        prev, ops.CAST_CACHE = ops.CAST_CACHE, self._param_casts(dt)
+        try:
+            with torch.autocast(device_type="cuda", enabled=False):
+                x, x_downsample = self.forward_features(x.to(dt))
+                return self.decoder(x, x_downsample)
+        finally:
+            ops.CAST_CACHE = prev
+
+    def _param_casts(self, dt):
+        """bf16 copies of the Linear parameters, re-made in one multi-tensor kernel after each optimizer step (ops.ParamCastCache)."""
+        if dt == torch.float32:
+            return None
+        cache = self.__dict__.get("_cast_cache")
+        params = [p for m in self.modules() if isinstance(m, HSLinear) for p in (m.weight, m.bias) if p is not None]
+        if (cache is None or cache.dtype != dt or len(cache.params) != len(params) or any(a is not b for a, b in zip(cache.params, params))
+                or any(sh.device != p.device for sh, p in zip(cache.shadows[:1], params[:1]))):
+            cache = ops.ParamCastCache(params, dt)
+            self.__dict__["_cast_cache"] = cache  # not a module attribute: stays out of state_dict / .to()
+        cache.refresh()
+        return cache

@@ -161,6 +161,26 @@ def _extras(x, row_scale, drop_p, seed):
     return rs, rps, float(drop_p or 0.0), int(seed or 0)
 
 
+def _norm_param_grads(weight, bias, width, device, want):
+    """Buffers the LayerNorm backward writes dgamma / dbeta to: under a GRAD_SINK the parameters' own fp32 .grad (the kernel
+    ADDS, autograd sees no gradient and launches no AccumulateGrad kernels), otherwise fresh tensors."""
+    direct = (GRAD_SINK is not None and want and weight.grad is not None and bias.grad is not None
+              and weight.grad.dtype == torch.float32 and bias.grad.dtype == torch.float32
+              and weight.grad.is_contiguous() and bias.grad.is_contiguous())
+    if direct:
+        return weight.grad, bias.grad, True
+    return (torch.empty(width, dtype=torch.float32, device=device), torch.empty(width, dtype=torch.float32, device=device), False)
+
+
+def _norm_param_result(weight, bias, dgamma, dbeta, direct):
+    if not direct:
+        return dgamma.to(weight.dtype), dbeta.to(bias.dtype)
+    if callable(GRAD_SINK):
+        GRAD_SINK(weight)
+        GRAD_SINK(bias)
+    return None, None
+
+
 class LayerNormFn(torch.autograd.Function):
     """y = [residual +] rs * LayerNorm(drop(x)) over the last dimension (eps 1e-5), statistics in fp32; rs / drop are the
     optional per-sample DropPath factor and dropout mask (train mode), absent in eval."""
@@ -188,27 +208,29 @@ class LayerNormFn(torch.autograd.Function):
             check(lib.hs_layernorm_drop_fwd(ptr(x), ptr(res), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), ptr(rs), rps, p, seed,
                                             rows, width, dt, stream_ptr(x.device)), "hs_layernorm_drop_fwd")
         ctx.save_for_backward(x, g, mean, rstd, None if extras is None else extras[0])
-        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype, residual is not None, extras)
+        ctx.meta = (rows, width, dt, residual is not None, extras)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, mean, rstd, rs = ctx.saved_tensors
-        rows, width, dt, wdt, bdt, has_res, extras = ctx.meta
+        rows, width, dt, has_res, extras = ctx.meta
+        weight, bias = ctx.params
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.empty(width, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(width, dtype=torch.float32, device=x.device)
+        dgamma, dbeta, direct = _norm_param_grads(weight, bias, width, x.device, ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=x.device)
         if extras is None:
             check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                       rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
+                                       int(direct), rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
         else:
             _, rps, p, seed = extras
             check(lib.hs_layernorm_drop_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
-                                            ptr(ws), ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
+                                            ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
                   "hs_layernorm_drop_bwd")
-        return dx, dgamma.to(wdt), dbeta.to(bdt), (dy if has_res else None), None
+        dw, db = _norm_param_result(weight, bias, dgamma, dbeta, direct)
+        return dx, dw, db, (dy if has_res else None), None
 
 
 def layer_norm(x, weight, bias, residual=None, row_scale=None, drop_p=0.0, seed=None):
@@ -240,13 +262,15 @@ class AddLayerNormFn(torch.autograd.Function):
             check(lib.hs_add_layernorm_drop_fwd(ptr(a), ptr(b), ptr(g), ptr(be), ptr(s), ptr(y), ptr(mean), ptr(rstd), ptr(rs),
                                                 rps, p, seed, rows, width, dt, stream_ptr(a.device)), "hs_add_layernorm_drop_fwd")
         ctx.save_for_backward(s, g, mean, rstd, None if extras is None else extras[0])
-        ctx.meta = (rows, width, dt, weight.dtype, bias.dtype, extras)
+        ctx.meta = (rows, width, dt, extras)
+        ctx.params = (weight, bias)
         return s, y
 
     @staticmethod
     def backward(ctx, ds, dy):
         s, g, mean, rstd, rs = ctx.saved_tensors
-        rows, width, dt, wdt, bdt, extras = ctx.meta
+        rows, width, dt, extras = ctx.meta
+        weight, bias = ctx.params
         if dy is None:  # only the sum was used downstream
             if extras is None:
                 return ds, ds, None, None, None
@@ -254,20 +278,21 @@ class AddLayerNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         ds_c = None if ds is None else ds.contiguous()
         da = torch.empty_like(s)
-        dgamma = torch.empty(width, dtype=torch.float32, device=s.device)
-        dbeta = torch.empty(width, dtype=torch.float32, device=s.device)
+        dgamma, dbeta, direct = _norm_param_grads(weight, bias, width, s.device, ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=s.device)
         if extras is None:
             check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(da), ptr(dgamma),
-                                           ptr(dbeta), ptr(ws), rows, width, dt, stream_ptr(s.device)), "hs_add_layernorm_bwd")
+                                           ptr(dbeta), ptr(ws), int(direct), rows, width, dt, stream_ptr(s.device)),
+                  "hs_add_layernorm_bwd")
             db = da
         else:
             _, rps, p, seed = extras
             db = torch.empty_like(s)
             check(lib.hs_add_layernorm_drop_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(da), ptr(db),
-                                                ptr(dgamma), ptr(dbeta), ptr(ws), ptr(rs), rps, p, seed, rows, width, dt,
-                                                stream_ptr(s.device)), "hs_add_layernorm_drop_bwd")
-        return da, db, dgamma.to(wdt), dbeta.to(bdt), None
+                                                ptr(dgamma), ptr(dbeta), ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width,
+                                                dt, stream_ptr(s.device)), "hs_add_layernorm_drop_bwd")
+        dw, dbias = _norm_param_result(weight, bias, dgamma, dbeta, direct)
+        return da, db, dw, dbias, None
 
 
 def add_layer_norm(a, b, weight, bias, row_scale=None, drop_p=0.0, seed=None):
@@ -333,6 +358,40 @@ ASYNC_WGRAD = None  # an AsyncWgrad instance, or None
 GRAD_SINK = None
 
 
+class ParamCastCache:
+    """Activation-dtype copies of the fp32 master parameters of the Linear layers.  Refreshed for ALL registered parameters
+    by one multi-tensor copy when any of them changed since the last refresh (the optimizer step bumps their version
+    counters), instead of one cast kernel per parameter and forward."""
+
+    def __init__(self, params, dtype):
+        self.params = [p for p in params if p.dtype != dtype]
+        self.dtype = dtype
+        self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.versions = None
+
+    def refresh(self):
+        versions = [p._version for p in self.params]
+        if versions != self.versions:
+            with torch.no_grad():
+                torch._foreach_copy_(self.shadows, self.params)
+            self.versions = versions
+
+    def get(self, p, dtype):
+        i = self.index.get(id(p)) if dtype == self.dtype else None
+        return None if i is None else self.shadows[i]
+
+
+CAST_CACHE = None  # a refreshed ParamCastCache while a model forward is running (set by SwinHPTransformerSys.forward)
+
+
+def _cast_param(p, dtype):
+    if p.dtype == dtype:
+        return p
+    c = CAST_CACHE.get(p, dtype) if CAST_CACHE is not None else None
+    return p.to(dtype) if c is None else c
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b with fp32 master parameters and activations in x.dtype.
     forward / input gradient: library GEMM; weight + bias gradient (bf16): `hs_linear_wgrad` (split over the token axis,
@@ -341,8 +400,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         _require_gpu(x, weight, bias)
-        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
-        b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
+        w = _cast_param(weight, x.dtype)
+        b = None if bias is None else _cast_param(bias, x.dtype)
         ctx.save_for_backward(x, weight)
         ctx.bias_param = bias
         ctx.w_cast = w if w is not weight else None  # activation-dtype copy, reused by the input-gradient GEMM

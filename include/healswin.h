@@ -172,12 +172,13 @@ int hs_gather_rows(const void* x, void* out, const int32_t* idx, int64_t roll,
 int hs_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta,
                      void* y, float* mean, float* rstd,
                      int64_t rows, int width, int dtype, void* stream);
-/* dx [dev] dtype[rows, width]; dgamma, dbeta [dev] f32[width] are OVERWRITTEN (sum over all rows).
+/* dx [dev] dtype[rows, width]; dgamma, dbeta [dev] f32[width]: sum over all rows, OVERWRITTEN, or ADDED to
+ * the existing contents when accumulate != 0 (a parameter's fp32 .grad buffer).
  * The residual branch's gradient is dy itself (identity) and is not produced here.
  * workspace [dev] f32[hs_layernorm_bwd_workspace(rows, width)] */
 int64_t hs_layernorm_bwd_workspace(int64_t rows, int width);
 int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                     void* dx, float* dgamma, float* dbeta, float* workspace,
+                     void* dx, float* dgamma, float* dbeta, float* workspace, int accumulate,
                      int64_t rows, int width, int dtype, void* stream);
 
 /* Fused residual add + LayerNorm (v1 norm placement, models_torch/swin_hp_transformer.py:337-338 and :316 of the
@@ -189,7 +190,7 @@ int hs_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const
                          int64_t rows, int width, int dtype, void* stream);
 int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma,
                          const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
-                         int64_t rows, int width, int dtype, void* stream);
+                         int accumulate, int64_t rows, int width, int dtype, void* stream);
 
 /* Train-mode variants with the block's stochastic regularisers fused in (models_torch/swin_hp_transformer.py:173 proj_drop,
  * :43 Mlp output dropout, :334-338 DropPath): drop() is a counter-based dropout mask (drop_p, seed; regenerated by the
@@ -202,14 +203,14 @@ int hs_layernorm_drop_fwd(const void* x, const void* residual, const float* gamm
                           float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample, float drop_p,
                           uint64_t seed, int64_t rows, int width, int dtype, void* stream);
 int hs_layernorm_drop_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                          void* dx, float* dgamma, float* dbeta, float* workspace, const float* row_scale,
+                          void* dx, float* dgamma, float* dbeta, float* workspace, int accumulate, const float* row_scale,
                           int64_t rows_per_sample, float drop_p, uint64_t seed, int64_t rows, int width, int dtype,
                           void* stream);
 int hs_add_layernorm_drop_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* sum_out, void* y,
                               float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample, float drop_p,
                               uint64_t seed, int64_t rows, int width, int dtype, void* stream);
 int hs_add_layernorm_drop_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
-                              const float* rstd, void* da, void* db, float* dgamma, float* dbeta, float* workspace,
+                              const float* rstd, void* da, void* db, float* dgamma, float* dbeta, float* workspace, int accumulate,
                               const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed,
                               int64_t rows, int width, int dtype, void* stream);
 
