@@ -48,18 +48,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int tok0, i
 }
 
 struct Geometry {
-    int tile_n, tiles_n, tiles_k, tiles, slices, chunks, per_xcd;
+    int tile_n, tile_k, tiles_n, tiles_k, tiles, slices, chunks, per_xcd, dma;
     int64_t rows_per_slice;
 };
 
-inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
+inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int wgs_per_cu) {
     Geometry g;
     g.tile_n = (n_out % 256 == 0 || n_out >= 512) ? 256 : 128;
+    g.tile_k = tile_k;
     g.tiles_n = (n_out + g.tile_n - 1) / g.tile_n;
-    g.tiles_k = (k_in + kTileK - 1) / kTileK;
+    g.tiles_k = (k_in + tile_k - 1) / tile_k;
     g.tiles = g.tiles_n * g.tiles_k;
-    // one resident round: 2 workgroups per CU (LDS / VGPR bound) x 256 CUs, all of equal length; at least 512 tokens per slice
-    static const int wgs_per_cu = getenv("HS_WGRAD_WGS_PER_CU") ? atoi(getenv("HS_WGRAD_WGS_PER_CU")) : 2;
+    // one resident round of equal workgroups over the 256 CUs; at least 512 tokens per slice
     int64_t want = (256 * wgs_per_cu) / g.tiles;
     int64_t max_by_rows = (rows + 511) / 512;
     if (want > max_by_rows) want = max_by_rows;
@@ -70,6 +70,23 @@ inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
     g.rows_per_slice = ((rps + kTok - 1) / kTok) * kTok;
     g.chunks = g.slices > 2 * kReduceChunks ? kReduceChunks : 1;
     g.per_xcd = (g.slices * g.tiles + 7) / 8;
+    // the LDS-DMA kernels address a slice through 32-bit buffer offsets
+    g.dma = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * 2 < ((int64_t)1 << 31);
+    return g;
+}
+
+// Tile shapes: 256 x 256 (8 waves, one workgroup per CU) when both extents allow it -- a third less L2 -> LDS fill traffic
+// per flop than 256 x 128, and the fill path is what bounds the compute-heavy shapes; else 256 x 128 or 128 x 128 (4 waves,
+// two workgroups per CU).  HS_WGRAD_VARIANT=0 selects the register-staged kernel (A/B measurements).
+inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
+    static const int variant = getenv("HS_WGRAD_VARIANT") ? atoi(getenv("HS_WGRAD_VARIANT")) : 1;
+    static const int big = getenv("HS_WGRAD_BIG_TILE") ? atoi(getenv("HS_WGRAD_BIG_TILE")) : 1;
+    if (variant == 1 && big && k_in % 256 == 0 && (n_out % 256 == 0 || n_out >= 512)) {
+        const Geometry g = geometry_for(rows, n_out, k_in, 256, 1);
+        if (g.dma) return g;
+    }
+    Geometry g = geometry_for(rows, n_out, k_in, kTileK, 2);
+    if (variant != 1) g.dma = 0;
     return g;
 }
 
@@ -241,26 +258,27 @@ __device__ __forceinline__ s16x8 tr_frag_asm(uint32_t a, int ks) {
     return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int NB>
-__global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+template <int NB, int TK>
+__global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                            float* __restrict__ part_w, float* __restrict__ part_b,
                                                            int64_t rows, int n_out, int k_in, Geometry g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource / LDS-DMA builtins exist in the device pass only
     constexpr int TN = 64 * NB;
-    constexpr int YRB = TN * 2, XRB = kTileK * 2;    // bytes of one staged dY / X tile row
+    constexpr int WK = TK / 64, NW = 2 * WK, NT = 64 * NW;  // waves along k, waves, threads: waves in 2 x WK, each (32*NB) x 64
+    constexpr int YRB = TN * 2, XRB = TK * 2;    // bytes of one staged dY / X tile row
     constexpr int YB = kTok * YRB, XB = kTok * XRB;  // bytes of one staged dY / X tile
     constexpr int STAGE = YB + XB, NSTAGE = 3;
-    constexpr int YI = YB / 1024 / 4, XI = XB / 1024 / 4;  // 1-KB DMA instructions per wave and stage
-    constexpr int YCH = YRB / 16;                          // 16-byte chunks per dY tile row
+    constexpr int YI = YB / 1024 / NW, XI = XB / 1024 / NW;  // 1-KB DMA instructions per wave and stage
+    constexpr int YCH = YRB / 16, XCH = XRB / 16;           // 16-byte chunks per dY / X tile row
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
     float* bred = (float*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WK, wk = wave % WK;
     int slice, tile;
     if (!block_to_work(g, blockIdx.x, slice, tile)) return;
     const int tn = tile / g.tiles_k, tk = tile % g.tiles_k;
-    const int n0 = tn * TN, k0 = tk * kTileK;
+    const int n0 = tn * TN, k0 = tk * TK;
     const int64_t m_begin = (int64_t)slice * g.rows_per_slice;
     int64_t m_end = m_begin + g.rows_per_slice;
     if (m_end > rows) m_end = rows;
@@ -280,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const uint16_t* __res
     }
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
-        const int p = (wave * XI + j) * 64 + lane, row = p >> 4, pc = p & 15;
+        const int p = (wave * XI + j) * 64 + lane, row = p / XCH, pc = p % XCH;
         voff_x[j] = row * k_in * 2 + k0 * 2 + ((pc ^ ((row & 3) << 2)) << 4);
     }
     const int ystep = kTok * n_out * 2, xstep = kTok * k_in * 2;
@@ -312,7 +330,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const uint16_t* __res
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // bias partial sums: thread -> (row group tid / YCH, logical chunk tid % YCH)
     const int yr = tid / YCH, yc = tid % YCH;
-    const int boff = yr * YRB + ((yc ^ ((yr & 3) << 2)) << 4);  // rows yr + (256 / YCH) * ps share (row & 3)
+    const int boff = yr * YRB + ((yc ^ ((yr & 3) << 2)) << 4);  // rows yr + (NT / YCH) * ps share (row & 3)
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     f32x16 acc[NB][2];
@@ -364,14 +382,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const uint16_t* __res
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[1][i]), __builtin_bit_cast(bf16x8, bf[1][j]), acc[i][j], 0, 0, 0);
         if (do_bias) {  // column sums of the staged dY tile (also asm reads: a plain LDS load would drain the DMA queue)
-            constexpr int PS = kTok / (256 / YCH);
+            constexpr int PS = kTok / (NT / YCH);
             u32x4 v[PS];
             const uint32_t ba = lds0 + buf * STAGE + boff;
             asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(ba));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[1]) : "v"(ba), "n"((256 / YCH) * YRB));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[1]) : "v"(ba), "n"((NT / YCH) * YRB));
             if constexpr (PS == 4) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[2]) : "v"(ba), "n"(2 * (256 / YCH) * YRB));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[3]) : "v"(ba), "n"(3 * (256 / YCH) * YRB));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[2]) : "v"(ba), "n"(2 * (NT / YCH) * YRB));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[3]) : "v"(ba), "n"(3 * (NT / YCH) * YRB));
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
@@ -414,7 +432,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const uint16_t* __res
         if (tid < TN) {
             float t = 0.f;
 #pragma unroll
-            for (int rg = 0; rg < 256 / YCH; ++rg) t += bred[rg * TN + tid];
+            for (int rg = 0; rg < NT / YCH; ++rg) t += bred[rg * TN + tid];
             if (n0 + tid < n_out) part_b[(int64_t)slice * ((int64_t)n_out * k_in + n_out) + n0 + tid] = t;
         }
     }
@@ -475,21 +493,18 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     float* mid = workspace + (int64_t)g.slices * rec;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(8 * g.per_xcd));
-    static const int variant = getenv("HS_WGRAD_VARIANT") ? atoi(getenv("HS_WGRAD_VARIANT")) : 1;
-    const bool dma_ok = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * 2 < (int64_t)1 << 31;
-    if (variant == 1 && dma_ok) {
-        if (g.tile_n == 256)
-            hipLaunchKernelGGL(wgrad_dma_kernel<4>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b,
-                               rows, n_out, k_in, g);
-        else
-            hipLaunchKernelGGL(wgrad_dma_kernel<2>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b,
-                               rows, n_out, k_in, g);
-    } else if (g.tile_n == 256)
-        hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b, rows,
-                           n_out, k_in, g);
+    const uint16_t* dyp = (const uint16_t*)dy;
+    const uint16_t* xp = (const uint16_t*)x;
+    if (g.dma && g.tile_k == 256)
+        hipLaunchKernelGGL((wgrad_dma_kernel<4, 256>), grid, dim3(512), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
+    else if (g.dma && g.tile_n == 256)
+        hipLaunchKernelGGL((wgrad_dma_kernel<4, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
+    else if (g.dma)
+        hipLaunchKernelGGL((wgrad_dma_kernel<2, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
+    else if (g.tile_n == 256)
+        hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
     else
-        hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)x, part_w, part_b, rows,
-                           n_out, k_in, g);
+        hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
     HS_LAUNCH_CHECK("linear_wgrad");
     const int64_t count = dbias ? rec : n;  // without a bias the tail of each record is never written nor read
     const unsigned bx = (unsigned)((count / 4 + 255) / 256);
