@@ -169,6 +169,9 @@ def main():
     ap.add_argument("--paper-drop-rates", action="store_true",
                     help="train with the paper's drop_rate = attn_drop_rate = drop_path_rate = 0.1 instead of 0")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="ignore the shipped TunableOp results for the library GEMMs")
+    ap.add_argument("--tune-gemm", metavar="CSV", default=None,
+                    help="(maintenance) run PyTorch TunableOp tuning over this workload's library GEMMs during the warm-up and "
+                         "write the results file CSV (copy it to heal-swin_amd/tuning/); the timed numbers of such a run are not a benchmark")
     ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
     args = ap.parse_args()
 
@@ -192,7 +195,12 @@ def main():
     # tuned once on an MI355X with PyTorch TunableOp (tuning itself stays OFF here; a validator mismatch -- other ROCm,
     # other GPU -- makes PyTorch ignore the file and fall back to the library heuristic).
     tuned = os.path.join(ROOT, "heal-swin_amd", "tuning", f"tunableop_gfx950_{args.workload}_bs{args.batch}_{args.dtype}.csv")
-    if os.path.exists(tuned) and not args.no_tuned_gemm:
+    if args.tune_gemm:
+        os.makedirs(os.path.dirname(os.path.abspath(args.tune_gemm)), exist_ok=True)
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_filename(args.tune_gemm, insert_device_ordinal=False)
+    elif os.path.exists(tuned) and not args.no_tuned_gemm:
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
         torch.cuda.tunable.set_filename(tuned, insert_device_ordinal=False)
@@ -234,6 +242,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if args.tune_gemm:
+        torch.cuda.tunable.tuning_enable(False)  # every shape was met during the warm-up; PyTorch writes the file at exit
     if args.graph:
         if world > 1 or args.paper_drop_rates:
             raise SystemExit("--graph supports single-GPU runs without dropout (collectives / host-drawn dropout seeds are not captured)")
@@ -273,7 +283,7 @@ def main():
                        "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
                        "launch": "hip graph replay" if args.graph else "eager",
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2), "final_loss": loss_val,
-                       "library_gemm_selection": "TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic"},
+                       "library_gemm_selection": "TunableOp tuning run" if args.tune_gemm else ("TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic")},
         }
         if timings:
             agg = {}
