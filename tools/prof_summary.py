@@ -14,6 +14,9 @@ def family(n):
     if "layernorm" in n: return "hs layernorm*"
     if "rel_bias" in n: return "hs rel_bias*"
     if "gather_rows" in n: return "hs gather_rows"
+    if "wgrad" in n: return "hs linear_wgrad"
+    if "reduce_slices" in n: return "hs linear_wgrad slice reduce"
+    if "gelu" in n: return "hs gelu fwd/bwd"
     if "hs::" in n: return "hs other"
     if n.startswith("Cijk") or n.startswith("Custom_Cijk"): return "hipBLASLt GEMM"
     if "Gelu" in n: return "torch GELU fwd/bwd"
