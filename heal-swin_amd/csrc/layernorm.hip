@@ -301,25 +301,35 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
     }
 }
 
-// sums the per-workgroup partial rows: 16 columns x 16 row slices per workgroup (accumulate: adds to dgamma / dbeta)
-__global__ void __launch_bounds__(256) layernorm_param_reduce_kernel(const float* __restrict__ partials,
-                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                     int nblocks, int width, int accumulate) {
-    __shared__ float part[16][17];
-    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + cl;  // over 2*width
+// Sum of the per-workgroup partial rows [nblocks][2 * width] in two coalesced levels: level 1 folds the rows into
+// kReduceGroups group rows (workgroup = 64 columns x one row group, a wave per row quarter, 256-byte row segments), level 2
+// folds the group rows into dgamma | dbeta (overwrite, or add when accumulate != 0).  Deterministic order.
+constexpr int kReduceGroups = 16;
+__global__ void __launch_bounds__(256) layernorm_param_reduce1_kernel(const float* __restrict__ partials, float* __restrict__ mid,
+                                                                      int nblocks, int width2) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int per = (nblocks + kReduceGroups - 1) / kReduceGroups;
+    const int begin = blockIdx.y * per, end = begin + per < nblocks ? begin + per : nblocks;
     float acc = 0.f;
-    if (col < 2 * width)
-        for (int b = slice; b < nblocks; b += 16) acc += partials[(size_t)b * 2 * width + col];
-    part[slice][cl] = acc;
-    __syncthreads();
-    if (slice == 0 && col < 2 * width) {
-        float tot = 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) tot += part[s2][cl];
-        float* dst = col < width ? dgamma + col : dbeta + (col - width);
-        *dst = accumulate ? *dst + tot : tot;
+    if (col < width2) {
+#pragma unroll 8
+        for (int b = begin + wave; b < end; b += 4) acc += partials[(size_t)b * width2 + col];
     }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col < width2) mid[(size_t)blockIdx.y * width2 + col] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+__global__ void __launch_bounds__(256) layernorm_param_reduce2_kernel(const float* __restrict__ rows_in, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta, int nrows, int width,
+                                                                      int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;  // over 2 * width
+    if (col >= 2 * width) return;
+    float tot = 0.f;
+    for (int r = 0; r < nrows; ++r) tot += rows_in[(size_t)r * 2 * width + col];
+    float* dst = col < width ? dgamma + col : dbeta + (col - width);
+    *dst = accumulate ? *dst + tot : tot;
 }
 
 // workgroups of the backward: enough to fill the chip for long inputs, few enough that the partial rows stay cheap
@@ -362,7 +372,16 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in, dadd_out,
                        ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed, v1_mode);
     HS_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(256), 0, s, ws, dgamma, dbeta, blocks,
+    const float* rows_in = ws;
+    int nrows = blocks;
+    if (blocks > 4 * kReduceGroups) {
+        float* mid = ws + (size_t)blocks * 2 * width;
+        hipLaunchKernelGGL(layernorm_param_reduce1_kernel, dim3((2 * width + 63) / 64, kReduceGroups), dim3(256), 0, s, ws, mid, blocks,
+                           2 * width);
+        rows_in = mid;
+        nrows = kReduceGroups;
+    }
+    hipLaunchKernelGGL(layernorm_param_reduce2_kernel, dim3((2 * width + 255) / 256), dim3(256), 0, s, rows_in, dgamma, dbeta, nrows,
                        width, accumulate);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
     return HS_OK;
@@ -461,7 +480,9 @@ int hs_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const
     return ln_fwd_impl(a, nullptr, gamma, beta, y, mean, rstd, rows, width, dtype, stream, b, sum_out, hs::LnExtra{});
 }
 
-int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) { return (int64_t)hs::bwd_blocks(rows) * 2 * width; }
+int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) {
+    return (int64_t)(hs::bwd_blocks(rows) + hs::kReduceGroups) * 2 * width;
+}
 
 int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, float* workspace, int accumulate, int64_t rows, int width, int dtype,

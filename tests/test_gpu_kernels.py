@@ -470,3 +470,38 @@ def test_block_with_paper_drop_rates_runs_and_is_identity_in_eval(v2):
     assert torch.isfinite(xt.grad.float()).all()
     for n, prm in blk.named_parameters():
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), n
+
+
+def test_layernorm_param_grads_accumulate_into_existing_buffers():
+    """`accumulate` of hs_layernorm_bwd / hs_add_layernorm_bwd: d_gamma / d_beta are ADDED to what the buffers hold (the
+    direct deposit into a parameter's fp32 .grad), bit-equal to overwrite-then-add."""
+    from heal_swin_amd import _lib
+    lib, ptr, check = _lib.lib, _lib.ptr, _lib.check
+    g = torch.Generator().manual_seed(5)
+    rows, width = 3000, 256
+    x = torch.randn(rows, width, generator=g).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(rows, width, generator=g).to(DEV).to(torch.bfloat16)
+    gamma = (1 + 0.1 * torch.randn(width, generator=g)).to(DEV)
+    beta = torch.zeros(width, device=DEV)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    check(lib.hs_layernorm_fwd(ptr(x), None, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, width, _lib.HS_BF16, None), "fwd")
+    ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), device=DEV)
+    dx = torch.empty_like(x)
+    dg0, db0 = torch.empty(width, device=DEV), torch.empty(width, device=DEV)
+    check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg0), ptr(db0), ptr(ws), 0,
+                               rows, width, _lib.HS_BF16, None), "bwd")
+    start_g, start_b = torch.randn(width, generator=g).to(DEV), torch.randn(width, generator=g).to(DEV)
+    dg1, db1 = start_g.clone(), start_b.clone()
+    check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg1), ptr(db1), ptr(ws), 1,
+                               rows, width, _lib.HS_BF16, None), "bwd acc")
+    assert torch.equal(dg1, start_g + dg0) and torch.equal(db1, start_b + db0)
+    dsum = torch.randn(rows, width, generator=g).to(DEV).to(torch.bfloat16)
+    dg2, db2 = start_g.clone(), start_b.clone()
+    dg3, db3 = torch.empty(width, device=DEV), torch.empty(width, device=DEV)
+    check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(dsum), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg3), ptr(db3), ptr(ws),
+                                   0, rows, width, _lib.HS_BF16, None), "add bwd")
+    check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(dsum), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg2), ptr(db2), ptr(ws),
+                                   1, rows, width, _lib.HS_BF16, None), "add bwd acc")
+    assert torch.equal(dg2, start_g + dg3) and torch.equal(db2, start_b + db3)
