@@ -485,8 +485,12 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     HS_CHECK_ARG(dy && x && dw && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && n_out > 0 && k_in > 0, "bad shape");
     if (dtype != HS_BF16) return fail(HS_ERR_UNSUPPORTED, "hs_linear_wgrad implements bf16 activations only");
-    if (n_out % 8 || k_in % 8) return fail(HS_ERR_UNSUPPORTED, "n_out and k_in must be multiples of 8 (16-byte rows)");
+    // k_in: 16-byte X rows.  n_out: multiples of 8, or of 4 on the LDS-DMA path (its dword-aligned buffer loads read a
+    // narrow dY row -- the 12-class segmentation head -- together with its successors; the surplus columns land in
+    // accumulators that are never stored)
+    if (n_out % 4 || k_in % 8) return fail(HS_ERR_UNSUPPORTED, "n_out must be a multiple of 4 and k_in a multiple of 8");
     const Geometry g = make_geometry(rows, n_out, k_in);
+    if (n_out % 8 && !g.dma) return fail(HS_ERR_UNSUPPORTED, "n_out must be a multiple of 8 for slices beyond 2 GiB");
     const int64_t n = (int64_t)n_out * k_in, rec = n + n_out;
     float* part_w = workspace;
     float* part_b = dbias ? workspace + n : nullptr;  // bias partials live behind each slice's weight partial

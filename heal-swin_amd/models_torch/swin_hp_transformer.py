@@ -474,8 +474,7 @@ class UnetDecoder(nn.Module):
             if dbg:
                 print(f"feature shape after decoder layer {inx}: {x.size()}")
         x = self.up(self.norm_up(x))  # B, Npix, C
-        w = self.output.weight[:, :, 0]
-        x = F.linear(x, w.to(x.dtype))  # 1x1 conv without bias (ref :756-761)
+        x = ops.linear(x, self.output.weight[:, :, 0])  # 1x1 conv without bias (ref :756-761); weight gradient by hs_linear_wgrad
         return x.transpose(1, 2)  # B, f_out, Npix
 
 

@@ -442,7 +442,7 @@ class LinearFn(torch.autograd.Function):
         want_b = bias is not None and ctx.needs_input_grad[2]
         if not (want_w or want_b):
             return dx, None, None
-        hip_ok = x.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and x2.is_contiguous()
+        hip_ok = x.dtype == torch.bfloat16 and n_out % 4 == 0 and k_in % 8 == 0 and x2.is_contiguous()
         aw = ASYNC_WGRAD
         sink = GRAD_SINK if aw is None else aw.sink
         direct = ((aw is not None or GRAD_SINK is not None) and hip_ok and want_w and weight.grad is not None

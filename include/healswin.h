@@ -231,7 +231,8 @@ int hs_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, float drop_p
  *   dy [dev] bf16[rows, n_out], x [dev] bf16[rows, k_in] (row-major token rows); dw [dev] f32[n_out, k_in] and
  *   dbias [dev] f32[n_out] (may be NULL) are overwritten (accumulate == 0) or added to (accumulate != 0: the
  *   caller's .grad buffers); workspace [dev] f32[hs_linear_wgrad_workspace(...)].
- * bf16 activations only (HS_BF16); n_out and k_in multiples of 8.  Split over the token axis, deterministic.
+ * bf16 activations only (HS_BF16); k_in a multiple of 8, n_out a multiple of 4 (of 8 when a token slice exceeds 2 GiB).
+ * Split over the token axis, deterministic.
  * ---------------------------------------------------------------------------------------------- */
 int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in);
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace,
