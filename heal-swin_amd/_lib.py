@@ -49,6 +49,9 @@ _SIGNATURES = {
                                   ctypes.c_uint64, c_i64, c_int, c_int, c_ptr],
     "hs_add_layernorm_drop_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64,
                                   ctypes.c_float, ctypes.c_uint64, c_i64, c_int, c_int, c_ptr],
+    "hs_seg_ce_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_ptr],
+    "hs_seg_ce_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64,
+                      c_int, c_ptr],
     "hs_layernorm_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_ptr],
 }
 _OTHER = {
@@ -57,6 +60,7 @@ _OTHER = {
     "hs_status_string": ([c_int], ctypes.c_char_p),
     "hs_device_count": ([], c_int),
     "hs_layernorm_bwd_workspace": ([c_i64, c_int], c_i64),
+    "hs_seg_ce_partials": ([c_i64, c_i64], c_i64),
     "hs_linear_wgrad_workspace": ([c_i64, c_int, c_int], c_i64),
     "hs_window_attn_bwd_workspace": ([c_int, c_i64, c_int, c_int, c_int, c_int], c_i64),
 }

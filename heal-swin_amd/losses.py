@@ -1,5 +1,6 @@
 """Caller-side losses of the two reference Lightning modules, so that a train step
-is self-contained.  Thin torch compositions; fp32 arithmetic regardless of the logits dtype."""
+is self-contained.  fp32 arithmetic regardless of the logits dtype; the segmentation cross-entropy runs in fused HIP
+kernels on device tensors, the depth losses are thin torch compositions."""
 import torch
 import torch.nn.functional as F
 
@@ -8,10 +9,54 @@ DEPTH_MEAN = 13.654291032986958
 DEPTH_STD = 29.58008801108711
 
 
+class _SegCrossEntropyFn(torch.autograd.Function):
+    """Weighted CE by `hs_seg_ce_fwd/bwd`: reads the logits in place through their strides (the model's [B, Npix, K] output
+    viewed as [B, K, Npix] is never transposed or widened to fp32) and recomputes the softmax in the backward."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weights):
+        from . import _lib
+        from ._lib import check, lib, ptr, stream_ptr
+        assert logits.dim() == 3 and labels.shape == (logits.shape[0], logits.shape[2]), "logits [B, K, Npix], labels [B, Npix]"
+        if logits.dtype not in (torch.float32, torch.bfloat16):
+            logits = logits.float()
+        if labels.dtype not in (torch.uint8, torch.int32, torch.int64):
+            labels = labels.long()
+        labels = labels.contiguous()
+        B, K, P = logits.shape
+        sb, sk, sp = logits.stride()
+        parts = torch.empty((int(lib.hs_seg_ce_partials(B, P)), 2), dtype=torch.float32, device=logits.device)
+        dt = _lib.dtype_code(logits.dtype)
+        check(lib.hs_seg_ce_fwd(ptr(logits), ptr(labels), ptr(weights), ptr(parts), B, P, K, sb, sk, sp, labels.element_size(), -100,
+                                dt, stream_ptr(logits.device)), "hs_seg_ce_fwd")
+        tot = parts.sum(0)
+        ctx.save_for_backward(logits, labels, weights, tot)
+        return tot[0] / tot[1]
+
+    @staticmethod
+    def backward(ctx, grad):
+        from . import _lib
+        from ._lib import check, lib, ptr, stream_ptr
+        logits, labels, weights, tot = ctx.saved_tensors
+        B, K, P = logits.shape
+        sb, sk, sp = logits.stride()
+        dense = sorted(logits.stride(), reverse=True) == sorted(logits.contiguous().stride(), reverse=True)
+        dl = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device) if dense else torch.empty_like(logits)
+        scale = (grad.to(torch.float32) / tot[1]).reshape(1)
+        db, dk, dp = dl.stride()
+        check(lib.hs_seg_ce_bwd(ptr(logits), ptr(labels), ptr(weights), ptr(scale), ptr(dl), B, P, K, sb, sk, sp, db, dk, dp,
+                                labels.element_size(), -100, _lib.dtype_code(logits.dtype), stream_ptr(logits.device)), "hs_seg_ce_bwd")
+        return dl, None, None
+
+
 def seg_loss(logits, labels, class_weights=None):
     """nn.CrossEntropyLoss(weight)(logits[B,K,Npix], labels.long()[B,Npix])
-    (heal_swin/models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111)."""
-    w = None if class_weights is None else class_weights.to(device=logits.device, dtype=torch.float32)
+    (heal_swin/models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111).
+    Device tensors: the fused HIP kernels (`hs_seg_ce_*`, fp32 arithmetic on bf16 or fp32 logits).  Host tensors (the CPU
+    unit tests of the caller-side formulas): the torch composition."""
+    w = None if class_weights is None else class_weights.to(device=logits.device, dtype=torch.float32).contiguous()
+    if logits.is_cuda:
+        return _SegCrossEntropyFn.apply(logits, labels, w)
     return F.cross_entropy(logits.float(), labels.long(), weight=w)
 
 

@@ -224,6 +224,28 @@ int hs_gelu_fwd(const void* x, void* y, int64_t n, float drop_p, uint64_t seed, 
 int hs_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, float drop_p, uint64_t seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Class-weighted cross-entropy of the segmentation caller (reference: nn.CrossEntropyLoss(weight)(logits[B,K,Npix],
+ * labels.long()[B,Npix]), models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111):
+ *     loss = sum_i w[y_i] (logsumexp_c z_i[c] - z_i[y_i]) / sum_i w[y_i]
+ * logits [dev] dtype, element (b, c, pixel) at b*stride_b + c*stride_k + pixel*stride_p (so the model's native
+ * [B, Npix, K] output viewed as [B, K, Npix] needs no copy); labels [dev] uint8 / int32 / int64 (label_bytes 1/4/8)
+ * [batch, npix] contiguous; class_weights [dev] f32[n_classes] or NULL; pixels labelled ignore_index (or out of range)
+ * are skipped.  n_classes <= 64.
+ *   hs_seg_ce_fwd: partials [dev] f32[hs_seg_ce_partials(batch, npix)][2] = per-workgroup (numerator, denominator);
+ *                  the caller sums them (fixed order) and divides.
+ *   hs_seg_ce_bwd: dlogits (own strides) = scale[0] * w[y] * (softmax(z) - onehot(y)), scale [dev] f32[1] =
+ *                  upstream gradient / denominator (a device scalar: no host synchronisation).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t hs_seg_ce_partials(int64_t batch, int64_t npix);
+int hs_seg_ce_fwd(const void* logits, const void* labels, const float* class_weights, float* partials,
+                  int64_t batch, int64_t npix, int n_classes, int64_t stride_b, int64_t stride_k, int64_t stride_p,
+                  int label_bytes, int64_t ignore_index, int dtype, void* stream);
+int hs_seg_ce_bwd(const void* logits, const void* labels, const float* class_weights, const float* scale, void* dlogits,
+                  int64_t batch, int64_t npix, int n_classes, int64_t stride_b, int64_t stride_k, int64_t stride_p,
+                  int64_t dstride_b, int64_t dstride_k, int64_t dstride_p, int label_bytes, int64_t ignore_index,
+                  int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Weight / bias gradient of the path's Linear layers (autograd of nn.Linear at
  * models_torch/swin_hp_transformer.py:33,:35 (Mlp), :116,:118 (qkv, proj), :375 (PatchMerging.reduction), :415-416
  * (PatchExpand.expand), :438, :717 (concat_back_dim)):

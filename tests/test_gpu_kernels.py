@@ -506,3 +506,36 @@ def test_layernorm_param_grads_accumulate_into_existing_buffers():
     check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(dsum), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg2), ptr(db2), ptr(ws),
                                    1, rows, width, _lib.HS_BF16, None), "add bwd acc")
     assert torch.equal(dg2, start_g + dg3) and torch.equal(db2, start_b + db3)
+
+
+# ----------------------------------------------------------------------------- fused segmentation cross-entropy
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_seg_cross_entropy_layouts_label_types_and_ignore_index(dtype):
+    """hs_seg_ce_fwd/bwd vs torch's fp32 CrossEntropyLoss on the host and vs the oracle: the model's pixel-major logits viewed as [B, K, Npix]
+    (no copy), a class-major tensor, uint8 / int32 / int64 labels, class weights, ignore_index = -100."""
+    from heal_swin_amd import losses as L
+    from oracle import model as OM
+    g = torch.Generator().manual_seed(3)
+    B, K, P = 3, 12, 5000
+    raw = (torch.randn(B, P, K, generator=g) * 3).to(dtype)           # what the decoder head produces
+    labels = torch.randint(0, K, (B, P), generator=g)
+    labels[0, :100] = -100
+    w = torch.rand(K, generator=g) + 0.5
+    ref_in = raw.float().transpose(1, 2).clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, labels, weight=w)  # torch fp32 on the host: ignore_index semantics
+    ref.backward()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2  # bf16: the gradient is rounded to bf16 on store
+    for layout in ("pixel_major_view", "class_major"):
+        z = raw.to(DEV).clone().requires_grad_(True)
+        logits = z.transpose(1, 2) if layout == "pixel_major_view" else z.transpose(1, 2).contiguous()
+        loss = L.seg_loss(logits, labels.to(DEV), w.to(DEV))
+        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), layout
+        loss.backward()
+        got = z.grad.float().cpu().transpose(1, 2)
+        assert float((got - ref_in.grad).abs().max()) <= tol * float(ref_in.grad.abs().max()) + 1e-9, layout
+        assert float(got[0, :, :100].abs().max()) == 0.0  # ignored pixels
+    keep = labels.clamp(min=0)
+    base = float(L.seg_loss(raw.to(DEV).transpose(1, 2), keep.to(DEV)))
+    for lt in (torch.uint8, torch.int32, torch.int64):
+        assert float(L.seg_loss(raw.to(DEV).transpose(1, 2), keep.to(lt).to(DEV))) == base
+    assert abs(base - float(OM.seg_loss(raw.float().transpose(1, 2), keep))) <= 2e-6 * max(1.0, abs(base))
