@@ -220,3 +220,21 @@ def test_depth_head_fp32_full_T_architecture_vs_oracle():
     assert abs(float(loss) - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref)))
     loss.backward()
     assert torch.isfinite(xg.grad).all()
+
+
+def test_uint8_batch_is_accepted_as_is():
+    """The sample format's uint8 images can be handed to the model directly (converted on the GPU): same logits as the
+    reference caller's `.float()` batch."""
+    M = _M()
+    from heal_swin_amd.data_spec import DataSpec
+    cfg = dict(patch_size=4, window_size=16, shift_size=8, shift_strategy="nest_roll", rel_pos_bias="flat", embed_dim=32,
+               depths=[2, 2], num_heads=[2, 4], drop_path_rate=0.0)
+    spec = DataSpec(dim_in=12 * 16 * 16, f_in=3, f_out=5, base_pix=12, class_names=[])
+    torch.manual_seed(2)
+    model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), spec).to(DEV).eval()
+    x8 = torch.randint(0, 256, (2, 3, spec.dim_in), dtype=torch.uint8, device=DEV)
+    for dt in (None, torch.bfloat16):
+        model.compute_dtype = dt
+        with torch.no_grad():
+            a, b = model(x8), model(x8.float())
+        assert a.dtype == b.dtype and torch.equal(a, b)

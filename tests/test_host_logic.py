@@ -37,3 +37,33 @@ def test_cast_param_falls_back_to_a_plain_cast_without_a_cache():
     assert ops._cast_param(p, torch.float32) is p
     c = ops._cast_param(p, torch.bfloat16)
     assert c.dtype == torch.bfloat16 and torch.equal(c, p.detach().to(torch.bfloat16))
+
+
+def test_npz_sample_format_round_trip(tmp_path):
+    """The reference's on-disk sample format (`hp_img` uint8 [3, Npix], `hp_mask` uint8 [Npix] in one .npz,
+    project_on_s2.py:365-372 / hp_datasets.py:92-98): write, list, read, collate, DataSpec."""
+    import numpy as np
+    from heal_swin_amd import data as D
+    rng = np.random.default_rng(0)
+    npix = 8 * 16 * 16
+    samples = {}
+    for name in ("00002_FV", "00001_RV", "00010_MVL"):
+        img = rng.integers(0, 256, (3, npix), dtype=np.uint8)
+        mask = rng.integers(0, 10, npix, dtype=np.uint8)
+        D.write_sample(tmp_path / f"{name}.npz", img, mask)
+        samples[name] = (img, mask)
+    (tmp_path / "metadata.txt").write_text("not a sample")
+    ds = D.HPSegmentationNpzDataset(str(tmp_path))
+    assert len(ds) == 3 and ds.names == sorted(samples)
+    raw = np.load(tmp_path / "00001_RV.npz")
+    assert sorted(raw.files) == ["hp_img", "hp_mask"]            # exactly the reference's keys
+    for i, name in enumerate(ds.names):
+        img, mask = ds[i]
+        assert img.dtype == np.uint8 and img.shape == (3, npix) and mask.dtype == np.uint8 and mask.shape == (npix,)
+        assert np.array_equal(img, samples[name][0]) and np.array_equal(mask, samples[name][1])
+    assert np.array_equal(ds.get_item_by_name("00010_MVL")[1], samples["00010_MVL"][1])
+    imgs, masks = D.collate_uint8([ds[0], ds[2]])
+    assert imgs.dtype == torch.uint8 and tuple(imgs.shape) == (2, 3, npix) and tuple(masks.shape) == (2, npix)
+    spec = D.data_spec_of(ds[0], n_classes=10)
+    assert (spec.dim_in, spec.f_in, spec.f_out, spec.base_pix) == (npix, 3, 10, 8)
+    assert D.data_spec_of((np.zeros((3, 12 * 256 * 256), np.uint8), None), 12).base_pix == 12
