@@ -468,8 +468,8 @@ class UnetDecoder(nn.Module):
         dbg = self.config.dev_mode
         for inx, layer_up in enumerate(self.layers_up):
             if inx > 0:
-                x = torch.cat([x, x_downsample[self.num_layers - 1 - inx]], -1)
-                x = self.concat_back_dim[inx](x)
+                lin = self.concat_back_dim[inx]  # Linear(2c -> c) on cat([x, skip]) (ref :772-775), without the concat copy
+                x = ops.concat_linear(x, x_downsample[self.num_layers - 1 - inx], lin.weight, lin.bias)
             x = layer_up(x)
             if dbg:
                 print(f"feature shape after decoder layer {inx}: {x.size()}")

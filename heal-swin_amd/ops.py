@@ -481,6 +481,71 @@ def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
 
 
+class ConcatLinearFn(torch.autograd.Function):
+    """y = cat([x, skip], -1) W^T + b without materialising the concatenation (the decoder's skip connection,
+    swin_hp_transformer.py:772-775): W = [Wa | Wb] by columns, y = x Wa^T + skip Wb^T + b.  Saves the concat copy in the
+    forward and the strided slices of the concatenated gradient (re-packed by their consumers) in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias):
+        _require_gpu(x, skip, weight, bias)
+        c = x.shape[-1]
+        w = _cast_param(weight, x.dtype)
+        b = None if bias is None else _cast_param(bias, x.dtype)
+        x2, s2 = x.reshape(-1, c), skip.reshape(-1, skip.shape[-1])
+        y = torch.addmm(b, x2, w[:, :c].t()) if b is not None else x2 @ w[:, :c].t()
+        y.addmm_(s2, w[:, c:].t())
+        ctx.save_for_backward(x, skip, weight)
+        ctx.bias_param = bias
+        ctx.w_cast = w if w is not weight else None
+        return y.reshape(x.shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, skip, weight = ctx.saved_tensors
+        bias = ctx.bias_param
+        n_out, c = weight.shape[0], x.shape[-1]
+        cs = weight.shape[1] - c
+        dy2 = dy.reshape(-1, n_out)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        x2, s2 = x.reshape(-1, c), skip.reshape(-1, cs)
+        w = ctx.w_cast if (ctx.w_cast is not None and ctx.w_cast.dtype == dy.dtype) else _cast_param(weight, dy.dtype)
+        ctx.w_cast = None
+        dx = (dy2 @ w[:, :c]).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dskip = (dy2 @ w[:, c:]).reshape(skip.shape) if ctx.needs_input_grad[1] else None
+        want_w = ctx.needs_input_grad[2]
+        want_b = bias is not None and ctx.needs_input_grad[3]
+        if not (want_w or want_b):
+            return dx, dskip, None, None
+        hip_ok = (x.dtype == torch.bfloat16 and n_out % 4 == 0 and c % 8 == 0 and cs % 8 == 0 and x2.is_contiguous()
+                  and s2.is_contiguous())
+        if hip_ok:
+            dwa, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, c, want_b)
+            dwb, _ = LinearFn._wgrad_hip(dy2, s2, n_out, cs, False)
+        else:
+            dwa, dwb = dy2.t() @ x2, dy2.t() @ s2
+            db32 = dy2.sum(0) if want_b else None
+        direct = (GRAD_SINK is not None and want_w and weight.grad is not None and weight.grad.dtype == torch.float32
+                  and (not want_b or (bias.grad is not None and bias.grad.dtype == torch.float32)))
+        if direct:
+            weight.grad[:, :c].add_(dwa)
+            weight.grad[:, c:].add_(dwb)
+            if want_b:
+                bias.grad.add_(db32)
+            if callable(GRAD_SINK):
+                GRAD_SINK(weight)
+                if want_b:
+                    GRAD_SINK(bias)
+            return dx, dskip, None, None
+        dw = torch.cat([dwa, dwb], 1).to(weight.dtype) if want_w else None
+        return dx, dskip, dw, (db32.to(bias.dtype) if want_b else None)
+
+
+def concat_linear(x, skip, weight, bias=None):
+    return ConcatLinearFn.apply(x, skip, weight, bias)
+
+
 # ----------------------------------------------------------------------------- standalone shift (gather rows)
 class GatherRowsFn(torch.autograd.Function):
     """out[:, j] = x[:, idx[j]]  (or roll); backward gathers with the inverse table."""
