@@ -373,7 +373,7 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
 // the bias / bias-gradient registers), which fits 2 waves per SIMD.  dQ rows are private to a wave; dV and dK are sums
 // over queries, so the two waves of a head exchange fp32 partials through LDS: wave 1 sends its dV half to wave 0 (into
 // the then-free V/dO tiles), wave 0 its dK half to wave 1 (into the P/dS' scratch).
-template <int HG, bool DROP>
+template <int HG, bool DROP, bool COS>
 __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
                                                                      float* __restrict__ dscale_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     const int64_t N = p.N;
     const int nW = (int)(N / kWs);
     const int64_t total_windows = (int64_t)p.B * nW;
-    const bool cosine = (p.flags & HS_ATTN_COSINE) != 0;
+    constexpr bool cosine = COS;  // compile-time: the plain variant carries none of the norm / scale-gradient arithmetic
     const float hscale = p.head_scale[h];
     const uint16_t* qkv = (const uint16_t*)p.qkv;
     const uint16_t* fo = (const uint16_t*)p.out;
@@ -454,8 +454,10 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ds += bf_lo(wdo[i]) * bf_lo(wo[i]) + bf_hi(wdo[i]) * bf_hi(wo[i]);
-                sq += bf_lo(wq[i]) * bf_lo(wq[i]) + bf_hi(wq[i]) * bf_hi(wq[i]);
-                sk += bf_lo(wk[i]) * bf_lo(wk[i]) + bf_hi(wk[i]) * bf_hi(wk[i]);
+                if constexpr (COS) {
+                    sq += bf_lo(wq[i]) * bf_lo(wq[i]) + bf_hi(wq[i]) * bf_hi(wq[i]);
+                    sk += bf_lo(wk[i]) * bf_lo(wk[i]) + bf_hi(wk[i]) * bf_hi(wk[i]);
+                }
             }
             ds += __shfl_xor(ds, 1, 64);
             ds += __shfl_xor(ds, 2, 64);
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                     }
                     const float dsv = pr * (dpv - dsum);
                     dbacc[kt][r] += dsv;
-                    dscale_acc = fmaf(dsv * qinv, sraw, dscale_acc);
+                    if constexpr (COS) dscale_acc = fmaf(dsv * qinv, sraw, dscale_acc);
                     accP[kt][r] = prd;        // (dropped) P, the operand of dV
                     accS[kt][r] = dsv * fqn;  // dS'
                 }
@@ -756,10 +758,10 @@ int pick_head_group_bwd(int nH) {
     return nH % 2 == 0 ? 2 : 1;
 }
 
-template <int HG, bool DROP>
+template <int HG, bool DROP, bool COS>
 int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     const LdsLayoutBwd L(HG);
-    auto kern = attn_bwd_mfma_kernel<HG, DROP>;
+    auto kern = attn_bwd_mfma_kernel<HG, DROP, COS>;
     static bool configured = false;
     if (!configured) {
         HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -832,11 +834,13 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
 
 int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream) {
     if (!workspace) return fail(HS_ERR_INVALID_ARG, "the MFMA backward needs a workspace (hs_window_attn_bwd_workspace)");
-    const bool drop = p.drop_p > 0.f;
-    switch (pick_head_group_bwd(p.nH)) {
-        case 2: return drop ? launch_bwd<2, true>(p, workspace, stream) : launch_bwd<2, false>(p, workspace, stream);
-        default: return drop ? launch_bwd<1, true>(p, workspace, stream) : launch_bwd<1, false>(p, workspace, stream);
+    const bool drop = p.drop_p > 0.f, cos = (p.flags & HS_ATTN_COSINE) != 0;
+    if (pick_head_group_bwd(p.nH) == 2) {
+        if (cos) return drop ? launch_bwd<2, true, true>(p, workspace, stream) : launch_bwd<2, false, true>(p, workspace, stream);
+        return drop ? launch_bwd<2, true, false>(p, workspace, stream) : launch_bwd<2, false, false>(p, workspace, stream);
     }
+    if (cos) return drop ? launch_bwd<1, true, true>(p, workspace, stream) : launch_bwd<1, false, true>(p, workspace, stream);
+    return drop ? launch_bwd<1, true, false>(p, workspace, stream) : launch_bwd<1, false, false>(p, workspace, stream);
 }
 
 }  // namespace hs
