@@ -636,35 +636,47 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ exchange the query-sum partials between the head's waves
         __syncthreads();  // every wave is done with the V / dO tiles and with the scratch
-        float* xch_v = (float*)v_tile;  // 8 KB = V + dO tiles: wave 1 -> wave 0, [kt][r][lane]
-        float* xch_k = (float*)scr;     // 8 KB of the scratch:  wave 0 -> wave 1
+        float4* xch_v = (float4*)v_tile;  // 8 KB = V + dO tiles: wave 1 -> wave 0, [kt][r / 4][lane] x 4 floats (b128 accesses)
+        float4* xch_k = (float4*)scr;     // 8 KB of the scratch:  wave 0 -> wave 1
         if (qt == 1) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xch_v[(kt * 16 + r) * 64 + lane] = dv[kt][r];
+                for (int rg = 0; rg < 4; ++rg)
+                    xch_v[(kt * 4 + rg) * 64 + lane] = make_float4(dv[kt][4 * rg], dv[kt][4 * rg + 1], dv[kt][4 * rg + 2], dv[kt][4 * rg + 3]);
         } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xch_k[(kt * 16 + r) * 64 + lane] = dk[kt][r];
+                for (int rg = 0; rg < 4; ++rg)
+                    xch_k[(kt * 4 + rg) * 64 + lane] = make_float4(dk[kt][4 * rg], dk[kt][4 * rg + 1], dk[kt][4 * rg + 2], dk[kt][4 * rg + 3]);
         }
         __syncthreads();
         if (qt == 0) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    *(uint16_t*)(stg + 2 * kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dv[kt][r] + xch_v[(kt * 16 + r) * 64 + lane]);
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 o = xch_v[(kt * 4 + rg) * 64 + lane];
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = kt * 32 + i + 8 * rg + 4 * half;
+                        *(uint16_t*)(stg + 2 * kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dv[kt][4 * rg + i] + ov[i]);
+                    }
                 }
         } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    *(uint16_t*)(stg + kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dk[kt][r] + xch_k[(kt * 16 + r) * 64 + lane]);
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 o = xch_k[(kt * 4 + rg) * 64 + lane];
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = kt * 32 + i + 8 * rg + 4 * half;
+                        *(uint16_t*)(stg + kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dk[kt][4 * rg + i] + ov[i]);
+                    }
                 }
         }
         __syncthreads();
