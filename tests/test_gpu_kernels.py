@@ -1,4 +1,7 @@
 """HIP kernels (through the C ABI / autograd ops) vs the oracle and the golden vectors.  Needs an MI355X."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -8,6 +11,7 @@ from _util import TOL, GRAD_TOL, assert_close
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
 DTYPES = [torch.float32, torch.bfloat16]
 
@@ -539,3 +543,30 @@ def test_seg_cross_entropy_layouts_label_types_and_ignore_index(dtype):
     for lt in (torch.uint8, torch.int32, torch.int64):
         assert float(L.seg_loss(raw.to(DEV).transpose(1, 2), keep.to(lt).to(DEV))) == base
     assert abs(base - float(OM.seg_loss(raw.float().transpose(1, 2), keep))) <= 2e-6 * max(1.0, abs(base))
+
+
+def test_linear_wgrad_register_staged_fallback_kernel():
+    """The register-staged predecessor of the LDS-DMA kernel stays in the library as the fallback for token slices beyond
+    the 2 GiB buffer-offset range; HS_WGRAD_VARIANT=0 (read once per process) selects it, so it is checked in a subprocess."""
+    import subprocess
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from heal_swin_amd._lib import check, lib, ptr
+for rows, n, k, bias in [(4096, 128, 128, True), (777, 96, 288, True), (33000, 512, 2048, False), (100, 8, 16, True), (70000, 256, 512, True)]:
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, k, generator=g).cuda().to(torch.bfloat16)
+    dy = torch.randn(rows, n, generator=g).cuda().to(torch.bfloat16)
+    dw = torch.empty(n, k, device="cuda"); db = torch.empty(n, device="cuda")
+    ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n, k)), device="cuda")
+    check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db) if bias else None, ptr(ws), rows, n, k, 0, 1, None), "wgrad")
+    ref = dy.float().t() @ x.float()
+    assert float((dw - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max())) * max(1.0, (rows / 4096) ** 0.5), (rows, n, k)
+    if bias:
+        rb = dy.float().sum(0)
+        assert float((db - rb).abs().max()) <= 2e-4 * max(1.0, float(rb.abs().max())), (rows, n, k)
+print("fallback ok")
+''' % ROOT
+    env = dict(os.environ, HS_WGRAD_VARIANT="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
