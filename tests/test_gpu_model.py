@@ -238,3 +238,36 @@ def test_uint8_batch_is_accepted_as_is():
         with torch.no_grad():
             a, b = model(x8), model(x8.float())
         assert a.dtype == b.dtype and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("rates", [0.0, 0.1])
+def test_activation_checkpointing_reproduces_the_plain_run(rates):
+    """`use_checkpoint=True` (reference BasicLayer :541-542): the recomputed forward must draw the same dropout / DropPath
+    masks (seeds come from torch's generators, whose state torch.utils.checkpoint restores), so loss and every parameter
+    gradient agree with the plain run (to bf16 rounding: checkpointed blocks run the un-deferred residual/norm kernels, so
+    the last bits differ; a different mask would change the gradients by O(1))."""
+    M = _M()
+    from heal_swin_amd import losses as L
+    from heal_swin_amd.data_spec import DataSpec
+    spec = DataSpec(dim_in=8 * 16 * 16, f_in=3, f_out=6, base_pix=8, class_names=[])
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 256, (2, 3, spec.dim_in), generator=g).float().to(DEV)
+    y = torch.randint(0, 6, (2, spec.dim_in), generator=g).to(DEV)
+    out = {}
+    for ck in (False, True):
+        cfg = dict(patch_size=4, window_size=16, shift_size=4, shift_strategy="ring_shift", rel_pos_bias="flat", embed_dim=32,
+                   depths=[2, 2], num_heads=[2, 4], drop_rate=rates, attn_drop_rate=rates, drop_path_rate=rates,
+                   use_cos_attn=True, use_v2_norm_placement=True, use_checkpoint=ck)
+        torch.manual_seed(9)
+        model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), spec).to(DEV).train()
+        model.compute_dtype = torch.bfloat16
+        torch.manual_seed(123)
+        torch.cuda.manual_seed(123)
+        loss = L.seg_loss(model(x), y)
+        loss.backward()
+        out[ck] = (float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert abs(out[False][0] - out[True][0]) <= 2e-3 * abs(out[False][0])
+    assert out[False][1].keys() == out[True][1].keys()
+    for n, gref in out[False][1].items():
+        scale = max(float(gref.abs().max()), 1e-6)
+        assert float((gref - out[True][1][n]).abs().max()) <= 3e-2 * scale, n
