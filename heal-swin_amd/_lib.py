@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libhealswin.so")
 
 HS_F32, HS_BF16 = 0, 1
 HS_ATTN_COSINE = 1
+HS_ATTN_FORCE_VALU = 2
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

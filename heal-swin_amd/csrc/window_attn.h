@@ -73,4 +73,10 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream);
 int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p);
 int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream);
 
+// fp32 MFMA path: Ws == 64, head_dim == 32, fp32 I/O (v_mfma_f32_32x32x2_f32)
+bool attn_mfma_f32_supported(const AttnParams& p, int dtype);
+int launch_attn_fwd_mfma_f32(const AttnParams& p, hipStream_t stream);
+int64_t attn_bwd_mfma_f32_workspace_floats(const AttnParams& p);
+int launch_attn_bwd_mfma_f32(const AttnParams& p, float* workspace, hipStream_t stream);
+
 }  // namespace hs

@@ -1,5 +1,5 @@
 // C-ABI entry points of the fused shift + window attention op: argument validation and dispatch
-// between the MFMA path (Ws = 64, head_dim = 32, bf16) and the fp32-VALU path (everything else).
+// between the MFMA paths (Ws = 64, head_dim = 32; bf16 and fp32) and the fp32-VALU path (everything else).
 #include "window_attn.h"
 
 namespace {
@@ -54,7 +54,9 @@ int hs_window_attn_fwd(const void* qkv, void* out, float* lse, const float* bias
                              window_size, flags, attn_drop, seed, dtype))
         return st;
     hipStream_t s = (hipStream_t)stream;
-    if (hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_fwd_mfma(p, s);
+    const bool valu = (flags & HS_ATTN_FORCE_VALU) != 0;
+    if (!valu && hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_fwd_mfma(p, s);
+    if (!valu && hs::attn_mfma_f32_supported(p, dtype)) return hs::launch_attn_fwd_mfma_f32(p, s);
     return hs::launch_attn_fwd_generic(p, dtype, s);
 }
 
@@ -67,7 +69,8 @@ int64_t hs_window_attn_bwd_workspace(int batch, int64_t n_tokens, int channels, 
     p.nH = num_heads;
     p.Ws = window_size;
     p.hd = channels / num_heads;
-    return hs::attn_mfma_supported(p, dtype) ? hs::attn_bwd_mfma_workspace_floats(p) : 0;
+    if (hs::attn_mfma_supported(p, dtype)) return hs::attn_bwd_mfma_workspace_floats(p);
+    return hs::attn_mfma_f32_supported(p, dtype) ? hs::attn_bwd_mfma_f32_workspace_floats(p) : 0;
 }
 
 int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
@@ -86,7 +89,9 @@ int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
     p.dbias = bias ? dbias : nullptr;
     p.dhead_scale = (flags & HS_ATTN_COSINE) ? dhead_scale : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_bwd_mfma(p, workspace, s);
+    const bool valu = (flags & HS_ATTN_FORCE_VALU) != 0;
+    if (!valu && hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_bwd_mfma(p, workspace, s);
+    if (!valu && hs::attn_mfma_f32_supported(p, dtype)) return hs::launch_attn_bwd_mfma_f32(p, workspace, s);
     return hs::launch_attn_bwd_generic(p, dtype, s);
 }
 

@@ -758,7 +758,7 @@ __global__ void reduce_scale_partials_kernel(const float* __restrict__ src, floa
 int bwd_slots(const AttnParams& p, int hg) {
     const int groups = p.nH / hg;
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    int64_t slots = (256 * 2 + groups - 1) / groups;
+    int64_t slots = (256 * 2) / groups;  // rounded DOWN: one workgroup beyond the resident set would run as a second round
     if (slots > windows) slots = windows;
     return (int)(slots < 1 ? 1 : slots);
 }
@@ -814,7 +814,7 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
     }
     const int groups = p.nH / HG;
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    int64_t slots = (256 * 2 + groups - 1) / groups;  // persistent grid = resident workgroups (2 per CU at 256 VGPRs)
+    int64_t slots = (256 * 2) / groups;  // persistent grid = resident workgroups (2 per CU at 256 VGPRs), rounded down
     if (slots > windows) slots = windows;
     if (slots < 1) slots = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)slots, (unsigned)groups), dim3(64 * HG), L.total, stream, p);

@@ -83,6 +83,9 @@ class RelPosBiasFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- fused shift + window attention
+FORCE_VALU_ATTENTION = False  # tests / A-B runs: route the attention op to the generic fp32-VALU kernels (HS_ATTN_FORCE_VALU)
+
+
 class WindowAttnCoreFn(torch.autograd.Function):
     """shift -> window_partition -> (cos|scaled) QK^T + bias + mask -> softmax -> @V -> window_reverse -> shift_back
     on the un-shifted qkv tensor (reference swin_hp_transformer.py:319-330 around :136-171)."""
@@ -100,7 +103,7 @@ class WindowAttnCoreFn(torch.autograd.Function):
         out = torch.empty((B, N, C), dtype=qkv.dtype, device=qkv.device)
         need_grad = any(ctx.needs_input_grad[:3])
         lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=qkv.device) if need_grad else None
-        flags = _lib.HS_ATTN_COSINE if cosine else 0
+        flags = (_lib.HS_ATTN_COSINE if cosine else 0) | (_lib.HS_ATTN_FORCE_VALU if FORCE_VALU_ATTENTION else 0)
         # algorithmic traffic: q,k,v read + o written once; flops: QK^T and PV, 2*Ws*hd each per (row, head)
         with _timed("window_attn_fwd", qkv.device, 4 * B * N * C * qkv.element_size(), 4 * B * N * C * window_size):
             check(lib.hs_window_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(bias_c), ptr(hs), ptr(idx), int(roll), ptr(labels),

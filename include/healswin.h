@@ -38,6 +38,7 @@ typedef enum { HS_F32 = 0, HS_BF16 = 1 } hs_dtype;
 
 /* flags of hs_window_attn_* */
 #define HS_ATTN_COSINE 1u      /* cosine attention: L2-normalise q,k (eps 1e-12), per-head scale */
+#define HS_ATTN_FORCE_VALU 2u  /* run the generic fp32-VALU kernels even where an MFMA kernel exists (cross-checks, A/B) */
 
 const char* hs_version(void);
 /* human-readable message of the last failing call on this thread ("" if none) */
@@ -114,7 +115,7 @@ int hs_rel_bias_scatter_grad(const float* dbias, const int32_t* rel_idx, float* 
  *   idx    [dev] int32[N] gather table of the shifter, or NULL: then shifted position j reads token
  *                         (j + roll) mod N   (roll = 0: NoShift; roll = shift_size: NestRollShift)
  *   labels [dev] uint8[N] region labels in shifted order, or NULL (no mask; unshifted blocks)
- *   flags  HS_ATTN_COSINE or 0
+ *   flags  HS_ATTN_COSINE and/or HS_ATTN_FORCE_VALU, or 0
  *   attn_drop, seed  attention dropout of :169 (self.attn_drop on the probabilities): each probability is zeroed with
  *                    probability attn_drop, survivors scaled by 1/(1-attn_drop); the mask is a pure function of
  *                    (seed, image, head, query, key), so hs_window_attn_bwd called with the same seed reproduces it.

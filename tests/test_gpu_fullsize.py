@@ -44,13 +44,26 @@ def test_mfma_path_matches_valu_path_full_size(shifted):
 
     b = qkv.float().requires_grad_(True)
     bb = bias.clone().requires_grad_(True)
-    ob = ops.window_attn_core(b, bb, hs, None, roll, labels, NH, WS, False)  # fp32-VALU path on the same values
-    ob.backward(dout.float())
+    ops.FORCE_VALU_ATTENTION = True
+    try:
+        ob = ops.window_attn_core(b, bb, hs, None, roll, labels, NH, WS, False)  # fp32-VALU path on the same values
+        ob.backward(dout.float())
+    finally:
+        ops.FORCE_VALU_ATTENTION = False
 
     assert_close(oa, ob, 1e-2, "out")
     assert_close(a.grad, b.grad, 3e-2, "dqkv")
     # bias gradient: a sum over 6144 windows; compare relative to its scale
     assert_close(ba.grad / ba.grad.abs().max(), bb.grad / bb.grad.abs().max(), 2e-2, "dbias")
+
+    # third implementation: the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) on the same fp32 values -- fp32 tolerance
+    c = qkv.float().requires_grad_(True)
+    bc = bias.clone().requires_grad_(True)
+    oc = ops.window_attn_core(c, bc, hs, None, roll, labels, NH, WS, False)
+    oc.backward(dout.float())
+    assert_close(oc, ob, 1e-5, "out fp32 mfma vs valu")
+    assert_close(c.grad, b.grad, 1e-4, "dqkv fp32 mfma vs valu")
+    assert_close(bc.grad / bb.grad.abs().max(), bb.grad / bb.grad.abs().max(), 1e-4, "dbias fp32 mfma vs valu")
 
 
 def test_softmax_rows_sum_to_one_full_size():
