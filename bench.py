@@ -200,6 +200,11 @@ def main():
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(True)
         torch.cuda.tunable.set_filename(args.tune_gemm, insert_device_ordinal=False)
+        # longer measurements than the defaults (30 ms / 100 iterations) and operands rotated through a buffer larger than
+        # L2 + MALL, so that candidates are ranked on HBM-resident behaviour as in the real step
+        torch.cuda.tunable.set_max_tuning_duration(int(os.environ.get("HS_TUNE_MS", "100")))
+        torch.cuda.tunable.set_max_tuning_iterations(int(os.environ.get("HS_TUNE_ITERS", "200")))
+        torch.cuda.tunable.set_rotating_buffer_size(int(os.environ.get("HS_TUNE_ROTATE_MB", "512")))
     elif os.path.exists(tuned) and not args.no_tuned_gemm:
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
