@@ -80,8 +80,7 @@ inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int 
 // two workgroups per CU).  HS_WGRAD_VARIANT=0 selects the register-staged kernel (A/B measurements).
 inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
     static const int variant = getenv("HS_WGRAD_VARIANT") ? atoi(getenv("HS_WGRAD_VARIANT")) : 1;
-    static const int big = getenv("HS_WGRAD_BIG_TILE") ? atoi(getenv("HS_WGRAD_BIG_TILE")) : 1;
-    if (variant == 1 && big && k_in % 256 == 0 && (n_out % 256 == 0 || n_out >= 512)) {
+    if (variant == 1 && k_in % 256 == 0 && (n_out % 256 == 0 || n_out >= 512)) {
         const Geometry g = geometry_for(rows, n_out, k_in, 256, 1);
         if (g.dma) return g;
     }
@@ -452,7 +451,8 @@ __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restr
     const int s_begin = blockIdx.y * per;
     const int s_end = s_begin + per < slices ? s_begin + per : slices;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = s_begin; s < s_end; ++s) {
+#pragma unroll 8
+    for (int s = s_begin; s < s_end; ++s) {  // unrolled: independent loads in flight, same summation order
         const float4 v = *(const float4*)(part + (int64_t)s * in_stride + e);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }

@@ -742,7 +742,8 @@ __global__ void reduce_partials_kernel(const float* __restrict__ src, float* __r
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     float acc = 0.f;
-    for (int s = 0; s < parts; ++s) acc += src[(int64_t)s * n + e];
+#pragma unroll 8
+    for (int s = 0; s < parts; ++s) acc += src[(int64_t)s * n + e];  // unrolled: 8 independent loads in flight, same order
     dst[e] += acc;
 }
 
