@@ -55,6 +55,10 @@ class HSLinear(nn.Linear):
     def forward(self, x):
         return ops.linear(x, self.weight, self.bias)
 
+    def forward_passthrough(self, x):
+        """(self(x), alias of x for a residual connection around the branch): see ops.LinearFn."""
+        return ops.linear_passthrough(x, self.weight, self.bias)
+
 
 class DropPath(nn.Module):
     """Stochastic depth per sample (the reference imports timm's; identity when p == 0 or in eval)."""
@@ -87,15 +91,21 @@ class Mlp(nn.Module):
         self.fc2 = HSLinear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x, apply_out_drop=True):
-        h = self.fc1(x)
+    def forward(self, x, apply_out_drop=True, residual_alias=False):
+        """residual_alias: also return an alias of x whose gradient is folded into fc1's input-gradient GEMM."""
+        x_res = None
+        if residual_alias:
+            h, x_res = self.fc1.forward_passthrough(x)
+        else:
+            h = self.fc1(x)
         if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
             # activation and the dropout behind it in one HIP pass (mask regenerated in backward)
             a = ops.gelu_dropout(h, self.drop.p if self.training else 0.0)
         else:
             a = self.drop(self.act(h))
         y = self.fc2(a)
-        return self.drop(y) if apply_out_drop else y  # the caller fuses the output dropout into the next norm kernel
+        y = self.drop(y) if apply_out_drop else y  # the caller fuses the output dropout into the next norm kernel
+        return (y, x_res) if residual_alias else y
 
 
 # ----------------------------------------------------------------------------- attention
@@ -152,16 +162,22 @@ class WindowAttention(nn.Module):
             return None
         return ops.RelPosBiasFn.apply(self.relative_position_bias_table, self._rel_idx32, self.window_size)
 
-    def attend(self, x, window_size, idx, roll, labels, apply_proj_drop=True):
-        """x: [B, N, C] in natural order -> attention branch output [B, N, C] in natural order."""
+    def attend(self, x, window_size, idx, roll, labels, apply_proj_drop=True, residual_alias=False):
+        """x: [B, N, C] in natural order -> attention branch output [B, N, C] in natural order
+        (residual_alias: also an alias of x whose gradient is folded into the qkv input-gradient GEMM)."""
         drop = self.attn_drop.p if self.training else 0.0  # dropout on the attention probabilities (ref :169), in-kernel
         if self.rel_pos_bias is not None and window_size != self.window_size:
             raise AssertionError("relative position bias needs input_resolution >= window_size")  # ref quirk :243-251
-        qkv = self.qkv(x)
+        x_res = None
+        if residual_alias:
+            qkv, x_res = self.qkv.forward_passthrough(x)
+        else:
+            qkv = self.qkv(x)
         o = ops.window_attn_core(qkv, self.bias(), self.head_scale(), idx, roll, labels, self.num_heads, window_size,
                                  self.use_cos_attn, attn_drop=drop)
         y = self.proj(o)
-        return self.proj_drop(y) if apply_proj_drop else y  # the caller fuses proj_drop into the next norm kernel
+        y = self.proj_drop(y) if apply_proj_drop else y  # the caller fuses proj_drop into the next norm kernel
+        return (y, x_res) if residual_alias else y
 
     def forward(self, x, mask=None):
         """Reference-compatible entry: x [num_windows*B, Ws, C], mask [nW, Ws, Ws] in {0,-100} or None."""
@@ -230,13 +246,13 @@ class SwinTransformerBlock(nn.Module):
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "
                 f"window_size={self.window_size}, shift_size={self.shift_size}, mlp_ratio={self.mlp_ratio}")
 
-    def _attention_branch(self, x, apply_proj_drop=True):
+    def _attention_branch(self, x, apply_proj_drop=True, residual_alias=False):
         if not self._shifted:
-            return self.attn.attend(x, self.window_size, None, 0, None, apply_proj_drop)
+            return self.attn.attend(x, self.window_size, None, 0, None, apply_proj_drop, residual_alias)
         idx, _, labels = self.shifter.tables(x.device)
         if self._is_roll:  # modular offset instead of a table
-            return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels, apply_proj_drop)
-        return self.attn.attend(x, self.window_size, idx, 0, labels, apply_proj_drop)
+            return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels, apply_proj_drop, residual_alias)
+        return self.attn.attend(x, self.window_size, idx, 0, labels, apply_proj_drop, residual_alias)
 
     def _hs_norms(self):
         return isinstance(self.norm1, HSLayerNorm) and isinstance(self.norm2, HSLayerNorm)
@@ -284,10 +300,12 @@ class SwinTransformerBlock(nn.Module):
             return self.resolve_pending(*self.forward_deferred(x, None))
         train = self.training
         if self.use_v2_norm_placement and self._hs_norms():  # ref :334-335: x + drop_path(norm(branch)), fused per branch
-            a = self._attention_branch(x, apply_proj_drop=False)
-            x = self.norm1(a, residual=x, row_scale=self._path_scale(x), drop_p=self.attn.proj_drop.p if train else 0.0)
-            m = self.mlp(x, apply_out_drop=False)
-            return self.norm2(m, residual=x, row_scale=self._path_scale(x), drop_p=self.mlp.drop.p if train else 0.0)
+            # the residual operand is the alias handed back by the branch's first Linear: its gradient is then added inside
+            # that Linear's input-gradient GEMM, not by a separate elementwise kernel
+            a, xr = self._attention_branch(x, apply_proj_drop=False, residual_alias=True)
+            x = self.norm1(a, residual=xr, row_scale=self._path_scale(x), drop_p=self.attn.proj_drop.p if train else 0.0)
+            m, xr = self.mlp(x, apply_out_drop=False, residual_alias=True)
+            return self.norm2(m, residual=xr, row_scale=self._path_scale(x), drop_p=self.mlp.drop.p if train else 0.0)
         if self.use_v2_norm_placement:  # foreign norm layers
             x = x + self.drop_path(self.norm1(self._attention_branch(x)))
             return x + self.drop_path(self.norm2(self.mlp(x)))

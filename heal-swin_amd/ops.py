@@ -401,14 +401,19 @@ class LinearFn(torch.autograd.Function):
     fp32 results straight into the master dtype)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, passthrough=False):
         _require_gpu(x, weight, bias)
         w = _cast_param(weight, x.dtype)
         b = None if bias is None else _cast_param(bias, x.dtype)
         ctx.save_for_backward(x, weight)
         ctx.bias_param = bias
         ctx.w_cast = w if w is not weight else None  # activation-dtype copy, reused by the input-gradient GEMM
-        return torch.nn.functional.linear(x, w, b)
+        ctx.passthrough = passthrough
+        y = torch.nn.functional.linear(x, w, b)
+        # passthrough: also hand x back (an alias) for the block's residual connection.  The gradient of that second use then
+        # arrives HERE together with dy, and the input-gradient GEMM adds it as its beta * C term instead of autograd
+        # launching a separate add over the whole activation (v2 norm placement: x + LN(branch(x)), ref :334-335)
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
     def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None):
@@ -427,10 +432,12 @@ class LinearFn(torch.autograd.Function):
         return dw32, db32
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_res=None):
         x, weight = ctx.saved_tensors
         bias = ctx.bias_param
         n_out, k_in = weight.shape
+        if dy is None:  # only the passthrough alias was used downstream
+            return dx_res, None, None, None
         dy2 = dy.reshape(-1, n_out)
         x2 = x.reshape(-1, k_in)
         if not dy2.is_contiguous():
@@ -439,12 +446,15 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w = ctx.w_cast if (ctx.w_cast is not None and ctx.w_cast.dtype == dy.dtype) else (
                 weight if weight.dtype == dy.dtype else weight.to(dy.dtype))
-            dx = (dy2 @ w).reshape(x.shape)
+            if dx_res is not None:
+                dx = torch.addmm(dx_res.reshape(-1, k_in).to(dy2.dtype), dy2, w).reshape(x.shape)
+            else:
+                dx = (dy2 @ w).reshape(x.shape)
         ctx.w_cast = None
         want_w = ctx.needs_input_grad[1]
         want_b = bias is not None and ctx.needs_input_grad[2]
         if not (want_w or want_b):
-            return dx, None, None
+            return dx, None, None, None
         hip_ok = x.dtype == torch.bfloat16 and n_out % 4 == 0 and k_in % 8 == 0 and x2.is_contiguous()
         aw = ASYNC_WGRAD
         sink = GRAD_SINK if aw is None else aw.sink
@@ -467,7 +477,7 @@ class LinearFn(torch.autograd.Function):
                 sink(weight)
                 if want_b:
                     sink(bias)
-            return dx, None, None
+            return dx, None, None, None
         if hip_ok:
             dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b)
             dw = dw32.to(weight.dtype) if want_w else None
@@ -477,11 +487,16 @@ class LinearFn(torch.autograd.Function):
                 dw = (dy2.t() @ x2).to(weight.dtype)
             if want_b:
                 db = dy2.sum(0).to(bias.dtype)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
+
+
+def linear_passthrough(x, weight, bias=None):
+    """(x W^T + b, alias of x): use the alias for a residual connection around the branch this Linear opens."""
+    return LinearFn.apply(x, weight, bias, True)
 
 
 class ConcatLinearFn(torch.autograd.Function):
