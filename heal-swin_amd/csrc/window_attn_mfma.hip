@@ -63,12 +63,16 @@ struct LdsLayout {
 };
 
 template <int HG, bool DROP>
-__global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p) {
+__global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p, int slots, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L(HG);
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;  // g: head inside the group (wave-uniform)
+    // 1-D grid -> (window slot bx, head group by), the head groups of a slot on ONE XCD (see the backward kernel)
+    const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
+    const int by = blocal % groups, bx = bxcd + 8 * (blocal / groups);
+    if (bx >= slots) return;
     const int half = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y * HG + g;
+    const int h = by * HG + g;
     const int C = p.C;
     const int64_t N = p.N;
     const int nW = (int)(N / kWs);
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p)
     const int srow = tid / (4 * HG);   // 0..15
     const int sc = tid % (4 * HG);     // 16-B chunk inside the row's HG*64-B segment
     const int sg = sc >> 2, scc = sc & 3;
-    const int64_t col0 = (int64_t)blockIdx.y * HG * kHd + sc * 8;  // element column inside a C-wide part
+    const int64_t col0 = (int64_t)by * HG * kHd + sc * 8;  // element column inside a C-wide part
 
     // software pipeline: the q/k/v rows of window i+1 are in flight (in registers) while window i is computed, so every
     // workgroup keeps ~HG*12 KB of HBM requests outstanding all the time instead of only during a load phase
@@ -118,9 +122,9 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p)
             for (int rb = 0; rb < 4; ++rb)
                 ld[part][rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + (int64_t)part * C + col0);
     };
-    if ((int64_t)blockIdx.x < total_windows) issue_loads(blockIdx.x);
+    if ((int64_t)bx < total_windows) issue_loads(bx);
 
-    for (int64_t wi = blockIdx.x; wi < total_windows; wi += gridDim.x) {
+    for (int64_t wi = bx; wi < total_windows; wi += slots) {
         const int b = (int)(wi / nW);
         const int w = (int)(wi - (int64_t)b * nW);
         const int64_t j0 = (int64_t)w * kWs;
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p)
             }
         }
         __syncthreads();
-        if (wi + gridDim.x < total_windows) issue_loads(wi + gridDim.x);  // prefetch: lands during the MFMAs / softmax below
+        if (wi + slots < total_windows) issue_loads(wi + slots);  // prefetch: lands during the MFMAs / softmax below
 
         bool mixed = false;  // does this window contain more than one region label?
         if (p.labels) {
@@ -375,13 +379,19 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
 // the then-free V/dO tiles), wave 0 its dK half to wave 1 (into the P/dS' scratch).
 template <int HG, bool DROP, bool COS>
 __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
-                                                                     float* __restrict__ dscale_part) {
+                                                                     float* __restrict__ dscale_part, int slots, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayoutBwd L(HG);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // 1-D grid -> (window slot bx, head group by): the dispatcher places block b on XCD b % 8, and the head groups of one
+    // window slot take ids 8 apart, so they run on the SAME XCD at about the same time -- their rows share 128-B lines when a
+    // head group is narrower than a line (one head = 64 B), and the second reader then hits that XCD's L2
+    const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
+    const int by = blocal % groups, bx = bxcd + 8 * (blocal / groups);
+    if (bx >= slots) return;
     const int g = wv >> 1, qt = wv & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y * HG + g;
+    const int h = by * HG + g;
     const int C = p.C;
     const int64_t N = p.N;
     const int nW = (int)(N / kWs);
@@ -416,13 +426,13 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
     float dscale_acc = 0.f;
 
-    for (int64_t wi = blockIdx.x; wi < total_windows; wi += gridDim.x) {
+    for (int64_t wi = bx; wi < total_windows; wi += slots) {
         // staging geometry: 128*HG threads move 32 rows x HG*64 B per pass, 2 passes per tile.  Derived from an opaque
         // copy of the thread id inside the loop so that the ~40 VGPRs of per-thread addresses are not hoisted and pinned.
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));
         const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;
-        const int64_t col0 = (int64_t)blockIdx.y * HG * kHd + sc * 8;
+        const int64_t col0 = (int64_t)by * HG * kHd + sc * 8;
         unsigned char* st = smem + sg * L.head;
         const int b = (int)(wi / nW);
         const int w = (int)(wi - (int64_t)b * nW);
@@ -723,7 +733,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 
     // ------------------------------------------------------------ per-workgroup partial parameter gradients
     if (dbias_part) {
-        float* dst = dbias_part + ((int64_t)blockIdx.x * p.nH + h) * kWs * kWs + (int64_t)qq * kWs;
+        float* dst = dbias_part + ((int64_t)bx * p.nH + h) * kWs * kWs + (int64_t)qq * kWs;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -733,7 +743,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     }
     if (dscale_part) {  // two waves per head: [slot][head][qt]
         const float tot = wave_sum(dscale_acc);
-        if (lane == 0) dscale_part[((int64_t)blockIdx.x * p.nH + h) * 2 + qt] = tot;
+        if (lane == 0) dscale_part[((int64_t)bx * p.nH + h) * 2 + qt] = tot;
     }
 }
 
@@ -756,10 +766,15 @@ __global__ void reduce_scale_partials_kernel(const float* __restrict__ src, floa
     dst[h] += acc;
 }
 
-int bwd_slots(const AttnParams& p, int hg) {
+int bwd_slots(const AttnParams& p, int hg) {  // (also used by the forward)
+    // Persistent grid = resident workgroups (2 per CU), counted PER XCD: the kernel maps the head groups of a window slot
+    // onto one XCD (32 CUs = 64 workgroups), so an XCD holds floor(64 / groups) slots; one workgroup beyond that would run as
+    // a second round and double the launch time.
     const int groups = p.nH / hg;
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    int64_t slots = (256 * 2) / groups;  // rounded DOWN: one workgroup beyond the resident set would run as a second round
+    int64_t per_xcd = 64 / groups;
+    if (per_xcd < 1) per_xcd = 1;
+    int64_t slots = 8 * per_xcd;
     if (slots > windows) slots = windows;
     return (int)(slots < 1 ? 1 : slots);
 }
@@ -783,7 +798,8 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     const int groups = p.nH / HG, slots = bwd_slots(p, HG);
     float* dbias_part = p.dbias ? workspace : nullptr;
     float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots, (unsigned)groups), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part);
+    const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part, slots, groups);
     HS_LAUNCH_CHECK("attn_bwd_mfma");
     if (dbias_part) {
         const int64_t n = (int64_t)p.nH * kWs * kWs;
@@ -814,11 +830,9 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
         configured = true;
     }
     const int groups = p.nH / HG;
-    const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    int64_t slots = (256 * 2) / groups;  // persistent grid = resident workgroups (2 per CU at 256 VGPRs), rounded down
-    if (slots > windows) slots = windows;
-    if (slots < 1) slots = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots, (unsigned)groups), dim3(64 * HG), L.total, stream, p);
+    const int slots = bwd_slots(p, HG);  // same sizing rule: 2 workgroups per CU, counted per XCD
+    const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * HG), L.total, stream, p, slots, groups);
     HS_LAUNCH_CHECK("attn_fwd_mfma");
     return HS_OK;
 }
