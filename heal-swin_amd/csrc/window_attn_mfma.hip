@@ -766,18 +766,20 @@ __global__ void reduce_scale_partials_kernel(const float* __restrict__ src, floa
     dst[h] += acc;
 }
 
-int bwd_slots(const AttnParams& p, int hg) {  // (also used by the forward)
-    // Persistent grid = resident workgroups (2 per CU), counted PER XCD: the kernel maps the head groups of a window slot
-    // onto one XCD (32 CUs = 64 workgroups), so an XCD holds floor(64 / groups) slots; one workgroup beyond that would run as
-    // a second round and double the launch time.
-    const int groups = p.nH / hg;
+// Persistent grid = resident workgroups, counted PER XCD: the kernels map the head groups of a window slot onto one XCD
+// (32 CUs x 8 wavefronts at <= 256 VGPRs), so an XCD holds floor(capacity / groups) slots; one workgroup beyond that would
+// run as a second round and double the launch time.
+int persistent_slots(const AttnParams& p, int groups, int waves_per_wg) {
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    int64_t per_xcd = 64 / groups;
+    const int capacity = 32 * (8 / waves_per_wg);
+    int64_t per_xcd = capacity / groups;
     if (per_xcd < 1) per_xcd = 1;
     int64_t slots = 8 * per_xcd;
     if (slots > windows) slots = windows;
     return (int)(slots < 1 ? 1 : slots);
 }
+int bwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / hg, 2 * hg); }  // two wavefronts per head
+int fwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / hg, hg); }
 
 int pick_head_group_bwd(int nH) {
     // 37 KB of LDS per head: pairs (128-B segments) where the head count allows; a 3-head group would need 112 KB and
@@ -830,7 +832,7 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
         configured = true;
     }
     const int groups = p.nH / HG;
-    const int slots = bwd_slots(p, HG);  // same sizing rule: 2 workgroups per CU, counted per XCD
+    const int slots = fwd_slots(p, HG);
     const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * HG), L.total, stream, p, slots, groups);
     HS_LAUNCH_CHECK("attn_fwd_mfma");
