@@ -88,19 +88,6 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
     float* qinv_s = (float*)(smem + L.qinv);
     unsigned char* lab_s = smem + L.lab;
 
-    // relative-position bias of this head, in the S^T accumulator layout: tile (kt, qt), register r holds
-    // query qt*32 + l31, key kt*32 + (r&3) + 8*(r>>2) + 4*half
-    float biasr[2][2][16];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, qq = qt * 32 + l31;
-                biasr[kt][qt][r] = p.bias ? p.bias[((int64_t)h * kWs + qq) * kWs + key] * kLog2e : 0.f;
-            }
-
     // staging geometry: 12 steps = 3 parts (q, k, v) x 4 row blocks of 16 rows; a step moves 16 rows x HG*64 B
     const int srow = tid / (4 * HG);   // 0..15
     const int sc = tid % (4 * HG);     // 16-B chunk inside the row's HG*64-B segment
@@ -123,6 +110,21 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
                 ld[part][rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + (int64_t)part * C + col0);
     };
     if ((int64_t)bx < total_windows) issue_loads(bx);
+
+    // (loaded AFTER the first window's rows were requested: both latencies overlap)
+    // relative-position bias of this head, in the S^T accumulator layout: tile (kt, qt), register r holds
+    // query qt*32 + l31, key kt*32 + (r&3) + 8*(r>>2) + 4*half
+    float biasr[2][2][16];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, qq = qt * 32 + l31;
+                biasr[kt][qt][r] = p.bias ? p.bias[((int64_t)h * kWs + qq) * kWs + key] * kLog2e : 0.f;
+            }
+
 
     for (int64_t wi = bx; wi < total_windows; wi += slots) {
         const int b = (int)(wi / nW);
