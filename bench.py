@@ -183,13 +183,20 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hook (tests/test_gpu_parallel.py): several ranks on ONE GPU over gloo exercise this script's multi-rank path on a
+    # 1-GPU box; the driver's runs use one GPU per rank over RCCL
+    shared_gpu = os.environ.get("HS_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     # Library GEMMs (forward / input-gradient of the Linear layers): load the per-shape hipBLASLt/rocBLAS solution choices
     # tuned once on an MI355X with PyTorch TunableOp (tuning itself stays OFF here; a validator mismatch -- other ROCm,

@@ -143,3 +143,23 @@ def test_rccl_backend_single_rank_matches_local():
     dp.remove()
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
+
+
+def test_bench_script_multi_rank_path_on_one_gpu():
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment, barrier + max-over-ranks timing, one JSON line from rank 0) -- with the two ranks sharing this box's single
+    GPU over gloo (HS_BENCH_SHARED_GPU=1) because RCCL needs one GPU per rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, HS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "tiny"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+    assert out["config"]["parallelism"] == "dp2" and "cpu_baseline" not in out and "roofline" in out
