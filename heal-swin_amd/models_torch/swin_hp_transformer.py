@@ -270,8 +270,8 @@ class SwinTransformerBlock(nn.Module):
         """v1 block on the input `x + rs*drop(p)` for pending = (p, rs, drop_p) (or None); returns (x1, pending') with the
         block output = x1 + rs'*drop(m) (ref :337-338 and :316 of the next block)."""
         train = self.training
-        if pending is None:
-            n1 = self.norm1(x)
+        if pending is None:  # x feeds norm1 AND the residual add below: the alias keeps the two gradients in one kernel
+            n1, x = ops.layer_norm_passthrough(x, self.norm1.weight, self.norm1.bias)
         else:
             t, rs, dp = pending
             x, n1 = ops.add_layer_norm(x, t, self.norm1.weight, self.norm1.bias, row_scale=rs, drop_p=dp)

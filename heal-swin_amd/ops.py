@@ -189,7 +189,7 @@ class LayerNormFn(torch.autograd.Function):
     optional per-sample DropPath factor and dropout mask (train mode), absent in eval."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, extras):
+    def forward(ctx, x, weight, bias, residual, extras, passthrough=False):
         _require_gpu(x, weight, bias, residual)
         x = x.contiguous()
         width = x.shape[-1]
@@ -213,18 +213,27 @@ class LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, g, mean, rstd, None if extras is None else extras[0])
         ctx.meta = (rows, width, dt, residual is not None, extras)
         ctx.params = (weight, bias)
-        return y
+        # passthrough (plain norm only): also hand x back as an alias for a second use (the block's residual connection); its
+        # gradient then arrives here with dy and is added inside the backward kernel instead of by a separate elementwise add
+        assert not passthrough or (extras is None and residual is None)
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_alias=None):
         x, g, mean, rstd, rs = ctx.saved_tensors
         rows, width, dt, has_res, extras = ctx.meta
         weight, bias = ctx.params
+        if dy is None:  # only the alias was used downstream
+            return dx_alias, None, None, None, None, None
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma, dbeta, direct = _norm_param_grads(weight, bias, width, x.device, ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=x.device)
-        if extras is None:
+        if dx_alias is not None:
+            check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(dx_alias.contiguous()), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx),
+                                           ptr(dgamma), ptr(dbeta), ptr(ws), int(direct), rows, width, dt, stream_ptr(x.device)),
+                  "hs_add_layernorm_bwd")
+        elif extras is None:
             check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
                                        int(direct), rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
         else:
@@ -233,11 +242,16 @@ class LayerNormFn(torch.autograd.Function):
                                             ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
                   "hs_layernorm_drop_bwd")
         dw, db = _norm_param_result(weight, bias, dgamma, dbeta, direct)
-        return dx, dw, db, (dy if has_res else None), None
+        return dx, dw, db, (dy if has_res else None), None, None
 
 
 def layer_norm(x, weight, bias, residual=None, row_scale=None, drop_p=0.0, seed=None):
     return LayerNormFn.apply(x, weight, bias, residual, _extras(x, row_scale, drop_p, seed))
+
+
+def layer_norm_passthrough(x, weight, bias):
+    """(LayerNorm(x), alias of x): use the alias for the second consumer of x (see LayerNormFn)."""
+    return LayerNormFn.apply(x, weight, bias, None, None, True)
 
 
 class AddLayerNormFn(torch.autograd.Function):
