@@ -18,6 +18,7 @@
 // Roofline: flop/byte = N*K/(N+K): HBM-bound at C <= 256 (stage 0/1), MFMA-bound from C = 512.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "hs_device.h"
 
@@ -52,9 +53,9 @@ struct Geometry {
     int64_t rows_per_slice;
 };
 
-inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int wgs_per_cu) {
+inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int wgs_per_cu, int tile_n = 0, int elt = 2) {
     Geometry g;
-    g.tile_n = (n_out % 256 == 0 || n_out >= 512) ? 256 : 128;
+    g.tile_n = tile_n ? tile_n : ((n_out % 256 == 0 || n_out >= 512) ? 256 : 128);
     g.tile_k = tile_k;
     g.tiles_n = (n_out + g.tile_n - 1) / g.tile_n;
     g.tiles_k = (k_in + tile_k - 1) / tile_k;
@@ -71,7 +72,7 @@ inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int 
     g.chunks = g.slices > 2 * kReduceChunks ? kReduceChunks : 1;
     g.per_xcd = (g.slices * g.tiles + 7) / 8;
     // the LDS-DMA kernels address a slice through 32-bit buffer offsets
-    g.dma = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * 2 < ((int64_t)1 << 31);
+    g.dma = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * elt < ((int64_t)1 << 31);
     return g;
 }
 
@@ -88,6 +89,9 @@ inline Geometry make_geometry(int64_t rows, int n_out, int k_in) {
     if (variant != 1) g.dma = 0;
     return g;
 }
+
+// fp32 activations: 128 x 128 tiles, 16-token stages (16 KB), three workgroups per CU
+inline Geometry make_geometry_f32(int64_t rows, int n_out, int k_in) { return geometry_for(rows, n_out, k_in, kTileK, 3, 128, 4); }
 
 // block id -> (slice, tile).  The dispatcher places block b on XCD b % 8; XCD x takes the contiguous range
 // [x * per_xcd, (x + 1) * per_xcd) of slice-major work ids, so the tiles of one token slice run on one XCD (two at a range
@@ -438,6 +442,185 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 activations
+// The reference's precision = 32 runs: the same split-token scheme on v_mfma_f32_32x32x2_f32.  The instruction contracts
+// TWO tokens (lane half h supplies token 2j + h) and each lane needs one element of one column per operand -- so the
+// row-major token tiles are read as they lie (lanes = consecutive columns: conflict-free ds_read_b32; no transposing reads,
+// no swizzle) and the LDS-DMA image is the plain tile.  128 x 128 tiles, 4 waves of 64 x 64, 16-token stages of 16 KB,
+// three stages, three workgroups per CU; MFMA-bound (the fp32 MFMA peak is 1/16 of bf16's).  hipBLASLt ran these
+// reductions at 10-40 TFLOP/s on the token-heavy stages.
+constexpr int kTokF = 16;
+
+template <int OFF>
+__device__ __forceinline__ float lds_b32(uint32_t a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_b128(uint32_t a) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__global__ void __launch_bounds__(256, 3) wgrad_dma_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               float* __restrict__ part_w, float* __restrict__ part_b, int64_t rows,
+                                                               int n_out, int k_in, Geometry g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TN = 128, TK = 128;
+    constexpr int RB = TN * 4;                       // bytes of one staged tile row (both tiles are 128 floats wide)
+    constexpr int YB = kTokF * RB, XB = kTokF * RB;  // 8 KB each
+    constexpr int STAGE = YB + XB, NSTAGE = 3;
+    constexpr int YI = YB / 1024 / 4, XI = XB / 1024 / 4;  // 1-KB DMA instructions per wave and stage (2 + 2)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+    float* bred = (float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wn = wave >> 1, wk = wave & 1;
+    int slice, tile;
+    if (!block_to_work(g, blockIdx.x, slice, tile)) return;
+    const int tn = tile / g.tiles_k, tk = tile % g.tiles_k;
+    const int n0 = tn * TN, k0 = tk * TK;
+    const int64_t m_begin = (int64_t)slice * g.rows_per_slice;
+    int64_t m_end = m_begin + g.rows_per_slice;
+    if (m_end > rows) m_end = rows;
+    const int m_len = m_end > m_begin ? (int)(m_end - m_begin) : 0;
+    const int nst = (m_len + kTokF - 1) / kTokF;
+    const bool do_bias = part_b != nullptr && tk == 0;
+
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + m_begin * n_out), 0, m_len * n_out * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + m_begin * k_in), 0, m_len * k_in * 4, 0x00020000);
+    int voff_y[YI], voff_x[XI];
+#pragma unroll
+    for (int j = 0; j < YI; ++j) {
+        const int p = (wave * YI + j) * 64 + lane, row = p >> 5, ch = p & 31;  // 32 16-byte chunks per 512-byte row
+        voff_y[j] = row * n_out * 4 + n0 * 4 + (ch << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int p = (wave * XI + j) * 64 + lane, row = p >> 5, ch = p & 31;
+        voff_x[j] = row * k_in * 4 + k0 * 4 + (ch << 4);
+    }
+    const int ystep = kTokF * n_out * 4, xstep = kTokF * k_in * 4;
+    auto issue = [&](int b) {
+        unsigned char* base = smem + b * STAGE;
+#pragma unroll
+        for (int j = 0; j < YI; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void*)(base + (wave * YI + j) * 1024), 16, voff_y[j], 0, 0, 0);
+            voff_y[j] += ystep;
+        }
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(base + YB + (wave * XI + j) * 1024), 16, voff_x[j], 0, 0, 0);
+            voff_x[j] += xstep;
+        }
+    };
+    // LDS reads through inline asm (a compiler-visible LDS load beside the DMA queue is preceded by s_waitcnt vmcnt(0))
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t ya = lds0 + half * RB + (wn * 64 + l31) * 4;       // dY: token 2j + half, column wn*64 + a*32 + l31
+    const uint32_t xa = lds0 + YB + half * RB + (wk * 64 + l31) * 4;  // X : token 2j + half, column wk*64 + b*32 + l31
+    const uint32_t ba = lds0 + (tid >> 5) * RB + (tid & 31) * 16;     // bias sums: thread -> (row of an 8-row group, 4 columns)
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
+
+    auto stage = [&](int t, auto buf_c, auto nbuf_c) {
+        constexpr int buf = decltype(buf_c)::value, nbuf = decltype(nbuf_c)::value;
+        if (t + 1 < nst)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YI + XI) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nst) issue(nbuf);
+        const uint32_t yb = ya + buf * STAGE, xb = xa + buf * STAGE;
+        float fa[8][2], fb[8][2];  // [token pair][32-column block]
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            fa[j][0] = lds_b32<2 * j * RB>(yb);
+            fa[j][1] = lds_b32<2 * j * RB + 128>(yb);
+            fb[j][0] = lds_b32<2 * j * RB>(xb);
+            fb[j][1] = lds_b32<2 * j * RB + 128>(xb);
+        });
+        asm volatile("s_waitcnt lgkmcnt(15)"  // LDS operations return in order: pairs 0..3 (16 reads) have landed
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[1][0]),
+                       "+v"(fb[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]),
+                       "+v"(fb[3][0]), "+v"(fb[3][1]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+                    acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][a], fb[j][b2], acc[a][b2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[4][0]), "+v"(fa[4][1]), "+v"(fb[4][0]), "+v"(fb[4][1]), "+v"(fa[5][0]), "+v"(fa[5][1]), "+v"(fb[5][0]),
+                       "+v"(fb[5][1]), "+v"(fa[6][0]), "+v"(fa[6][1]), "+v"(fb[6][0]), "+v"(fb[6][1]), "+v"(fa[7][0]), "+v"(fa[7][1]),
+                       "+v"(fb[7][0]), "+v"(fb[7][1]));
+#pragma unroll
+        for (int j = 4; j < 8; ++j)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+                    acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][a], fb[j][b2], acc[a][b2], 0, 0, 0);
+        if (do_bias) {  // column sums of the staged dY tile: rows (tid >> 5) and (tid >> 5) + 8
+            u32x4 v0 = lds_b128<0>(ba + buf * STAGE), v1 = lds_b128<8 * RB>(ba + buf * STAGE);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bsum[i] += __uint_as_float(v0[i]) + __uint_as_float(v1[i]);
+        }
+    };
+    if (nst > 0) issue(0);
+    if (nst > 1) issue(1);
+    for (int t = 0; t < nst; t += NSTAGE) {
+        stage(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        if (t + 2 < nst) stage(t + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    }
+
+    float* dst = part_w + (int64_t)slice * ((int64_t)n_out * k_in + n_out);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int kk = k0 + wk * 64 + b2 * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (nn < n_out && kk < k_in) dst[(int64_t)nn * k_in + kk] = acc[a][b2][r];
+            }
+        }
+    if (do_bias) {
+        __syncthreads();  // every wave is done with the stage buffers
+        const int rg = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bred[rg * TN + c4 + i] = bsum[i];
+        __syncthreads();
+        if (tid < TN) {
+            float t = 0.f;
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) t += bred[r2 * TN + tid];
+            if (n0 + tid < n_out) part_b[(int64_t)slice * ((int64_t)n_out * k_in + n_out) + n0 + tid] = t;
+        }
+    }
+#endif
+}
+
 // Sums the slices of chunk blockIdx.y of the partial records part[s * in_stride + 0..count) (n_w weight entries followed
 // by bias entries).  Intermediate pass (final_pass == 0): out[chunk * count + 0..count).  Final pass: weights to dw, bias
 // to db (skipped if null), added to the existing contents when accumulate != 0.
@@ -475,8 +658,10 @@ extern "C" {
 
 int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in) {
     if (rows <= 0 || n_out <= 0 || k_in <= 0) return 0;
-    const hs::Geometry g = hs::make_geometry(rows, n_out, k_in);
-    return (int64_t)(g.slices + (g.chunks > 1 ? g.chunks : 0)) * ((int64_t)n_out * k_in + n_out);
+    // the larger of the bf16 and fp32 geometries (the call does not know the dtype)
+    const hs::Geometry g = hs::make_geometry(rows, n_out, k_in), f = hs::make_geometry_f32(rows, n_out, k_in);
+    const int64_t a = g.slices + (g.chunks > 1 ? g.chunks : 0), b = f.slices + (f.chunks > 1 ? f.chunks : 0);
+    return (a > b ? a : b) * ((int64_t)n_out * k_in + n_out);
 }
 
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out,
@@ -484,13 +669,16 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     using namespace hs;
     HS_CHECK_ARG(dy && x && dw && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && n_out > 0 && k_in > 0, "bad shape");
-    if (dtype != HS_BF16) return fail(HS_ERR_UNSUPPORTED, "hs_linear_wgrad implements bf16 activations only");
-    // k_in: 16-byte X rows.  n_out: multiples of 8, or of 4 on the LDS-DMA path (its dword-aligned buffer loads read a
+    HS_CHECK_ARG(dtype == HS_BF16 || dtype == HS_F32, "dtype must be HS_F32 or HS_BF16");
+    // bf16: k_in: 16-byte X rows.  n_out: multiples of 8, or of 4 on the LDS-DMA path (its dword-aligned buffer loads read a
     // narrow dY row -- the 12-class segmentation head -- together with its successors; the surplus columns land in
-    // accumulators that are never stored)
-    if (n_out % 4 || k_in % 8) return fail(HS_ERR_UNSUPPORTED, "n_out must be a multiple of 4 and k_in a multiple of 8");
-    const Geometry g = make_geometry(rows, n_out, k_in);
-    if (n_out % 8 && !g.dma) return fail(HS_ERR_UNSUPPORTED, "n_out must be a multiple of 8 for slices beyond 2 GiB");
+    // accumulators that are never stored).  fp32: multiples of 4 (16-byte rows); LDS-DMA path only.
+    if (dtype == HS_BF16 && (n_out % 4 || k_in % 8))
+        return fail(HS_ERR_UNSUPPORTED, "bf16: n_out must be a multiple of 4 and k_in a multiple of 8");
+    if (dtype == HS_F32 && (n_out % 4 || k_in % 4)) return fail(HS_ERR_UNSUPPORTED, "fp32: n_out and k_in must be multiples of 4");
+    const Geometry g = dtype == HS_F32 ? make_geometry_f32(rows, n_out, k_in) : make_geometry(rows, n_out, k_in);
+    if (dtype == HS_BF16 && n_out % 8 && !g.dma) return fail(HS_ERR_UNSUPPORTED, "n_out must be a multiple of 8 for slices beyond 2 GiB");
+    if (dtype == HS_F32 && !g.dma) return fail(HS_ERR_UNSUPPORTED, "fp32: a token slice exceeds the 2 GiB buffer-offset range");
     const int64_t n = (int64_t)n_out * k_in, rec = n + n_out;
     float* part_w = workspace;
     float* part_b = dbias ? workspace + n : nullptr;  // bias partials live behind each slice's weight partial
@@ -499,7 +687,10 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     const dim3 grid((unsigned)(8 * g.per_xcd));
     const uint16_t* dyp = (const uint16_t*)dy;
     const uint16_t* xp = (const uint16_t*)x;
-    if (g.dma && g.tile_k == 256)
+    if (dtype == HS_F32)
+        hipLaunchKernelGGL(wgrad_dma_f32_kernel, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, part_w, part_b, rows, n_out,
+                           k_in, g);
+    else if (g.dma && g.tile_k == 256)
         hipLaunchKernelGGL((wgrad_dma_kernel<4, 256>), grid, dim3(512), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
     else if (g.dma && g.tile_n == 256)
         hipLaunchKernelGGL((wgrad_dma_kernel<4, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);

@@ -440,9 +440,9 @@ class LinearFn(torch.autograd.Function):
         if want_b:
             db32 = db_out if db_out is not None else torch.empty(n_out, dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=dev)
-        with _timed("linear_wgrad", dev, 2 * rows * (n_out + k_in), 2 * rows * n_out * k_in):
+        with _timed("linear_wgrad", dev, x2.element_size() * rows * (n_out + k_in), 2 * rows * n_out * k_in):
             check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate,
-                                      _lib.HS_BF16, stream_ptr(dev)), "hs_linear_wgrad")
+                                      _lib.dtype_code(x2.dtype), stream_ptr(dev)), "hs_linear_wgrad")
         return dw32, db32
 
     @staticmethod
@@ -469,7 +469,8 @@ class LinearFn(torch.autograd.Function):
         want_b = bias is not None and ctx.needs_input_grad[2]
         if not (want_w or want_b):
             return dx, None, None, None
-        hip_ok = x.dtype == torch.bfloat16 and n_out % 4 == 0 and k_in % 8 == 0 and x2.is_contiguous()
+        hip_ok = (x2.is_contiguous() and n_out % 4 == 0 and
+                  ((x.dtype == torch.bfloat16 and k_in % 8 == 0) or (x.dtype == torch.float32 and k_in % 4 == 0)))
         aw = ASYNC_WGRAD
         sink = GRAD_SINK if aw is None else aw.sink
         direct = ((aw is not None or GRAD_SINK is not None) and hip_ok and want_w and weight.grad is not None
@@ -550,8 +551,9 @@ class ConcatLinearFn(torch.autograd.Function):
         want_b = bias is not None and ctx.needs_input_grad[3]
         if not (want_w or want_b):
             return dx, dskip, None, None
-        hip_ok = (x.dtype == torch.bfloat16 and n_out % 4 == 0 and c % 8 == 0 and cs % 8 == 0 and x2.is_contiguous()
-                  and s2.is_contiguous())
+        align = 8 if x.dtype == torch.bfloat16 else 4
+        hip_ok = (x.dtype in (torch.bfloat16, torch.float32) and n_out % 4 == 0 and c % align == 0 and cs % align == 0
+                  and x2.is_contiguous() and s2.is_contiguous())
         if hip_ok:
             dwa, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, c, want_b)
             dwb, _ = LinearFn._wgrad_hip(dy2, s2, n_out, cs, False)

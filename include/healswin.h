@@ -251,10 +251,11 @@ int hs_seg_ce_bwd(const void* logits, const void* labels, const float* class_wei
  * models_torch/swin_hp_transformer.py:33,:35 (Mlp), :116,:118 (qkv, proj), :375 (PatchMerging.reduction), :415-416
  * (PatchExpand.expand), :438, :717 (concat_back_dim)):
  *     dw[n, k] = sum_m dy[m, n] * x[m, k]        dbias[n] = sum_m dy[m, n]
- *   dy [dev] bf16[rows, n_out], x [dev] bf16[rows, k_in] (row-major token rows); dw [dev] f32[n_out, k_in] and
+ *   dy [dev] dtype[rows, n_out], x [dev] dtype[rows, k_in] (row-major token rows); dw [dev] f32[n_out, k_in] and
  *   dbias [dev] f32[n_out] (may be NULL) are overwritten (accumulate == 0) or added to (accumulate != 0: the
  *   caller's .grad buffers); workspace [dev] f32[hs_linear_wgrad_workspace(...)].
- * bf16 activations only (HS_BF16); k_in a multiple of 8, n_out a multiple of 4 (of 8 when a token slice exceeds 2 GiB).
+ * dtype HS_BF16: dy, x bf16; k_in a multiple of 8, n_out a multiple of 4 (of 8 when a token slice exceeds 2 GiB).
+ * dtype HS_F32: dy, x f32 (v_mfma_f32_32x32x2_f32); n_out and k_in multiples of 4.
  * Split over the token axis, deterministic.
  * ---------------------------------------------------------------------------------------------- */
 int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in);

@@ -229,11 +229,12 @@ def test_cpu_tensors_are_rejected():
                                               (2048, 256, 1024), (100, 8, 16), (65536, 128, 512), (3000, 24, 40),
                                               (70000, 12, 128), (5000, 20, 96), (40000, 512, 512)])
 @pytest.mark.parametrize("bias", [True, False])
-def test_linear_wgrad_vs_fp32(rows, n_out, k_in, bias):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_linear_wgrad_vs_fp32(rows, n_out, k_in, bias, dtype):
     ops, _, _ = _mods()
     g = torch.Generator().manual_seed(rows + n_out)
-    x = torch.randn(rows, k_in, generator=g).to(DEV).to(torch.bfloat16)
-    dy = torch.randn(rows, n_out, generator=g).to(DEV).to(torch.bfloat16)
+    x = torch.randn(rows, k_in, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(rows, n_out, generator=g).to(DEV).to(dtype)
     w = (torch.randn(n_out, k_in, generator=g) * 0.05).to(DEV).requires_grad_(True)
     b = torch.zeros(n_out, device=DEV, requires_grad=True) if bias else None
     xin = x.clone().requires_grad_(True)
@@ -246,8 +247,8 @@ def test_linear_wgrad_vs_fp32(rows, n_out, k_in, bias):
     if bias:
         ref_b = dy.float().sum(0)
         assert float((b.grad - ref_b).abs().max()) <= 2e-4 * max(1.0, float(ref_b.abs().max()))
-    ref_dx = (dy.float() @ w.detach().to(torch.bfloat16).float())
-    assert_close(xin.grad, ref_dx, 1e-2, "dx")
+    ref_dx = (dy.float() @ w.detach().to(dtype).float())
+    assert_close(xin.grad, ref_dx, 1e-2 if dtype == torch.bfloat16 else 1e-4, "dx")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
