@@ -6,6 +6,8 @@ import sys
 
 
 def family(n):
+    if "attn_bwd_f32" in n: return "hs attn_bwd_mfma_f32"
+    if "attn_fwd_f32" in n: return "hs attn_fwd_mfma_f32"
     if "attn_bwd_mfma" in n: return "hs attn_bwd_mfma"
     if "attn_fwd_mfma" in n: return "hs attn_fwd_mfma"
     if "attn_bwd_generic" in n: return "hs attn_bwd_generic"
