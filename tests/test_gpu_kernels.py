@@ -227,7 +227,8 @@ def test_cpu_tensors_are_rejected():
 # ----------------------------------------------------------------------------- Linear weight / bias gradient
 @pytest.mark.parametrize("rows,n_out,k_in", [(4096, 128, 128), (5000, 384, 128), (777, 96, 288), (33000, 512, 2048),
                                               (2048, 256, 1024), (100, 8, 16), (65536, 128, 512), (3000, 24, 40),
-                                              (70000, 12, 128), (5000, 20, 96), (40000, 512, 512)])
+                                              (70000, 12, 128), (5000, 20, 96), (40000, 512, 512), (1, 8, 8), (31, 16, 24),
+                                              (2000, 300, 200), (513, 1024, 264)])
 @pytest.mark.parametrize("bias", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_linear_wgrad_vs_fp32(rows, n_out, k_in, bias, dtype):
