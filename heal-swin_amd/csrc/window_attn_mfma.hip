@@ -543,20 +543,33 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             const float fq2 = fqn * kLog2e;
             const float lse2 = p.lse[((int64_t)b * p.nH + h) * N + j0 + qq] * kLog2e;
             const float dsum = dsum_s[g * kWs + qq];
-            const int mylab = mixed ? lab_s[qq] : 0;
             const DropRng rng(p, ((int64_t)b * p.nH + h) * N + j0 + qq);
+            // bias (log2 domain) and, in the rare windows cut by the shift boundary, the mask: folded into one additive term
+            // under a single wave-uniform branch so that the element loop below is branch-free
+            float brow[2][16];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    brow[kt][4 * rg] = biasv[kt][rg].x * kLog2e;
+                    brow[kt][4 * rg + 1] = biasv[kt][rg].y * kLog2e;
+                    brow[kt][4 * rg + 2] = biasv[kt][rg].z * kLog2e;
+                    brow[kt][4 * rg + 3] = biasv[kt][rg].w * kLog2e;
+                }
+            if (mixed) {
+                const int mylab = lab_s[qq];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (lab_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != mylab) brow[kt][r] += kMaskLog2;
+            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float sraw = accS[kt][r];
-                    const float4 b4 = biasv[kt][r >> 2];
-                    const float bias_r = (r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w;
-                    float t = fmaf(sraw, fq2, bias_r * kLog2e);
-                    if (mixed) {
-                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (lab_s[key] != mylab) t += kMaskLog2;
-                    }
+                    const float t = fmaf(sraw, fq2, brow[kt][r]);
                     const float pr = __builtin_amdgcn_exp2f(t - lse2);
                     float dpv = accP[kt][r], prd = pr;
                     if constexpr (DROP) {  // the forward multiplied V by P o mask/(1-p): regenerate the same mask
