@@ -47,18 +47,21 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // "lowbias32" integer 
     return x;
 }
 struct ElemRng {
-    uint32_t key_lo, key_hi, thresh;
+    uint32_t key_lo, key_hi, thresh16;
     float keep_scale;
     __device__ __forceinline__ ElemRng(float p, uint64_t seed) {
         key_lo = (uint32_t)seed;
         key_hi = (uint32_t)(seed >> 32);
-        thresh = p >= 1.f ? 0xffffffffu : (uint32_t)(p * 4294967296.f);
+        thresh16 = p >= 1.f ? 65536u : (uint32_t)(p * 65536.f);  // drop probability in steps of 2^-16
         keep_scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
     }
-    // multiplier of element i: 0 (dropped) or 1/(1-p)
+    // multiplier of element i: 0 (dropped) or 1/(1-p).  One hash serves the element pair (2j, 2j+1), 16 bits each: the kernels
+    // process 4 or 8 consecutive elements per lane, so half of the hashes are shared.
     __device__ __forceinline__ float mult(int64_t i) const {
-        const uint32_t h = mix32((uint32_t)i ^ key_lo ^ mix32((uint32_t)((uint64_t)i >> 32) ^ key_hi));
-        return h >= thresh ? keep_scale : 0.f;
+        const uint64_t j = (uint64_t)i >> 1;
+        const uint32_t h = mix32((uint32_t)j ^ key_lo ^ mix32((uint32_t)(j >> 32) ^ key_hi));
+        const uint32_t bits = (i & 1) ? (h >> 16) : (h & 0xffffu);
+        return bits >= thresh16 ? keep_scale : 0.f;
     }
 };
 

@@ -49,18 +49,23 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {  // "lowbias32" integer
     return x;
 }
 struct DropRng {
-    uint32_t row_key, thresh;
+    uint32_t row_key, thresh16;
     float keep_scale;
     // row = ((b * nH + h) * N + shifted_row): one per (image, head, query)
     __device__ __forceinline__ DropRng(const AttnParams& p, int64_t row) {
         const uint64_t base = (uint64_t)row * 256u;  // up to 256 keys per window
         row_key = hash32((uint32_t)(base >> 32) ^ p.seed_hi) ^ p.seed_lo ^ (uint32_t)base;
         const float pd = p.drop_p;
-        thresh = pd >= 1.f ? 0xffffffffu : (uint32_t)(pd * 4294967296.f);
+        thresh16 = pd >= 1.f ? 65536u : (uint32_t)(pd * 65536.f);  // drop probability in steps of 2^-16
         keep_scale = pd >= 1.f ? 0.f : 1.f / (1.f - pd);
     }
-    // multiplier of probability (row, key): 0 or 1/(1-p)
-    __device__ __forceinline__ float mult(int key) const { return hash32(row_key + (uint32_t)key * 0x9E3779B9u) >= thresh ? keep_scale : 0.f; }
+    // multiplier of probability (row, key): 0 or 1/(1-p).  One 32-bit hash serves the two keys 2m, 2m+1 (16 bits each): the
+    // kernels hold adjacent keys in adjacent registers, so the hash -- most of the dropout's instruction cost -- is shared.
+    __device__ __forceinline__ float mult(int key) const {
+        const uint32_t hsh = hash32(row_key + (uint32_t)(key >> 1) * 0x9E3779B9u);
+        const uint32_t bits = (key & 1) ? (hsh >> 16) : (hsh & 0xffffu);
+        return bits >= thresh16 ? keep_scale : 0.f;
+    }
 };
 
 // fp32-VALU path: any Ws in {4,16,64,256}, head_dim <= 128 (fwd) / <= 64 (bwd); fp32 or bf16 I/O
