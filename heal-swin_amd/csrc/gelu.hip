@@ -114,6 +114,32 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const void* __restrict__ 
     }
 }
 
+// out = x + rs * drop(t)  (the standalone form of a block's residual branch -- end of a stage, foreign norm layers: dropout on
+// the branch output, swin_hp_transformer.py:43 / :173, and DropPath, :334-338) and its backward dt = dy * rs * mask.  rs is
+// the per-sample DropPath factor row_scale[i / elems_per_sample] (NULL = 1); x == NULL gives out = rs * drop(t).
+template <typename T>
+__global__ void __launch_bounds__(256) residual_drop_kernel(const void* __restrict__ x, const void* __restrict__ t, void* __restrict__ out,
+                                                            const float* __restrict__ row_scale, int64_t elems_per_sample, int64_t n,
+                                                            float p, uint64_t seed) {
+    constexpr int V = vec<T>::N;
+    const ElemRng rng(p, seed);
+    const bool dropping = p > 0.f;
+    const int64_t nvec = n / V;  // elems_per_sample is a multiple of V (checked by the host)
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nvec; c += (int64_t)gridDim.x * blockDim.x) {
+        float a[V], b[V];
+        vec<T>::load(t, c * V, b);
+        const float rs = row_scale ? row_scale[(c * V) / elems_per_sample] : 1.f;
+        if (x) vec<T>::load(x, c * V, a);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = b[k] * rs;
+            if (dropping) v *= rng.mult(c * V + k);
+            b[k] = x ? a[k] + v : v;
+        }
+        vec<T>::store(out, c * V, b);
+    }
+}
+
 inline unsigned grid_for(int64_t n, int v) {
     int64_t b = (n / v + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -162,6 +188,27 @@ int hs_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, float drop_p
         else hipLaunchKernelGGL((gelu_bwd_kernel<float, false>), dim3(grid_for(n, 4)), dim3(256), 0, s, dy, x, dx, n, drop_p, seed);
     }
     HS_LAUNCH_CHECK("gelu_bwd");
+    return HS_OK;
+}
+
+int hs_residual_drop(const void* x, const void* t, void* out, const float* row_scale, int64_t elems_per_sample, int64_t n,
+                     float drop_p, uint64_t seed, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(t && out && n >= 0, "bad arguments");
+    HS_CHECK_ARG(drop_p >= 0.f && drop_p <= 1.f, "drop_p must be in [0, 1]");
+    HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
+    const int v = dtype == HS_BF16 ? 8 : 4;
+    HS_CHECK_ARG(n % v == 0 && (!row_scale || (elems_per_sample > 0 && elems_per_sample % v == 0 && n % elems_per_sample == 0)),
+                 "n and elems_per_sample must be multiples of the 16-byte vector width");
+    HS_CHECK_ARG(((uintptr_t)t % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)x % 16 == 0), "buffers must be 16-byte aligned");
+    if (n == 0) return HS_OK;
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(residual_drop_kernel<bf16_t>, dim3(grid_for(n, 8)), dim3(256), 0, (hipStream_t)stream, x, t, out, row_scale,
+                           elems_per_sample, n, drop_p, seed);
+    else
+        hipLaunchKernelGGL(residual_drop_kernel<float>, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, x, t, out, row_scale,
+                           elems_per_sample, n, drop_p, seed);
+    HS_LAUNCH_CHECK("residual_drop");
     return HS_OK;
 }
 

@@ -287,6 +287,9 @@ class SwinTransformerBlock(nn.Module):
         if pending is None:
             return x
         t, rs, dp = pending
+        vec = 8 if t.dtype == torch.bfloat16 else 4
+        if (dp or rs is not None) and t.is_cuda and t.dtype in (torch.bfloat16, torch.float32) and (t.numel() // t.shape[0]) % vec == 0:
+            return ops.residual_drop(x, t, rs, dp)  # dropout, DropPath and the add in one HIP pass
         if dp:
             t = F.dropout(t, dp, True)
         if rs is not None:

@@ -342,6 +342,42 @@ class GeluDropoutFn(torch.autograd.Function):
         return dx, None, None
 
 
+class ResidualDropFn(torch.autograd.Function):
+    """x + rs * drop(t) in one pass (`hs_residual_drop`); the mask is regenerated in the backward from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, t, row_scale, p, seed):
+        _require_gpu(x, t, row_scale)
+        x, t = x.contiguous(), t.contiguous()
+        assert x.shape == t.shape and x.dtype == t.dtype
+        rs = None if row_scale is None else row_scale.detach().to(torch.float32).contiguous()
+        eps = t.numel() // t.shape[0]
+        out = torch.empty_like(t)
+        dt = _lib.dtype_code(t.dtype)
+        check(lib.hs_residual_drop(ptr(x), ptr(t), ptr(out), ptr(rs), eps, t.numel(), float(p), int(seed), dt, stream_ptr(t.device)),
+              "hs_residual_drop")
+        ctx.save_for_backward(rs)
+        ctx.meta = (eps, float(p), int(seed), dt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rs,) = ctx.saved_tensors
+        eps, p, seed, dt = ctx.meta
+        dy = dy.contiguous()
+        dtv = torch.empty_like(dy)
+        check(lib.hs_residual_drop(None, ptr(dy), ptr(dtv), ptr(rs), eps, dy.numel(), p, seed, dt, stream_ptr(dy.device)),
+              "hs_residual_drop (backward)")
+        return dy, dtv, None, None, None
+
+
+def residual_drop(x, t, row_scale=None, p=0.0, seed=None):
+    """x + rs * dropout(t): DropPath factor per sample (row_scale [B] or None) and dropout with probability p."""
+    if p > 0.0 and seed is None:
+        seed = _draw_seed()
+    return ResidualDropFn.apply(x, t, row_scale, float(p), int(seed or 0))
+
+
 def gelu_dropout(x, p=0.0, seed=None):
     if p > 0.0 and seed is None:
         seed = _draw_seed()

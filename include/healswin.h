@@ -224,6 +224,13 @@ int hs_add_layernorm_drop_bwd(const void* dy, const void* dsum, const void* sum,
 int hs_gelu_fwd(const void* x, void* y, int64_t n, float drop_p, uint64_t seed, int dtype, void* stream);
 int hs_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, float drop_p, uint64_t seed, int dtype, void* stream);
 
+/* out = x + rs * drop(t): a residual branch added in its standalone form (end of a stage; dropout on the branch output
+ * models_torch/swin_hp_transformer.py:43, :173 and DropPath :334-338 in one pass).  rs = row_scale[i / elems_per_sample]
+ * (row_scale [dev] f32[n / elems_per_sample], NULL = 1); x == NULL gives out = rs * drop(t), which is also the backward:
+ * dt = hs_residual_drop(NULL, dy, ...) with the forward's seed (dx = dy). */
+int hs_residual_drop(const void* x, const void* t, void* out, const float* row_scale, int64_t elems_per_sample, int64_t n,
+                     float drop_p, uint64_t seed, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Class-weighted cross-entropy of the segmentation caller (reference: nn.CrossEntropyLoss(weight)(logits[B,K,Npix],
  * labels.long()[B,Npix]), models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111):

@@ -572,3 +572,32 @@ print("fallback ok")
     env = dict(os.environ, HS_WGRAD_VARIANT="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_residual_drop_matches_the_explicit_formula(dtype):
+    """hs_residual_drop: out = x + rs * drop(t) and dt = dy * rs * mask, with the mask recovered from the output itself
+    (statistics: keep rate 1 - p; survivors scaled by exactly 1 / (1 - p); backward uses the same mask)."""
+    ops, _, _ = _mods()
+    g = torch.Generator().manual_seed(11)
+    B, N, C, p = 4, 1000, 64, 0.2
+    x = torch.randn(B, N, C, generator=g).to(DEV).to(dtype)
+    t = (torch.rand(B, N, C, generator=g) * 2 + 1).to(DEV).to(dtype)  # in [1, 3]: the mask is readable from the result
+    rs = torch.tensor([1.25, 0.0, 1.25, 1.25], device=DEV)           # DropPath with keep 0.8: sample 1 dropped
+    tt = t.clone().requires_grad_(True)
+    xx = x.clone().requires_grad_(True)
+    out = ops.residual_drop(xx, tt, rs, p, seed=77)
+    branch = (out.float() - x.float())
+    mask = (branch.abs() > 1e-3).float()
+    assert float(mask[1].sum()) == 0.0
+    keep_rate = float(mask[[0, 2, 3]].mean())
+    assert abs(keep_rate - (1 - p)) < 5e-3
+    expect = x.float() + mask * t.float() * rs.view(-1, 1, 1) / (1 - p)
+    assert_close(out, expect, 1e-5 if dtype == torch.float32 else 1e-2, "out")
+    dy = torch.randn(B, N, C, generator=g).to(DEV).to(dtype)
+    out.backward(dy)
+    assert torch.equal(xx.grad, dy)
+    assert_close(tt.grad, dy.float() * mask * rs.view(-1, 1, 1) / (1 - p), 1e-5 if dtype == torch.float32 else 1e-2, "dt")
+    # same seed -> same mask; p = 0 and no DropPath -> plain add
+    assert torch.equal(ops.residual_drop(x, t, rs, p, seed=77), out.detach())
+    assert torch.equal(ops.residual_drop(x, t, None, 0.0), x + t)
