@@ -123,12 +123,14 @@ def test_ring_shift_gather_roundtrip_full_size():
     assert torch.equal(fused, staged)
 
 
-def test_linear_wgrad_checksum_full_size():
-    """sum over all entries of dW equals (column sums of dY) . (column sums of X): a checksum of checksums at M = 1.5 M rows."""
+@pytest.mark.parametrize("dtype,n_out,k_in", [(torch.bfloat16, 384, 128), (torch.bfloat16, 2048, 512), (torch.float32, 288, 96)])
+def test_linear_wgrad_checksum_full_size(dtype, n_out, k_in):
+    """sum over all entries of dW equals (column sums of dY) . (column sums of X): a checksum of checksums at M = 1.5 M rows
+    (bf16: the 128-wide and the 256 x 256 tile kernels; fp32: the v_mfma_f32_32x32x2 kernel)."""
     ops, _ = _ops()
-    M, n_out, k_in = 1572864, 384, 128
-    x = (torch.randn(M, k_in, device=DEV) * 0.5).to(torch.bfloat16)
-    dy = (torch.randn(M, n_out, device=DEV) * 0.5).to(torch.bfloat16)
+    M = 1572864 if n_out < 1024 else 98304 * 4
+    x = (torch.randn(M, k_in, device=DEV) * 0.5).to(dtype)
+    dy = (torch.randn(M, n_out, device=DEV) * 0.5).to(dtype)
     w = torch.zeros(n_out, k_in, device=DEV, requires_grad=True)
     b = torch.zeros(n_out, device=DEV, requires_grad=True)
     ops.linear(x.requires_grad_(False), w, b).backward(dy)
