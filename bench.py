@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--no-tuned-gemm", action="store_true", help="ignore the shipped TunableOp results for the library GEMMs")
     ap.add_argument("--tune-gemm", metavar="CSV", default=None,
                     help="(maintenance) run PyTorch TunableOp tuning over this workload's library GEMMs during the warm-up and "
-                         "write the results file CSV (copy it to heal-swin_amd/tuning/); the timed numbers of such a run are not a benchmark")
+                         "write the results file CSV (copy it to heal_swin_amd/tuning/); the timed numbers of such a run are not a benchmark")
     ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
     args = ap.parse_args()
 
@@ -201,7 +201,7 @@ def main():
     # Library GEMMs (forward / input-gradient of the Linear layers): load the per-shape hipBLASLt/rocBLAS solution choices
     # tuned once on an MI355X with PyTorch TunableOp (tuning itself stays OFF here; a validator mismatch -- other ROCm,
     # other GPU -- makes PyTorch ignore the file and fall back to the library heuristic).
-    tuned = os.path.join(ROOT, "heal-swin_amd", "tuning", f"tunableop_gfx950_{args.workload}_bs{args.batch}_{args.dtype}.csv")
+    tuned = os.path.join(ROOT, "heal_swin_amd", "tuning", f"tunableop_gfx950_{args.workload}_bs{args.batch}_{args.dtype}.csv")
     if args.tune_gemm:
         os.makedirs(os.path.dirname(os.path.abspath(args.tune_gemm)), exist_ok=True)
         torch.cuda.tunable.enable(True)

@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_OTHER))
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
-            f"libhealswin.so not found at {LIB_PATH}: build it first (python heal-swin_amd/build.py, or "
+            f"libhealswin.so not found at {LIB_PATH}: build it first (python heal_swin_amd/build.py, or "
             "__graft_entry__.build()).  heal_swin_amd has no CPU or PyTorch fallback."
         )
     lib = ctypes.CDLL(LIB_PATH)

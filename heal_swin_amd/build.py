@@ -1,6 +1,6 @@
 """Build libhealswin.so (HIP kernels + C ABI, include/healswin.h) for gfx950 with hipcc.
 
-In-tree build: objects under heal-swin_amd/build/, the shared library at heal-swin_amd/lib/libhealswin.so
+In-tree build: objects under heal_swin_amd/build/, the shared library at heal_swin_amd/lib/libhealswin.so
 (git-ignored, but it travels to the GPU box with the repo snapshot).  hipcc cross-compiles gfx950 code
 objects without a GPU present.
 """

@@ -8,7 +8,7 @@ swin_hp_transformer}.py`).  Every function cites the reference file:line it foll
 Rules (enforced by tests/test_layout.py):
   * only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
     import anything from here -- as the checker, never as the thing shipped;
-  * nothing under `heal-swin_amd/` imports `oracle`.
+  * nothing under `heal_swin_amd/` imports `oracle`.
 
 Pinning status ("Oracle"):
   * index tables, masks, module/whole-model forward + gradients, losses: PINNED against

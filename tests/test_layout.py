@@ -17,7 +17,7 @@ def _py_files(sub):
 
 def test_product_never_imports_oracle():
     pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
-    for f in list(_py_files("heal-swin_amd")) + [os.path.join(ROOT, "heal_swin_amd.py")]:
+    for f in list(_py_files("heal_swin_amd")):
         assert not pat.search(open(f).read()), f"{f} imports the oracle"
 
 
@@ -30,7 +30,7 @@ def test_oracle_imports_only_inside_allowed_bench_and_smoke_legs():
 
 
 def test_nothing_reads_the_reference_at_run_time():
-    for sub in ("heal-swin_amd", "oracle", "tools"):
+    for sub in ("heal_swin_amd", "oracle", "tools"):
         for f in _py_files(sub):
             assert "/root/reference" not in open(f).read().replace("/root/reference/heal_swin", "<cite>").replace(
                 "`/root/reference", "<cite>").replace("(read-only, /root/reference)", "<cite>"), f
@@ -44,5 +44,5 @@ def test_nothing_reads_the_reference_at_run_time():
 def test_required_layout():
     for p in ("bench.py", "__graft_entry__.py", "include/healswin.h", "oracle/model.py", "oracle/tables.py", "oracle/healpix.py",
               "tests/golden/make_golden.py", "tests/golden/tables.npz", "tests/golden/modules.npz", "tests/golden/models.npz",
-              "tests/golden/losses.npz", "heal-swin_amd/csrc/window_attn_mfma.hip", "DESIGN.md", "INTEGRATION.md", "profiles"):
+              "tests/golden/losses.npz", "heal_swin_amd/csrc/window_attn_mfma.hip", "DESIGN.md", "INTEGRATION.md", "profiles"):
         assert os.path.exists(os.path.join(ROOT, p)), p
