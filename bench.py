@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
 
 WORKLOADS = {
     # BASELINE.json configs[2]: HEAL-SWIN-B, nside 256, 12 base pixels (full sphere), window 64 (nest_roll: the only
@@ -108,49 +109,86 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(wl, budget_s=25.0):
-    """Times the CPU oracle (forward + CE loss + backward over all parameters; a port of the reference's forward) on
-    this host's usable cores, on a BOUNDED sample of the same model: ONE image at a reduced nside, chosen by a
-    calibration run so that the sample costs about 10-30 s; images/s is rescaled by the pixel ratio (cost is linear
-    in the pixel count for windowed attention)."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle_timing(wl, nside, batch, warmup, iters):
+    """Seconds per fwd + CE + bwd of the CPU oracle on `batch` images at `nside` (list of timed iterations after warm-up)."""
     from oracle import model as OM  # the checker, used here as the reported CPU baseline ("port")
 
+    model, cfg, spec = build_model(wl, nside)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
+          if not k.endswith("attn_mask")}
+    del model
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (batch, 3, spec["dim_in"]), generator=g).float()
+    y = torch.randint(0, spec["f_out"], (batch, spec["dim_in"]), generator=g)
+    cfg_ns, spec_ns = types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec)
+    times = []
+    for it in range(warmup + iters):
+        t0 = time.time()
+        loss = OM.seg_loss(OM.forward(sd, cfg_ns, spec_ns, x), y)
+        loss.backward()
+        if it >= warmup:
+            times.append(time.time() - t0)
+        for v in sd.values():
+            v.grad = None
+    return times
+
+
+def cpu_baseline(wl, budget_s=25.0):
+    """Times the CPU oracle (forward + CE loss + backward over all parameters; a port of the reference's forward, fp32) on
+    this host's usable cores.  Headline workload: a BOUNDED sample of the same model -- ONE image at a reduced nside chosen
+    by calibration so that 1 warm-up + 3 timed iterations cost about 10-30 s; images/s is rescaled by the pixel ratio (cost
+    is linear in the pixel count for windowed attention).  BASELINE configs[0] (tiny) and configs[1] (T, nside 128) are timed
+    at their full size alongside (1 warm-up + 3 timed iterations)."""
     cores = usable_cores()
     torch.set_num_threads(cores)
     L = len(wl["cfg"]["depths"])
-    min_nside = 16 * 2 ** (L - 1)  # >= one 64-token window per base-pixel quartet at the last stage
-    cfg_ns = spec_ns = None
-
-    def run(nside, iters_cap, budget):
-        nonlocal cfg_ns, spec_ns
-        model, cfg, spec = build_model(wl, nside)
-        sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
-              if not k.endswith("attn_mask")}
-        del model
-        g = torch.Generator().manual_seed(0)
-        x = torch.randint(0, 256, (1, 3, spec["dim_in"]), generator=g).float()
-        y = torch.randint(0, spec["f_out"], (1, spec["dim_in"]), generator=g)
-        cfg_ns, spec_ns = types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec)
-        times, t_begin = [], time.time()
-        while len(times) < iters_cap and (not times or time.time() - t_begin + times[-1] < budget):
-            t0 = time.time()
-            loss = OM.seg_loss(OM.forward(sd, cfg_ns, spec_ns, x), y)
-            loss.backward()
-            times.append(time.time() - t0)
-            for v in sd.values():
-                v.grad = None
-        return times
-
-    nside = min(wl["nside"], min_nside)
-    times = run(nside, 2, 1e9)  # calibration (also the answer if even this is slow)
-    while nside * 2 <= wl["nside"] and min(times) * 4 * 1.2 < budget_s:
+    nside = min(wl["nside"], 16 * 2 ** (L - 1))  # >= one 64-token window per base-pixel quartet at the last stage
+    t = min(_oracle_timing(wl, nside, 1, 0, 1))  # calibration
+    while nside * 2 <= wl["nside"] and t * 4 * 4 * 1.2 < budget_s:
         nside *= 2
-        times = run(nside, 4, budget_s)
-    t = min(times)
+        t *= 4
+    times = _oracle_timing(wl, nside, 1, 1, 3)
+    t = sum(times) / len(times)
     scale = (wl["nside"] / nside) ** 2
-    return {"value": 1.0 / (t * scale), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (CPU restatement of the reference forward) fwd+CE+bwd, fp32, 1 image at nside={nside} "
-                      f"({len(times)} iters, best {t:.2f}s on {cores} threads), rescaled x{1 / scale:.4g} to nside={wl['nside']} by pixel count"}
+    out = {"value": 1.0 / (t * scale), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+           "sample": f"oracle (CPU restatement of the reference forward) fwd+CE+bwd, fp32, 1 image at nside={nside}, 1 warm-up + "
+                     f"{len(times)} timed iterations (mean {t:.2f}s, min {min(times):.2f}s on {cores} threads), rescaled "
+                     f"x{1 / scale:.4g} to nside={wl['nside']} by pixel count"}
+    other = {}
+    for key, batch in (("tiny", 1), ("T128", 1)):  # BASELINE configs[0] and configs[1] at full size
+        w = WORKLOADS[key]
+        ts = _oracle_timing(w, w["nside"], batch, 1, 3)
+        other[key] = {"workload": w["name"], "images_per_s": batch * len(ts) / sum(ts), "s_per_iter": [round(v, 3) for v in ts],
+                      "batch": batch, "iters": "1 warm-up + 3 timed"}
+    out["other_configs"] = other
+    return out
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -163,6 +201,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-fp32-companion", action="store_true", help="skip the fp32 run of the same workload (N = 1 only)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd + loss + bwd + Adam) in one HIP graph and replay it (single GPU, no "
                          "dropout); removes host launch latency, which dominates the small workloads")
@@ -178,9 +217,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # does not return
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     # test hook (tests/test_gpu_parallel.py): several ranks on ONE GPU over gloo exercise this script's multi-rank path on a
@@ -218,18 +258,97 @@ def main():
         torch.cuda.tunable.set_filename(tuned, insert_device_ordinal=False)
         torch.cuda.tunable.read_file(tuned)
 
-    from heal_swin_amd import ops
-    from heal_swin_amd.losses import seg_loss
-    from heal_swin_amd.parallel import GradBucketAllReduce
-
     wl = WORKLOADS[args.workload]
     if args.paper_drop_rates:
         wl = dict(wl, cfg=dict(wl["cfg"], drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1),
                   name=wl["name"] + " drop 0.1/0.1/0.1")
+    ctx = types.SimpleNamespace(args=args, wl=wl, dev=dev, world=world, rank=rank, shared_gpu=shared_gpu)
+    res = run_workload(ctx, args.dtype, args.steps, args.warmup, timing=not args.no_kernel_timing)
+    elapsed = res.elapsed
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec fwd+bwd, HEAL-SWIN nside=256 seg, batch=8 at 1/2/4/8 MI355X",
+            "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
+                       "launch": "hip graph replay" if args.graph else "eager",
+                       "params_M": res.params_m, "final_loss": res.loss,
+                       "library_gemm_selection": "TunableOp tuning run" if args.tune_gemm else ("TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic")},
+        }
+        if world > 1:
+            out["rccl"] = res.rccl
+        if res.timings:
+            out["roofline"] = roofline_of(res.timings, elapsed)
+    # the reference trains in fp32 (training/train_config.py:95 `precision: int = 32`): same workload, same batch, fp32
+    # activations, a few steps -- so the reference's own precision is measured next to the bf16 headline
+    if world == 1 and args.dtype == "bf16" and not args.no_fp32_companion and not args.graph and not args.tune_gemm:
+        k = max(2, min(args.steps, 3))
+        r32 = run_workload(ctx, "fp32", k, 1, timing=False)
+        out["fp32"] = {"value": args.batch * k / r32.elapsed, "unit": "images/s", "ms_per_step": 1e3 * r32.elapsed / k, "steps": k,
+                       "warmup": 1, "batch_per_gpu": args.batch, "workload": wl["name"], "final_loss": r32.loss,
+                       "note": "fp32 activations and MFMA-f32 kernels; library GEMMs with the default heuristic"}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline_of(timings, elapsed):
+    """attention roofline = attention flops of the timed launches (fwd + bwd) / their measured time against the
+    dense bf16 MFMA peak; the HBM view of the same launches (algorithmic bytes / time against 8 TB/s) is kept beside it
+    because a core-only attention kernel (32 flop/B) is bandwidth-bound by construction."""
+    agg = {}
+    for tag, s, e, nbytes, flops in timings:
+        a = agg.setdefault(tag, [0.0, 0, 0, 0, {}])
+        a[0] += s.elapsed_time(e) * 1e-3
+        a[1] += nbytes
+        a[2] += flops
+        a[3] += 1
+        a[4][nbytes] = a[4].get(nbytes, 0) + 1
+    attn = {t: a for t, a in agg.items() if t.startswith("window_attn")}
+    tot_t = sum(a[0] for a in attn.values())
+    tot_b = sum(a[1] for a in attn.values())
+    tot_f = sum(a[2] for a in attn.values())
+    launches = sum(a[3] for a in attn.values())
+    tf = tot_f / tot_t / 1e12
+    gbs = tot_b / tot_t / 1e9
+    traffic = pmc_traffic_per_launch({t: a for t, a in attn.items() if t in ("window_attn_fwd", "window_attn_bwd")})
+    return {
+        "kernel": " + ".join(sorted(attn)) + " (fused shift / window partition / attention / reverse)",
+        "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+        "traffic": traffic,
+        "traffic_source": "profiles/r01_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same "
+                          "kernels and shapes; looked up, not measured in this run)" if traffic is not None else None,
+        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": tot_b / launches},
+        "algorithmic_flops_per_launch": tot_f / launches,
+        "avg_launch_us": 1e6 * tot_t / launches, "launches": launches, "share_of_step": tot_t / elapsed,
+        "per_kernel": {tag: {"launches": a[3], "avg_us": 1e6 * a[0] / a[3], "GB/s": a[1] / a[0] / 1e9,
+                             "TFLOP/s": a[2] / a[0] / 1e12, "share_of_step": a[0] / elapsed}
+                       for tag, a in agg.items()},
+    }
+
+
+def run_workload(ctx, dtype_name, steps, warmup, timing):
+    """Build the model / optimizer / gradient exchange for `dtype_name`, run `warmup` untimed and `steps` timed steps
+    (barrier + synchronize on both sides, MAX over ranks) and release everything again."""
+    import gc
+
+    import torch.distributed as dist
+    from heal_swin_amd import ops
+    from heal_swin_amd.losses import seg_loss
+    from heal_swin_amd.parallel import GradBucketAllReduce
+
+    args, wl, dev, world, rank = ctx.args, ctx.wl, ctx.dev, ctx.world, ctx.rank
     model, cfg, spec = build_model(wl)
     model = model.to(dev).train()
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model.compute_dtype = dtype
+    model.compute_dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=args.graph)  # ref: training/optimizer.py:57-66
 
@@ -251,7 +370,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
     if args.tune_gemm:
@@ -270,61 +389,50 @@ def main():
 
         step()
         sync()
-    if not args.no_kernel_timing:
+    if timing:
         ops.KERNEL_TIMINGS = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     sync()
     elapsed = time.perf_counter() - t0
     timings, ops.KERNEL_TIMINGS = ops.KERNEL_TIMINGS, None
+    rccl = None
     if world > 1:
+        assert dist.get_world_size() == world == args.gpus
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(loss.item())
-
-    if rank == 0:
-        images = args.batch * world * args.steps
-        out = {
-            "metric": "images/sec fwd+bwd, HEAL-SWIN nside=256 seg, batch=8 at 1/2/4/8 MI355X",
-            "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
-                       "launch": "hip graph replay" if args.graph else "eager",
-                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2), "final_loss": loss_val,
-                       "library_gemm_selection": "TunableOp tuning run" if args.tune_gemm else ("TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic")},
-        }
-        if timings:
-            agg = {}
-            for tag, s, e, nbytes, flops in timings:
-                a = agg.setdefault(tag, [0.0, 0, 0, 0, {}])
-                a[0] += s.elapsed_time(e) * 1e-3
-                a[1] += nbytes
-                a[2] += flops
-                a[3] += 1
-                a[4][nbytes] = a[4].get(nbytes, 0) + 1
-            attn = {t: a for t, a in agg.items() if t.startswith("window_attn")}
-            tot_t = sum(a[0] for a in attn.values())
-            tot_b = sum(a[1] for a in attn.values())
-            launches = sum(a[3] for a in attn.values())
-            ach = tot_b / tot_t / 1e9
-            out["roofline"] = {
-                "kernel": "hs_window_attn_fwd + hs_window_attn_bwd (fused shift / window partition / attention / reverse)",
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_per_launch(attn), "algorithmic_bytes_per_launch": tot_b / launches,
-                "avg_launch_us": 1e6 * tot_t / launches, "launches": launches, "share_of_step": tot_t / elapsed,
-                "per_kernel": {tag: {"launches": a[3], "avg_us": 1e6 * a[0] / a[3], "GB/s": a[1] / a[0] / 1e9,
-                                     "TFLOP/s": a[2] / a[0] / 1e12, "share_of_step": a[0] / elapsed}
-                               for tag, a in agg.items()},
-            }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        # the exchange on its own: every gradient bucket all-reduced back to back, timed per rank with events
+        reps = 5
+        for flat in dp.buckets:
+            dist.all_reduce(flat)
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for flat in dp.buckets:
+                dist.all_reduce(flat)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        mine = torch.tensor([e0.elapsed_time(e1) / reps], device=dev, dtype=torch.float64)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        nbytes = sum(f.numel() * 4 for f in dp.buckets)
+        ms = [float(v.item()) for v in per_rank]
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "buckets": len(dp.buckets),
+                "allreduce_bytes_per_step": nbytes, "allreduce_ms_per_step_standalone_per_rank": [round(v, 3) for v in ms],
+                "allreduce_bus_GBps": 2 * (world - 1) / world * nbytes / (max(ms) * 1e-3) / 1e9,
+                "exchange": "fp32 flat buckets, async all-reduce launched from gradient hooks during backward"}
+    res = types.SimpleNamespace(elapsed=elapsed, loss=float(loss.item()), timings=timings if rank == 0 else None, rccl=rccl,
+                                params_m=round(sum(p.numel() for p in model.parameters()) / 1e6, 2))
+    dp.remove()
+    del model, dp, opt, imgs, labels, loss, step
+    if args.graph:
+        del graph, static_loss, eager_step
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

@@ -244,7 +244,7 @@ int hs_build_nest_grid_shift(int nside, int base_pix, int window_size, int32_t* 
 int hs_build_ring_shift(int nside, int base_pix, int window_size, int shift_size, int32_t* idx, int32_t* inv, uint8_t* labels) {
     if (int st = check_nside(nside)) return st;
     HS_CHECK_ARG(base_pix == 8, "RingShift is only valid for base_pix == 8 (the reference fails for every other value)");
-    HS_CHECK_ARG(hs::isqrt_pow2_window(window_size) > 0, "window_size must be 4^k, got %d", window_size);
+    HS_CHECK_ARG(window_size > 0 && (window_size & (window_size - 1)) == 0, "window_size must be a power of two, got %d", window_size);
     HS_CHECK_ARG(shift_size > 0, "shift_size must be positive");
     const int64_t npface = (int64_t)nside * nside, npix = base_pix * npface, nfull = 12 * npface;
     std::vector<int64_t> src(npix);

@@ -59,7 +59,9 @@ struct ElemRng {
     // process 4 or 8 consecutive elements per lane, so half of the hashes are shared.
     __device__ __forceinline__ float mult(int64_t i) const {
         const uint64_t j = (uint64_t)i >> 1;
-        const uint32_t h = mix32((uint32_t)j ^ key_lo ^ mix32((uint32_t)(j >> 32) ^ key_hi));
+        // keyed, two full rounds: the low counter word is mixed with key_lo BEFORE the high word / key_hi enter, so masks of
+        // different seeds are unrelated sequences (a single round over j ^ key made them XOR-translates of one sequence)
+        const uint32_t h = mix32(mix32((uint32_t)j + key_lo) ^ ((uint32_t)(j >> 32) * 0x9E3779B9u + key_hi));
         const uint32_t bits = (i & 1) ? (h >> 16) : (h & 0xffffu);
         return bits >= thresh16 ? keep_scale : 0.f;
     }

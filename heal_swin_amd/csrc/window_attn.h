@@ -54,7 +54,8 @@ struct DropRng {
     // row = ((b * nH + h) * N + shifted_row): one per (image, head, query)
     __device__ __forceinline__ DropRng(const AttnParams& p, int64_t row) {
         const uint64_t base = (uint64_t)row * 256u;  // up to 256 keys per window
-        row_key = hash32((uint32_t)(base >> 32) ^ p.seed_hi) ^ p.seed_lo ^ (uint32_t)base;
+        // keyed with both seed words through two rounds (once per row): rows of different seeds get unrelated key streams
+        row_key = hash32(hash32((uint32_t)base + p.seed_lo) ^ ((uint32_t)(base >> 32) * 0x9E3779B9u + p.seed_hi));
         const float pd = p.drop_p;
         thresh16 = pd >= 1.f ? 65536u : (uint32_t)(pd * 65536.f);  // drop probability in steps of 2^-16
         keep_scale = pd >= 1.f ? 0.f : 1.f / (1.f - pd);
@@ -68,7 +69,7 @@ struct DropRng {
     }
 };
 
-// fp32-VALU path: any Ws in {4,16,64,256}, head_dim <= 128 (fwd) / <= 64 (bwd); fp32 or bf16 I/O
+// fp32-VALU path: any power-of-two Ws in [4, 256], head_dim <= 128; fp32 or bf16 I/O
 int launch_attn_fwd_generic(const AttnParams& p, int dtype, hipStream_t stream);
 int launch_attn_bwd_generic(const AttnParams& p, int dtype, hipStream_t stream);
 

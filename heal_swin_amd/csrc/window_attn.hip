@@ -12,8 +12,10 @@ int fill_params(hs::AttnParams& p, const void* qkv, void* out, float* lse, const
     HS_CHECK_ARG(batch > 0 && n_tokens > 0 && channels > 0 && num_heads > 0, "non-positive size");
     HS_CHECK_ARG(n_tokens < (1ll << 31), "n_tokens must fit int32 (gather table is int32)");
     HS_CHECK_ARG(channels % num_heads == 0, "channels %d not divisible by num_heads %d", channels, num_heads);
-    // hp_windowing.py:16 asserts a power of two; the nested scheme needs a square block, i.e. 4^k
-    HS_CHECK_ARG(hs::isqrt_pow2_window(window_size) > 0 || window_size == 1, "window_size must be 4^k, got %d", window_size);
+    // hp_windowing.py:16 asserts a power of two.  Square nested blocks (4^k) are only needed by the relative-position index
+    // and the grid shift, which are validated where those tables are built; the kernels take any power of two
+    // (e.g. a last stage clamped to 8 * 4^k tokens with 8 base pixels, swin_hp_transformer.py:243-246)
+    HS_CHECK_ARG((window_size & (window_size - 1)) == 0, "window_size must be a power of two, got %d", window_size);
     HS_CHECK_ARG(window_size <= 256, "window_size %d > 256 is not supported", window_size);
     HS_CHECK_ARG(n_tokens % window_size == 0, "n_tokens %lld not divisible by window_size %d", (long long)n_tokens, window_size);
     HS_CHECK_ARG(window_size >= 4, "window_size must be at least 4");

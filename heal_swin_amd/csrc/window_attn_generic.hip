@@ -1,5 +1,5 @@
 // fp32-VALU path of the fused  shift -> window_partition -> attention -> window_reverse -> shift_back
-// kernel: any window size in {4,16,64,256} and any head_dim (padded to a power of two), fp32 or bf16
+// kernel: any power-of-two window size in [4, 256] and any head_dim <= 128 (padded to a power of two), fp32 or bf16
 // activations, all arithmetic in fp32.  This is the production path for fp32 models (exact-fp32
 // scores, as the reference computes them) and the fallback for shapes the MFMA path does not cover.
 //
@@ -341,7 +341,8 @@ int dispatch_bwd(const AttnParams& p, hipStream_t s) {
     if (hd <= 16) return launch_bwd<T, 16>(p, s);
     if (hd <= 32) return launch_bwd<T, 32>(p, s);
     if (hd <= 64) return launch_bwd<T, 64>(p, s);
-    return fail(HS_ERR_UNSUPPORTED, "head_dim %d > 64 (backward)", hd);
+    if (hd <= 128) return launch_bwd<T, 128>(p, s);
+    return fail(HS_ERR_UNSUPPORTED, "head_dim %d > 128 (backward)", hd);
 }
 
 }  // namespace

@@ -52,13 +52,35 @@ def collate_uint8(samples):
     return imgs, masks
 
 
+class DeviceBatch(tuple):
+    """(imgs, masks) on the device, as returned by `to_device`.  When the copies ran on a side stream, `ready` is the event
+    recorded behind them and `wait()` must be called on the consuming stream before the tensors are used."""
+
+    ready = None
+
+    def wait(self, stream=None):
+        """Make `stream` (default: the current stream) wait for the copies, and tell the caching allocator that the
+        tensors are used there, so their blocks are not handed out again while that stream still reads them."""
+        if self.ready is not None:
+            stream = torch.cuda.current_stream(self[0].device) if stream is None else stream
+            stream.wait_event(self.ready)
+            for t in self:
+                t.record_stream(stream)
+        return self
+
+
 def to_device(batch, device, stream=None):
-    """Asynchronous host -> HBM copy of a collated uint8 batch (on `stream` if given: overlaps the previous step's compute)."""
+    """Asynchronous host -> HBM copy of a collated uint8 batch.  Without `stream` the copies are ordered on the current
+    stream and the result can be used at once.  With a side `stream` (to overlap the previous step's compute) the result
+    carries the event recorded behind the copies: call `.wait()` on it before the first use --
+        nxt = to_device(host_batch, dev, copy_stream); ...; imgs, masks = nxt.wait()"""
     imgs, masks = batch
     if stream is None:
-        return imgs.to(device, non_blocking=True), masks.to(device, non_blocking=True)
+        return DeviceBatch((imgs.to(device, non_blocking=True), masks.to(device, non_blocking=True)))
     with torch.cuda.stream(stream):
-        out = imgs.to(device, non_blocking=True), masks.to(device, non_blocking=True)
+        out = DeviceBatch((imgs.to(device, non_blocking=True), masks.to(device, non_blocking=True)))
+        out.ready = torch.cuda.Event()
+        out.ready.record(stream)
     return out
 
 

@@ -1,8 +1,9 @@
 """Caller-side losses of the two reference Lightning modules, so that a train step
 is self-contained.  fp32 arithmetic regardless of the logits dtype; the segmentation cross-entropy runs in fused HIP
 kernels on device tensors, the depth losses are thin torch compositions."""
+from functools import partial
+
 import torch
-import torch.nn.functional as F
 
 # MaskedDepthDataStatistics, heal_swin/data/depth_estimation/normalize_depth_data.py:31-40
 DEPTH_MEAN = 13.654291032986958
@@ -51,13 +52,13 @@ class _SegCrossEntropyFn(torch.autograd.Function):
 
 def seg_loss(logits, labels, class_weights=None):
     """nn.CrossEntropyLoss(weight)(logits[B,K,Npix], labels.long()[B,Npix])
-    (heal_swin/models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111).
-    Device tensors: the fused HIP kernels (`hs_seg_ce_*`, fp32 arithmetic on bf16 or fp32 logits).  Host tensors (the CPU
-    unit tests of the caller-side formulas): the torch composition."""
+    (heal_swin/models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111) by the fused HIP kernels
+    `hs_seg_ce_*` (fp32 arithmetic on bf16 or fp32 logits).  Device tensors only: there is no CPU path."""
+    if not logits.is_cuda:
+        raise RuntimeError("heal_swin_amd.losses.seg_loss runs only on an MI355X (HIP) device: got CPU logits; "
+                           "there is no CPU fallback")
     w = None if class_weights is None else class_weights.to(device=logits.device, dtype=torch.float32).contiguous()
-    if logits.is_cuda:
-        return _SegCrossEntropyFn.apply(logits, labels, w)
-    return F.cross_entropy(logits.float(), labels.long(), weight=w)
+    return _SegCrossEntropyFn.apply(logits, labels, w)
 
 
 def seg_predictions(logits):
@@ -89,3 +90,29 @@ def depth_l2_loss(pred, target, mask_background=False):
     """`mse`: mean (pred[:,0] - target)^2 / 2 over non-inf targets (loss_depth_regression.py:9-21)."""
     keep = _finite(target)
     return ((pred[:, 0].float()[keep] - target[keep]) ** 2 / 2).mean()
+
+
+def depth_huber_loss(pred, target, mask_background=False, delta=1.0):
+    """SmoothL1Loss(beta=delta, reduction='mean') over non-inf targets (loss_depth_regression.py:56-68); like the reference
+    (which indexes all channels of `preds` with the [B,1,Npix] mask) it is defined for one-channel predictions."""
+    assert pred.shape[1] == 1, "huber_loss needs a one-channel prediction (reference loss_depth_regression.py:66)"
+    keep = _finite(target)
+    d = (pred[:, 0].float()[keep] - target[keep]).abs()
+    return torch.where(d < delta, 0.5 * d * d / delta, d - 0.5 * delta).mean()
+
+
+def depth_mean_log_var_loss(pred, target, mask_background=False):
+    """mean of log_var/2 + (mean - target)^2 exp(-log_var)/2 over non-inf targets, channel 0 = mean, channel 1 = log variance
+    (loss_depth_regression.py:23-38)."""
+    keep = _finite(target)
+    means, log_var = pred[:, 0].float()[keep], pred[:, 1].float()[keep]
+    return (0.5 * log_var + (means - target[keep]) ** 2 * (0.5 * torch.exp(-log_var))).mean()
+
+
+def get_depth_loss(common_depth_config):
+    """Same selection as the reference's get_depth_loss (loss_depth_regression.py:70-83); the argument needs the fields
+    `use_logvar`, `loss` ('l2' | 'l1' | 'huber') and `huber_delta` of CommonDepthConfig (depth_common_config.py:7-10)."""
+    if common_depth_config.use_logvar:
+        return depth_mean_log_var_loss
+    return {"l2": depth_l2_loss, "l1": depth_l1_loss,
+            "huber": partial(depth_huber_loss, delta=common_depth_config.huber_delta)}[common_depth_config.loss]

@@ -495,7 +495,7 @@ class UnetDecoder(nn.Module):
             if dbg:
                 print(f"feature shape after decoder layer {inx}: {x.size()}")
         x = self.up(self.norm_up(x))  # B, Npix, C
-        x = ops.linear(x, self.output.weight[:, :, 0])  # 1x1 conv without bias (ref :756-761); weight gradient by hs_linear_wgrad
+        x = ops.linear(x, self.output.weight)  # 1x1 conv without bias (ref :756-761) as the [f_out, C] matrix it is (ops.LinearFn)
         return x.transpose(1, 2)  # B, f_out, Npix
 
 
@@ -629,3 +629,10 @@ class SwinHPTransformerSys(nn.Module):
             self.__dict__["_cast_cache"] = cache  # not a module attribute: stays out of state_dict / .to()
         cache.refresh()
         return cache
+
+    def invalidate_param_casts(self):
+        """Force the bf16 parameter copies to be re-made at the next forward (needed only after in-place writes through
+        `param.data`, which PyTorch's version counters do not see; see ops.ParamCastCache)."""
+        cache = self.__dict__.get("_cast_cache")
+        if cache is not None:
+            cache.invalidate()

@@ -164,23 +164,29 @@ def _extras(x, row_scale, drop_p, seed):
     return rs, rps, float(drop_p or 0.0), int(seed or 0)
 
 
+def _sink_buffer(p):
+    """fp32 gradient buffer of parameter p that a kernel may ADD into (a view into GRAD_SINK's flat buckets), or None when no
+    sink is installed or p is not registered with it."""
+    sink = GRAD_SINK
+    return None if (sink is None or p is None) else sink.grad_buffer(p)
+
+
 def _norm_param_grads(weight, bias, width, device, want):
-    """Buffers the LayerNorm backward writes dgamma / dbeta to: under a GRAD_SINK the parameters' own fp32 .grad (the kernel
-    ADDS, autograd sees no gradient and launches no AccumulateGrad kernels), otherwise fresh tensors."""
-    direct = (GRAD_SINK is not None and want and weight.grad is not None and bias.grad is not None
-              and weight.grad.dtype == torch.float32 and bias.grad.dtype == torch.float32
-              and weight.grad.is_contiguous() and bias.grad.is_contiguous())
-    if direct:
-        return weight.grad, bias.grad, True
+    """Buffers the LayerNorm backward writes dgamma / dbeta to: under a GRAD_SINK that knows both parameters their fp32
+    gradient buffers (the kernel ADDS, autograd sees no gradient and launches no AccumulateGrad kernels), otherwise fresh
+    tensors."""
+    wbuf = _sink_buffer(weight) if want else None
+    bbuf = _sink_buffer(bias) if wbuf is not None else None
+    if wbuf is not None and bbuf is not None:
+        return wbuf.view(-1), bbuf.view(-1), True
     return (torch.empty(width, dtype=torch.float32, device=device), torch.empty(width, dtype=torch.float32, device=device), False)
 
 
 def _norm_param_result(weight, bias, dgamma, dbeta, direct):
     if not direct:
         return dgamma.to(weight.dtype), dbeta.to(bias.dtype)
-    if callable(GRAD_SINK):
-        GRAD_SINK(weight)
-        GRAD_SINK(bias)
+    GRAD_SINK.deposited(weight)
+    GRAD_SINK.deposited(bias)
     return None, None
 
 
@@ -386,18 +392,14 @@ def gelu_dropout(x, p=0.0, seed=None):
 
 # ----------------------------------------------------------------------------- Linear with HIP weight gradient
 class AsyncWgrad:
-    """Opt-in: run the weight/bias-gradient kernels of every Linear on a SIDE stream and deposit their results straight
-    into the parameters' .grad buffers (which must already exist, e.g. as views into parallel.GradBucketAllReduce's flat
-    buckets, zeroed each step).  Nothing on the backward critical path consumes dW, and the wgrad kernels are MFMA work
-    while much of the rest of backward (LayerNorm, GELU, attention) is HBM-bound, so the two co-schedule on the chip.
+    """Opt-in: run the weight/bias-gradient kernels of every Linear on a SIDE stream (their results go straight into the
+    GRAD_SINK's buffers).  Nothing on the backward critical path consumes dW, and the wgrad kernels are MFMA work while much
+    of the rest of backward (LayerNorm, attention) is HBM-bound, so the two can co-schedule on the chip.
+    `sync()` makes the current stream wait for everything enqueued so far (the sink calls it before it exchanges a bucket
+    and at the end of the pass)."""
 
-    `sink(param)` is called after each deposit is ENQUEUED (bucket bookkeeping); `sync()` makes the current stream wait
-    for everything enqueued so far (call before reading gradients: all-reduce, optimizer step)."""
-
-    def __init__(self, device, sink=None):
+    def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
-        self.sink = sink
-        self.event = torch.cuda.Event()
 
     def sync(self):
         cur = torch.cuda.current_stream(self.stream.device)
@@ -405,16 +407,21 @@ class AsyncWgrad:
 
 
 ASYNC_WGRAD = None  # an AsyncWgrad instance, or None
-# Direct gradient deposit on the CURRENT stream: when set (True, or a callable notified per parameter), Linear weight/bias
-# gradients are accumulated by the wgrad kernel straight into existing fp32 .grad buffers and autograd sees no gradient for
-# them (post-accumulate hooks do not fire: the callable replaces them).  Set by parallel.GradBucketAllReduce.
+# Direct gradient deposit: an object with `grad_buffer(param) -> fp32 tensor | None` and `deposited(param)` (installed by
+# parallel.GradBucketAllReduce).  Linear / LayerNorm parameter gradients of the parameters it knows are accumulated by the
+# kernels straight into those buffers and autograd sees no gradient for them (no AccumulateGrad kernels, no dtype round trip).
 GRAD_SINK = None
 
 
 class ParamCastCache:
     """Activation-dtype copies of the fp32 master parameters of the Linear layers.  Refreshed for ALL registered parameters
-    by one multi-tensor copy when any of them changed since the last refresh (the optimizer step bumps their version
-    counters), instead of one cast kernel per parameter and forward."""
+    by one multi-tensor copy when any of them changed since the last refresh, instead of one cast kernel per parameter and
+    forward.  A change is detected through (data_ptr, _version) of each parameter: optimizer steps, load_state_dict,
+    `param.data = ...` are seen; in-place writes through `param.data` (some EMA / SWA utilities, manual weight surgery) bump
+    neither -- call `invalidate()` (or `model.invalidate_param_casts()`) after those, or set `always_refresh = True` to pay
+    the one multi-tensor copy every forward."""
+
+    always_refresh = False
 
     def __init__(self, params, dtype):
         self.params = [p for p in params if p.dtype != dtype]
@@ -423,9 +430,12 @@ class ParamCastCache:
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.versions = None
 
+    def invalidate(self):
+        self.versions = None
+
     def refresh(self):
-        versions = [p._version for p in self.params]
-        if versions != self.versions:
+        versions = [(p.data_ptr(), p._version) for p in self.params]
+        if self.always_refresh or versions != self.versions:
             with torch.no_grad():
                 torch._foreach_copy_(self.shadows, self.params)
             self.versions = versions
@@ -447,17 +457,20 @@ def _cast_param(p, dtype):
 
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b with fp32 master parameters and activations in x.dtype.
-    forward / input gradient: library GEMM; weight + bias gradient (bf16): `hs_linear_wgrad` (split over the token axis,
-    fp32 results straight into the master dtype)."""
+    forward / input gradient: library GEMM; weight + bias gradient: `hs_linear_wgrad` (split over the token axis, fp32
+    results straight into the master dtype).  `weight` may carry trailing singleton dimensions (the decoder's 1x1 Conv1d head,
+    [f_out, C, 1]): it is used as the [n_out, k_in] matrix it is, so the PARAMETER itself (a leaf) receives the gradient."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, passthrough=False):
         _require_gpu(x, weight, bias)
-        w = _cast_param(weight, x.dtype)
+        n_out = weight.shape[0]
+        k_in = weight.numel() // n_out
+        w = _cast_param(weight, x.dtype).view(n_out, k_in)
         b = None if bias is None else _cast_param(bias, x.dtype)
         ctx.save_for_backward(x, weight)
         ctx.bias_param = bias
-        ctx.w_cast = w if w is not weight else None  # activation-dtype copy, reused by the input-gradient GEMM
+        ctx.w_cast = w if w.dtype != weight.dtype else None  # activation-dtype copy, reused by the input-gradient GEMM
         ctx.passthrough = passthrough
         y = torch.nn.functional.linear(x, w, b)
         # passthrough: also hand x back (an alias) for the block's residual connection.  The gradient of that second use then
@@ -467,7 +480,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None):
-        """dW (and db) of one Linear.  With dw_out/db_out (existing fp32 .grad buffers) the result is ADDED there."""
+        """dW (and db) of one Linear.  With dw_out/db_out (existing fp32 gradient buffers) the result is ADDED there."""
         rows = x2.shape[0]
         dev = x2.device
         accumulate = 1 if dw_out is not None else 0
@@ -485,7 +498,8 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy, dx_res=None):
         x, weight = ctx.saved_tensors
         bias = ctx.bias_param
-        n_out, k_in = weight.shape
+        n_out = weight.shape[0]
+        k_in = weight.numel() // n_out
         if dy is None:  # only the passthrough alias was used downstream
             return dx_res, None, None, None
         dy2 = dy.reshape(-1, n_out)
@@ -495,7 +509,7 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             w = ctx.w_cast if (ctx.w_cast is not None and ctx.w_cast.dtype == dy.dtype) else (
-                weight if weight.dtype == dy.dtype else weight.to(dy.dtype))
+                weight if weight.dtype == dy.dtype else weight.to(dy.dtype)).view(n_out, k_in)
             if dx_res is not None:
                 dx = torch.addmm(dx_res.reshape(-1, k_in).to(dy2.dtype), dy2, w).reshape(x.shape)
             else:
@@ -507,35 +521,33 @@ class LinearFn(torch.autograd.Function):
             return dx, None, None, None
         hip_ok = (x2.is_contiguous() and n_out % 4 == 0 and
                   ((x.dtype == torch.bfloat16 and k_in % 8 == 0) or (x.dtype == torch.float32 and k_in % 4 == 0)))
-        aw = ASYNC_WGRAD
-        sink = GRAD_SINK if aw is None else aw.sink
-        direct = ((aw is not None or GRAD_SINK is not None) and hip_ok and want_w and weight.grad is not None
-                  and weight.grad.dtype == torch.float32 and weight.grad.is_contiguous()
-                  and (not want_b or (bias.grad is not None and bias.grad.dtype == torch.float32)))
-        if direct:
-            # accumulate dW (and db) straight into the parameters' .grad buffers (no autograd AccumulateGrad kernels, no
-            # dtype round trip); optionally on the side stream
+        wbuf = _sink_buffer(weight) if (hip_ok and want_w) else None
+        bbuf = _sink_buffer(bias) if (wbuf is not None and want_b) else None
+        if wbuf is not None and (not want_b or bbuf is not None):
+            # accumulate dW (and db) straight into the sink's gradient buffers (no autograd AccumulateGrad kernels, no dtype
+            # round trip); optionally on the side stream
+            aw = ASYNC_WGRAD
+            wbuf = wbuf.view(n_out, k_in)
             if aw is not None:
                 cur = torch.cuda.current_stream(x.device)
                 aw.stream.wait_stream(cur)
                 dy2.record_stream(aw.stream)
                 x2.record_stream(aw.stream)
                 with torch.cuda.stream(aw.stream):
-                    LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, weight.grad, bias.grad if want_b else None)
+                    LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
             else:
-                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, weight.grad, bias.grad if want_b else None)
-            if callable(sink):
-                sink(weight)
-                if want_b:
-                    sink(bias)
+                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
+            GRAD_SINK.deposited(weight)
+            if want_b:
+                GRAD_SINK.deposited(bias)
             return dx, None, None, None
         if hip_ok:
             dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b)
-            dw = dw32.to(weight.dtype) if want_w else None
+            dw = dw32.to(weight.dtype).view(weight.shape) if want_w else None
             db = db32.to(bias.dtype) if want_b else None
-        else:  # fp32 activations (or odd widths): library GEMM
+        else:  # odd widths: library GEMM
             if want_w:
-                dw = (dy2.t() @ x2).to(weight.dtype)
+                dw = (dy2.t() @ x2).to(weight.dtype).view(weight.shape)
             if want_b:
                 db = dy2.sum(0).to(bias.dtype)
         return dx, dw, db, None
@@ -596,17 +608,16 @@ class ConcatLinearFn(torch.autograd.Function):
         else:
             dwa, dwb = dy2.t() @ x2, dy2.t() @ s2
             db32 = dy2.sum(0) if want_b else None
-        direct = (GRAD_SINK is not None and want_w and weight.grad is not None and weight.grad.dtype == torch.float32
-                  and (not want_b or (bias.grad is not None and bias.grad.dtype == torch.float32)))
-        if direct:
-            weight.grad[:, :c].add_(dwa)
-            weight.grad[:, c:].add_(dwb)
+        wbuf = _sink_buffer(weight) if want_w else None
+        bbuf = _sink_buffer(bias) if (wbuf is not None and want_b) else None
+        if wbuf is not None and (not want_b or bbuf is not None):
+            wbuf[:, :c].add_(dwa)
+            wbuf[:, c:].add_(dwb)
             if want_b:
-                bias.grad.add_(db32)
-            if callable(GRAD_SINK):
-                GRAD_SINK(weight)
-                if want_b:
-                    GRAD_SINK(bias)
+                bbuf.add_(db32)
+            GRAD_SINK.deposited(weight)
+            if want_b:
+                GRAD_SINK.deposited(bias)
             return dx, dskip, None, None
         dw = torch.cat([dwa, dwb], 1).to(weight.dtype) if want_w else None
         return dx, dskip, dw, (db32.to(bias.dtype) if want_b else None)

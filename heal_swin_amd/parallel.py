@@ -8,7 +8,20 @@ The reference's only collective is Lightning-DDP's gradient all-reduce (heal_swi
     the exchange overlaps the rest of backward;
   * bucket size defaults to 64 MiB: xGMI is point-to-point and ring steps are per-link bound, so few large
     messages beat many small ones (298-596 MB per step for the B model).
+
+Step protocol (one optimizer step):
+
+    dp.zero_grad()                      # or optimizer.zero_grad(set_to_none=True): detected, see _begin_pass
+    with dp.no_sync():                  # optional gradient accumulation: all micro-batches but the last
+        loss_1.backward(); dp.finish()
+    loss_k.backward(); dp.finish()      # last micro-batch: buckets are exchanged (sum of the micro-batches, averaged)
+    optimizer.step()
+
+A backward pass that would add local gradients on top of already exchanged ones (a second backward() after an
+exchanging pass without zeroing in between) raises instead of silently letting the replicas diverge.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -23,30 +36,32 @@ class GradBucketAllReduce:
         # a one-rank group normally skips the collectives; exchange_single_rank keeps them (exercises the RCCL path on one GPU)
         self._exchange = self.world > 1 or (exchange_single_rank and dist.is_initialized())
         self.buckets = []       # flat fp32 tensors
-        self._pending = []      # per bucket: number of grads still missing this step
-        self._counts = []
+        self._counts = []       # parameters per bucket
         self._where = {}        # param -> bucket id
-        self._works = []
-        self._seen = set()      # parameters already counted in this step
+        self._views = {}        # param -> its .grad view into the bucket
         self._build(bucket_bytes)
-        self._hooks = []
-        if self._exchange:
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._sync = True       # False inside no_sync()
+        self._reduced = False   # a bucket has been exchanged since the gradients were last zeroed
+        self._stepped = False   # an attached optimizer has stepped since the last exchange
+        self._reset_pass()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._direct = False
-        if direct_wgrad and not async_wgrad and self.params and self.params[0].is_cuda:
-            # Linear weight/bias gradients are accumulated by the wgrad kernel straight into the bucket views
+        on_gpu = bool(self.params) and self.params[0].is_cuda
+        if (direct_wgrad or async_wgrad) and on_gpu:
+            # kernels accumulate Linear / LayerNorm parameter gradients straight into the bucket views of the parameters
+            # REGISTERED HERE (ops asks grad_buffer(p) per parameter; other models in the process are unaffected)
             from . import ops
 
-            ops.GRAD_SINK = self._on_grad if self._exchange else True
+            ops.GRAD_SINK = self
             self._direct = True
-        if async_wgrad and self.params and self.params[0].is_cuda:
-            # Linear weight/bias gradients are produced on a side stream straight into the bucket views (ops.AsyncWgrad)
+        if async_wgrad and on_gpu:
+            # the Linear weight-gradient kernels additionally run on a side stream (ops.AsyncWgrad)
             from . import ops
 
-            self.async_wgrad = ops.AsyncWgrad(self.params[0].device, sink=self._on_grad if self._exchange else None)
+            self.async_wgrad = ops.AsyncWgrad(self.params[0].device)
             ops.ASYNC_WGRAD = self.async_wgrad
 
+    # ------------------------------------------------------------------ construction
     def _build(self, bucket_bytes):
         order = list(reversed(self.params))
         groups, cur, cur_bytes = [], [], 0
@@ -64,64 +79,163 @@ class GradBucketAllReduce:
             off = 0
             for p in ps:
                 assert p.dtype == torch.float32, "master parameters are fp32"
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                view = flat[off:off + p.numel()].view_as(p)
+                p.grad = view
                 off += p.numel()
                 self._where[p] = b
+                self._views[p] = view
             self.buckets.append(flat)
             self._counts.append(len(ps))
-        self._pending = list(self._counts)
 
+    def _reset_pass(self):
+        self._pending = list(self._counts)   # per bucket: gradients still missing in this backward pass
+        self._launched = [False] * len(self.buckets)
+        self._seen = set()                   # parameters already counted in this pass
+        self._works = []
+        self._pass_open = False
+
+    # ------------------------------------------------------------------ step protocol
     def zero_grad(self):
-        """Zero the buckets in place (keeps the .grad views alive; use instead of optimizer.zero_grad(set_to_none=True))."""
+        """Zero the buckets in place and (re-)attach every .grad view."""
         for flat in self.buckets:
             flat.zero_()
-        self._pending = list(self._counts)
-        self._works = []
-        self._seen = set()
+        for p, view in self._views.items():
+            if p.grad is not view:
+                p.grad = view
+        self._reduced = False
+        self._stepped = False
+        self._reset_pass()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside accumulate locally (no exchange), as DistributedDataParallel.no_sync()."""
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
+
+    @contextlib.contextmanager
+    def suspended(self):
+        """No direct deposit inside (e.g. around torch.autograd.grad calls that need the parameter gradients returned)."""
+        from . import ops
+        prev_sink, prev_aw = ops.GRAD_SINK, ops.ASYNC_WGRAD
+        if prev_sink is self:
+            ops.GRAD_SINK = None
+        if prev_aw is self.async_wgrad:
+            ops.ASYNC_WGRAD = None
+        try:
+            yield
+        finally:
+            ops.GRAD_SINK, ops.ASYNC_WGRAD = prev_sink, prev_aw
+
+    def attach_optimizer(self, optimizer):
+        """Lets a step of `optimizer` mark the start of a new iteration, for callers that zero gradients in place with
+        optimizer.zero_grad(set_to_none=False) instead of dp.zero_grad()."""
+        optimizer.register_step_post_hook(lambda *a, **k: setattr(self, "_stepped", True))
+        return optimizer
+
+    def _detached(self, p):
+        g = p.grad
+        return g is None or g.data_ptr() != self._views[p].data_ptr()
+
+    def _begin_pass(self):
+        """First gradient event of a backward pass.  `.grad` of a registered parameter that is None (the PyTorch / Lightning
+        default optimizer.zero_grad(set_to_none=True)) or a fresh tensor installed by autograd means "zero so far": the
+        view is zeroed, takes over what autograd may already have stored, and is attached again, so the direct-deposit
+        path and the flat buckets stay in use whatever way the caller zeroes."""
+        det = [p for p in self.params if self._detached(p)]
+        if det:
+            with torch.no_grad():
+                if len(det) == len(self.params):
+                    for flat in self.buckets:
+                        flat.zero_()
+                    self._reduced = False
+                else:
+                    for p in det:
+                        self._views[p].zero_()
+                for p in det:
+                    if p.grad is not None:
+                        self._views[p].copy_(p.grad)
+                    p.grad = self._views[p]
+        if self._reduced:
+            if not self._stepped:
+                raise RuntimeError(
+                    "GradBucketAllReduce: a backward pass started on gradients that were already exchanged and not zeroed "
+                    "since.  For gradient accumulation run all micro-batches but the last under dp.no_sync(); between "
+                    "optimizer steps call dp.zero_grad() or optimizer.zero_grad(set_to_none=True) (or attach_optimizer()).")
+            self._reduced = False  # the attached optimizer stepped: the caller zeroed in place (as with DDP, not verified)
+        self._stepped = False
+        self._pass_open = True
+
+    # ------------------------------------------------------------------ gradient events
+    def grad_buffer(self, p):
+        """fp32 buffer a kernel may ADD p's gradient into (the bucket view), or None if p is not registered here."""
+        if p not in self._where:
+            return None
+        if not self._pass_open:
+            self._begin_pass()
+        view = self._views[p]
+        if p.grad is not view and self._detached(p):
+            p.grad = view  # only reachable if the caller dropped .grad in the middle of a pass
+        return view
+
+    def deposited(self, p):
+        """A kernel has enqueued p's gradient into grad_buffer(p)."""
+        self._on_grad(p)
 
     def _on_grad(self, p):
-        # idempotent per step: a parameter whose gradient is deposited directly by a kernel is announced by the op itself,
+        # idempotent per pass: a parameter whose gradient is deposited directly by a kernel is announced by the op itself,
         # and PyTorch may ALSO run its post-accumulate hook (it does, with an undefined gradient)
+        if not self._pass_open:
+            self._begin_pass()
         if p in self._seen:
             return
         self._seen.add(p)
         b = self._where[p]
         self._pending[b] -= 1
-        if self._pending[b] == 0:
-            flat = self.buckets[b]
-            if self.async_wgrad is not None:
-                self.async_wgrad.sync()  # gradients deposited from the side stream must have landed before the exchange
-            flat.mul_(1.0 / self.world)  # average, as DDP does (gloo has no AVG op)
-            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._pending[b] == 0 and self._sync and self._exchange:
+            self._launch(b)
+
+    def _launch(self, b):
+        flat = self.buckets[b]
+        if self.async_wgrad is not None:
+            self.async_wgrad.sync()  # gradients deposited from the side stream must have landed before the exchange
+        flat.mul_(1.0 / self.world)  # average, as DDP does (gloo has no AVG op)
+        self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched[b] = True
+        self._reduced = True
 
     def finish(self):
-        """Wait for every in-flight bucket; call after backward(), before optimizer.step()."""
+        """End of a backward pass: wait for every in-flight bucket (and, outside no_sync(), exchange the buckets no hook
+        has launched); call after backward(), before optimizer.step()."""
         if self.async_wgrad is not None:
             self.async_wgrad.sync()
-        if self._exchange:
-            # parameters that received no gradient this step (unused) still need their bucket exchanged
+        if self._exchange and self._sync:
             for b, left in enumerate(self._pending):
-                if left not in (0, ) and left != self._counts[b]:
+                if self._launched[b]:
+                    continue
+                if 0 < left < self._counts[b] and self._pass_open:
                     raise RuntimeError("a gradient bucket was only partially produced; unused parameters are not supported")
-                if left == self._counts[b]:
-                    self.buckets[b].mul_(1.0 / self.world)
-                    self._works.append(dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                # untouched in this pass (parameters without gradient, or gradients accumulated under no_sync() earlier)
+                self._launch(b)
         for w in self._works:
             w.wait()
-        self._works = []
+        self._reset_pass()
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self.async_wgrad is not None:
-            from . import ops
+        if not self._direct and self.async_wgrad is None:
+            return
+        from . import ops
 
+        if self.async_wgrad is not None:
             if ops.ASYNC_WGRAD is self.async_wgrad:
                 ops.ASYNC_WGRAD = None
             self.async_wgrad = None
         if self._direct:
-            from . import ops
-
-            ops.GRAD_SINK = None
+            if ops.GRAD_SINK is self:
+                ops.GRAD_SINK = None
             self._direct = False

@@ -264,3 +264,28 @@ def depth_l2_loss(pred, target):
     means = pred[:, 0]
     keep = ~torch.isinf(target)
     return ((means[keep] - target[keep]) ** 2 / 2).mean()
+
+
+def depth_huber_loss(pred, target, delta=1.0):
+    """reference training/loss_depth_regression.py:56-68: SmoothL1Loss(beta=delta, mean) over non-inf targets,
+    i.e. 0.5 d^2 / delta for |d| < delta, else |d| - 0.5 delta.  The reference indexes `preds` (all channels) with the
+    [B,1,Npix] mask, which only works for a one-channel prediction."""
+    assert pred.shape[1] == 1, "the reference's huber_loss indexes preds[B,C,Npix] with a [B,1,Npix] mask: C must be 1"
+    keep = ~torch.isinf(target)
+    d = (pred[:, 0][keep] - target[keep]).abs()
+    return torch.where(d < delta, 0.5 * d * d / delta, d - 0.5 * delta).mean()
+
+
+def depth_mean_log_var_loss(pred, target):
+    """reference training/loss_depth_regression.py:23-38: mean of log_var/2 + (mean-target)^2 * exp(-log_var)/2 over
+    non-inf targets; channel 0 = mean, channel 1 = log variance."""
+    means, log_var = pred[:, 0], pred[:, 1]
+    keep = ~torch.isinf(target)
+    return (0.5 * log_var[keep] + (means[keep] - target[keep]) ** 2 * (0.5 * torch.exp(-log_var[keep]))).mean()
+
+
+def get_depth_loss(loss="l2", use_logvar=False, huber_delta=1.0):
+    """reference training/loss_depth_regression.py:70-83 (fields of CommonDepthConfig, depth_common_config.py:7-10)"""
+    if use_logvar:
+        return depth_mean_log_var_loss
+    return {"l2": depth_l2_loss, "l1": depth_l1_loss, "huber": lambda p, t: depth_huber_loss(p, t, huber_delta)}[loss]

@@ -1,22 +1,59 @@
-"""Shared helpers for the GPU parity tests."""
+"""Shared helpers for the GPU parity tests.
+
+Error measures (all against the reference / oracle tensor b):
+  scale_err  max|a-b| / max|b|          -- absolute error relative to the tensor's own scale (NO floor at 1: a tensor of
+                                            scale 1e-4, e.g. a parameter gradient, is judged at 1e-4)
+  rms_err    ||a-b||_2 / ||b||_2        -- average relative error
+  elem_err   99.9th percentile of |a-b| / max(|b|, 1e-2 max|b|)   -- element-relative error, elements below 1 % of the scale
+                                            judged against 1 % of the scale (relative error is meaningless at zero crossings)
+north_star tolerances: activations within 1e-3 (fp32) / 1e-2 (bf16) of the reference; asserted on scale_err.
+"""
 import numpy as np
 import torch
 
-# north_star tolerances: activations within 1e-3 (fp32) / 1e-2 (bf16) of the reference, measured
-# relative to the tensor's scale: max|a-b| / max(1, max|b|)
 TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
 # gradients of bf16 runs accumulate more rounding (two passes through every bf16 activation)
 GRAD_TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2}
 
+REPORT = []  # (what, scale_err, rms_err, elem_err, scale) of every comparison made; printed at the end of the session
+
+
+def _np(a):
+    return np.asarray(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float64)
+
+
+def errors(a, b):
+    a, b = _np(a), _np(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = np.abs(a - b)
+    scale = float(np.abs(b).max()) if b.size else 0.0
+    if scale == 0.0:
+        return dict(scale=0.0, abs=float(d.max()) if d.size else 0.0, scale_err=float(d.max()) if d.size else 0.0, rms_err=0.0, elem_err=0.0)
+    rms = float(np.sqrt((d * d).sum()) / max(np.sqrt((b * b).sum()), 1e-300))
+    el = d / np.maximum(np.abs(b), 1e-2 * scale)
+    return dict(scale=scale, abs=float(d.max()), scale_err=float(d.max()) / scale, rms_err=rms,
+                elem_err=float(np.quantile(el, 0.999)) if el.size > 1000 else float(el.max()))
+
 
 def rel_err(a, b):
-    a = np.asarray(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float64)
-    b = np.asarray(b.detach().float().cpu().numpy() if torch.is_tensor(b) else b, dtype=np.float64)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+    """max|a-b| / max|b| (an all-zero reference is compared absolutely)."""
+    return errors(a, b)["scale_err"]
 
 
-def assert_close(a, b, tol, what=""):
-    e = rel_err(a, b)
-    assert e <= tol, f"{what}: rel-to-scale err {e:.3e} > {tol}"
-    return e
+def assert_close(a, b, tol, what="", floor=0.0):
+    """scale_err <= tol.  `floor`: absolute error always accepted (for tensors that are exactly or nearly zero in the
+    reference, e.g. the gradient of a bias behind a LayerNorm)."""
+    e = errors(a, b)
+    REPORT.append((what, e["scale_err"], e["rms_err"], e["elem_err"], e["scale"]))
+    assert e["scale_err"] <= tol or e["abs"] <= floor, (
+        f"{what}: max|a-b|/max|b| = {e['scale_err']:.3e} > {tol} (scale {e['scale']:.3e}, abs {e['abs']:.3e}, "
+        f"rms {e['rms_err']:.3e}, elem99.9 {e['elem_err']:.3e})")
+    return e["scale_err"]
+
+
+def worst(prefix=""):
+    """(worst scale_err, worst rms_err, worst elem_err) over the comparisons whose label starts with prefix."""
+    rows = [r for r in REPORT if r[0].startswith(prefix)]
+    if not rows:
+        return 0.0, 0.0, 0.0
+    return max(r[1] for r in rows), max(r[2] for r in rows), max(r[3] for r in rows)

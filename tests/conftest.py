@@ -6,6 +6,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+_PER_TEST = {}  # test id -> (n comparisons, worst scale_err, worst rms_err, worst elem_err)
+NOTES = []      # free-form measured-error lines the parity tests want in the terminal summary
 
 
 def pytest_configure(config):
@@ -22,3 +28,28 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _collect_errors(request):
+    import _util
+
+    start = len(_util.REPORT)
+    yield
+    rows = _util.REPORT[start:]
+    if rows:
+        _PER_TEST[request.node.nodeid] = (len(rows), max(r[1] for r in rows), max(r[2] for r in rows), max(r[3] for r in rows))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Observed parity errors (max|a-b|/max|b|, rms, element-relative 99.9 %) of every test that compared tensors."""
+    if not _PER_TEST and not NOTES:
+        return
+    tr = terminalreporter
+    tr.section("observed parity errors")
+    for line in NOTES:
+        tr.write_line(line)
+    worst = sorted(_PER_TEST.items(), key=lambda kv: -kv[1][1])
+    tr.write_line(f"{len(_PER_TEST)} tests compared tensors; the 25 largest max|a-b|/max|b| (scale / rms / elem99.9, #comparisons):")
+    for nodeid, (n, s, r, e) in worst[:25]:
+        tr.write_line(f"  {s:.2e} / {r:.2e} / {e:.2e}  ({n:4d})  {nodeid.split('/')[-1]}")

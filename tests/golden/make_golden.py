@@ -269,16 +269,35 @@ def make_losses():
     out["depth/standardize/in"] = npy(d)
     out["depth/standardize/out"] = npy(ND.normalize_data(d, st, "standardize"))
     out["depth/standardize/back"] = npy(ND.unnormalize_data(ND.normalize_data(d, st, "standardize"), st, "standardize"))
+    # huber (delta 1 and 0.3) on the one-channel prediction and the mean / log-variance loss on a two-channel one:
+    # training/loss_depth_regression.py:23-38, :56-83 (drawn AFTER everything above, so the earlier arrays keep their values)
+    from heal_swin.models_lightning.depth_estimation.depth_common_config import CommonDepthConfig
+
+    for tag, delta in (("huber_d1", 1), ("huber_d0p3", 0.3)):
+        fn = LD.get_depth_loss(CommonDepthConfig(loss="huber", huber_delta=delta))
+        loss = fn(pred, target)
+        (g,) = torch.autograd.grad(loss, pred)
+        out[f"depth/{tag}/loss"] = npy(loss)
+        out[f"depth/{tag}/dpred"] = npy(g)
+    assert LD.get_depth_loss(CommonDepthConfig(loss="l1")) is LD.l1_loss and LD.get_depth_loss(CommonDepthConfig(loss="l2")) is LD.mse
+    pred2 = torch.randn(2, 2, 512, generator=gen).requires_grad_(True)
+    fn = LD.get_depth_loss(CommonDepthConfig(loss="l1", use_logvar=True))
+    assert fn is LD.mean_log_var_loss
+    loss = fn(pred2, target)
+    (g,) = torch.autograd.grad(loss, pred2)
+    out["depth/logvar/loss"] = npy(loss)
+    out["depth/logvar/dpred"] = npy(g)
+    out["depth/logvar/pred"] = npy(pred2)
     np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
     print("losses.npz", len(out), "arrays")
 
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    make_tables()
-    make_modules()
-    make_models()
-    make_losses()
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]  # e.g. `make_golden.py losses` regenerates one file
+    for name, fn in (("tables", make_tables), ("modules", make_modules), ("models", make_models), ("losses", make_losses)):
+        if not only or name in only:
+            fn()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -1,0 +1,118 @@
+"""Parity on BASELINE.json's own architectures, default-initialised, against the oracle (forward AND backward):
+
+  configs[1]  HEAL-SWIN-T, nside 128, 8 base pixels, window 64, nest_roll -- at its full size, bf16 and fp32
+  configs[2]  HEAL-SWIN-B (embed 128, depths [2,2,18,2], heads [4,8,16,32]), 12 base pixels, window 64 -- at nside 64
+              (the oracle's 46 blocks at nside 256 take minutes per image on the host)
+  paper       HEAL-SWIN-T ring_shift(4) + cosine attention + v2 norm placement at nside 64, logit_scale at its init (ln 10)
+
+Weights as `SwinHPTransformerSys.__init__` leaves them (trunc-normal 0.02 Linears, unit LayerNorms) except the
+relative-position table, which the reference initialises to zero and is drawn N(0, 0.02) here so that the bias path
+carries signal.  Inputs are raw 0..255 images and random labels; the loss is the segmentation caller's cross entropy.
+north_star: logits within 1e-3 (fp32) / 1e-2 (bf16) of the reference -- asserted on max|a-b|/max|b|, with the observed
+errors (also rms and element-relative) printed in the terminal summary.  The goldens with one attention head pinned at
+the x100 logit clamp are a separate, explicitly labelled stress case (tests/test_gpu_model.py, test_gpu_kernels.py).
+"""
+import types
+
+import pytest
+import torch
+
+import conftest
+from _util import assert_close, errors
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+T_CFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24])
+B_CFG = dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32])
+CASES = {
+    # name: (arch, nside, base_pix, batch, overrides)
+    "configs1_T_nside128_bp8": (T_CFG, 128, 8, 2, dict(shift_strategy="nest_roll", shift_size=32)),
+    "configs2_B_nside64_bp12": (B_CFG, 64, 12, 1, dict(shift_strategy="nest_roll", shift_size=32)),
+    "paper_T_ring_cos_v2_nside64_bp8": (T_CFG, 64, 8, 1, dict(shift_strategy="ring_shift", shift_size=4, use_cos_attn=True,
+                                                                use_v2_norm_placement=True)),
+}
+# logits: north_star; parameter / input gradients: two passes through every bf16 activation
+LOGIT_TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+GRAD_TOL = {torch.float32: 2e-3, torch.bfloat16: 5e-2}
+_ORACLE = {}
+
+
+def _setup(name):
+    from heal_swin_amd.data_spec import DataSpec
+    from heal_swin_amd.models_torch import swin_hp_transformer as M
+    arch, nside, bp, batch, over = CASES[name]
+    cfg = dict(patch_size=4, window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", mlp_ratio=4.0,
+               qkv_bias=True, qk_scale=None, use_cos_attn=False, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0,
+               use_v2_norm_placement=False, ape=False)
+    cfg.update(arch)
+    cfg.update(over)
+    spec = dict(dim_in=bp * nside * nside, f_in=3, f_out=12, base_pix=bp, class_names=[])
+    torch.manual_seed(11)
+    model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), DataSpec(**spec))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("relative_position_bias_table"):
+                p.normal_(0, 0.02)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (batch, 3, spec["dim_in"]), generator=g).float()
+    y = torch.randint(0, 12, (batch, spec["dim_in"]), generator=g)
+    return model, cfg, spec, x, y
+
+
+def _oracle(name):
+    """Oracle logits, loss and gradients of the case (CPU fp32, computed once per session)."""
+    if name not in _ORACLE:
+        from oracle import model as OM
+        model, cfg, spec, x, y = _setup(name)
+        sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
+              if not k.endswith("attn_mask")}
+        xr = x.clone().requires_grad_(True)
+        logits = OM.forward(sd, types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec), xr)
+        loss = OM.seg_loss(logits, y)
+        loss.backward()
+        grads = {k: v.grad.detach() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+        _ORACLE[name] = (logits.detach(), float(loss), grads, xr.grad.detach())
+    return _ORACLE[name]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_baseline_architecture_fwd_bwd_vs_oracle(name, dtype):
+    from heal_swin_amd.losses import seg_loss
+    ref_logits, ref_loss, ref_grads, ref_dx = _oracle(name)
+    model, cfg, spec, x, y = _setup(name)
+    model = model.to(DEV).train()
+    model.compute_dtype = dtype
+    xg = x.to(DEV).requires_grad_(True)
+    logits = model(xg)
+    assert logits.dtype == dtype and logits.shape == ref_logits.shape
+    loss = seg_loss(logits, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    tag = f"{name}[{'bf16' if dtype == torch.bfloat16 else 'fp32'}]"
+    e = errors(logits, ref_logits)
+    conftest.NOTES.append(f"{tag}: logits max|a-b|/max|b| {e['scale_err']:.2e} (scale {e['scale']:.2f}), rms {e['rms_err']:.2e}, "
+                          f"elem99.9 {e['elem_err']:.2e}; loss {float(loss):.6f} vs oracle {ref_loss:.6f}")
+    assert_close(logits, ref_logits, LOGIT_TOL[dtype], tag + " logits")
+    assert abs(float(loss) - ref_loss) <= (1e-4 if dtype == torch.float32 else 2e-3) * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+
+    params = dict(model.named_parameters())
+    worst = ("", 0.0)
+    rms = []
+    for k, g in ref_grads.items():
+        got = params[k].grad
+        got = torch.zeros_like(params[k]) if got is None else got
+        eg = errors(got, g)
+        rms.append(eg["rms_err"])
+        if eg["scale_err"] > worst[1]:
+            worst = (k, eg["scale_err"])
+        # biases in front of a LayerNorm-free softmax (k bias of scaled attention) have an exactly-zero gradient in the
+        # reference: compare those absolutely against the scale of their weight's gradient
+        floor = 1e-6 * float(ref_grads[k.replace(".bias", ".weight")].abs().max()) if k.endswith(".bias") else 0.0
+        assert_close(got, g, GRAD_TOL[dtype], f"{tag} grad {k}", floor=floor + (1e-7 if dtype == torch.bfloat16 else 1e-9))
+    edx = errors(xg.grad, ref_dx)
+    assert_close(xg.grad, ref_dx, GRAD_TOL[dtype], tag + " dx")
+    conftest.NOTES.append(f"{tag}: {len(ref_grads)} parameter gradients, worst max|a-b|/max|b| {worst[1]:.2e} ({worst[0]}), "
+                          f"median rms {sorted(rms)[len(rms) // 2]:.2e}; input gradient {edx['scale_err']:.2e}")

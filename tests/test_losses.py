@@ -1,6 +1,6 @@
 """Caller-side losses of the product (heal_swin_amd/losses.py) vs the golden vectors captured from
-the reference's CrossEntropyLoss / loss_depth_regression / normalize_depth_data.  Plain torch compositions: run on CPU
-here and on the GPU in the gpu-marked variant."""
+the reference's CrossEntropyLoss / loss_depth_regression / normalize_depth_data.  The depth losses are plain torch compositions (checked on CPU here and on the GPU); the segmentation
+cross-entropy exists only as HIP kernels (GPU test; the oracle restatement is pinned in tests/test_oracle_model.py)."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +8,30 @@ import torch
 from _golden import load
 
 
-def _check(dev):
+def _check_depth(dev):
+    from types import SimpleNamespace as NS
+
+    from heal_swin_amd import losses as L
+    z = load("losses")
+    tgt = torch.from_numpy(z["depth/target"]).to(dev)
+    cases = [("l1", L.get_depth_loss(NS(use_logvar=False, loss="l1", huber_delta=1)), "depth/pred"),
+             ("l2", L.get_depth_loss(NS(use_logvar=False, loss="l2", huber_delta=1)), "depth/pred"),
+             ("huber_d1", L.get_depth_loss(NS(use_logvar=False, loss="huber", huber_delta=1)), "depth/pred"),
+             ("huber_d0p3", L.get_depth_loss(NS(use_logvar=False, loss="huber", huber_delta=0.3)), "depth/pred"),
+             ("logvar", L.get_depth_loss(NS(use_logvar=True, loss="l1", huber_delta=1)), "depth/logvar/pred")]
+    assert cases[0][1] is L.depth_l1_loss and cases[1][1] is L.depth_l2_loss and cases[4][1] is L.depth_mean_log_var_loss
+    for tag, fn, pkey in cases:
+        pred = torch.from_numpy(z[pkey]).to(dev).requires_grad_(True)
+        loss = fn(pred, tgt)
+        assert abs(float(loss) - float(z[f"depth/{tag}/loss"])) < 1e-6, tag
+        loss.backward()
+        assert np.abs(pred.grad.cpu().numpy() - z[f"depth/{tag}/dpred"]).max() < 1e-7, tag
+    d = torch.from_numpy(z["depth/standardize/in"]).to(dev)
+    assert np.allclose(L.depth_standardize(d).cpu().numpy(), z["depth/standardize/out"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(L.depth_unstandardize(L.depth_standardize(d)).cpu().numpy(), z["depth/standardize/back"], rtol=1e-6, atol=1e-5)
+
+
+def _check_seg(dev):
     from heal_swin_amd import losses as L
     z = load("losses")
     for tag in ("weighted", "uniform"):
@@ -18,15 +41,6 @@ def _check(dev):
         loss.backward()
         assert np.abs(logits.grad.cpu().numpy() - z[f"seg/{tag}/dlogits"]).max() < 1e-7
     assert np.array_equal(L.seg_predictions(torch.from_numpy(z["seg/logits"]).to(dev)).cpu().numpy(), z["seg/argmax"])
-    for tag, fn in (("l1", L.depth_l1_loss), ("l2", L.depth_l2_loss)):
-        pred = torch.from_numpy(z["depth/pred"]).to(dev).requires_grad_(True)
-        loss = fn(pred, torch.from_numpy(z["depth/target"]).to(dev))
-        assert abs(float(loss) - float(z[f"depth/{tag}/loss"])) < 1e-6
-        loss.backward()
-        assert np.abs(pred.grad.cpu().numpy() - z[f"depth/{tag}/dpred"]).max() < 1e-7
-    d = torch.from_numpy(z["depth/standardize/in"]).to(dev)
-    assert np.allclose(L.depth_standardize(d).cpu().numpy(), z["depth/standardize/out"], rtol=1e-6, atol=1e-6)
-    assert np.allclose(L.depth_unstandardize(L.depth_standardize(d)).cpu().numpy(), z["depth/standardize/back"], rtol=1e-6, atol=1e-5)
     # bf16 logits are up-cast: the loss of rounded logits equals the fp32 loss of the same rounded values
     lg = torch.from_numpy(z["seg/logits"]).to(dev).to(torch.bfloat16)
     a = L.seg_loss(lg, torch.from_numpy(z["seg/labels"]).to(dev))
@@ -34,10 +48,18 @@ def _check(dev):
     assert float(a) == float(b)
 
 
-def test_losses_cpu():
-    _check("cpu")
+def test_depth_losses_cpu():
+    _check_depth("cpu")  # thin torch compositions: device-agnostic host logic
+
+
+def test_seg_loss_has_no_cpu_path():
+    from heal_swin_amd import losses as L
+    z = load("losses")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.seg_loss(torch.from_numpy(z["seg/logits"]), torch.from_numpy(z["seg/labels"]))
 
 
 @pytest.mark.gpu
 def test_losses_gpu():
-    _check("cuda")
+    _check_seg("cuda")
+    _check_depth("cuda")

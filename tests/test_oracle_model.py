@@ -99,8 +99,12 @@ def test_seg_loss():
 
 def test_depth_losses():
     z = load("losses")
-    for tag, fn in (("l1", OM.depth_l1_loss), ("l2", OM.depth_l2_loss)):
-        pred = torch.from_numpy(z["depth/pred"]).requires_grad_(True)
+    cases = (("l1", OM.get_depth_loss("l1"), "depth/pred"), ("l2", OM.get_depth_loss("l2"), "depth/pred"),
+             ("huber_d1", OM.get_depth_loss("huber", huber_delta=1), "depth/pred"),
+             ("huber_d0p3", OM.get_depth_loss("huber", huber_delta=0.3), "depth/pred"),
+             ("logvar", OM.get_depth_loss("l1", use_logvar=True), "depth/logvar/pred"))
+    for tag, fn, pkey in cases:
+        pred = torch.from_numpy(z[pkey]).requires_grad_(True)
         loss = fn(pred, torch.from_numpy(z["depth/target"]))
         close(loss.detach().numpy(), z[f"depth/{tag}/loss"], 1e-6, "loss")
         loss.backward()

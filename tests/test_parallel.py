@@ -90,3 +90,98 @@ def test_single_process_is_a_noop_wrapper():
     dp.finish()
     flat = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))])
     assert torch.equal(flat, dp.buckets[0])  # .grad tensors are views into the flat bucket
+
+
+def _accum_worker(rank, world, port, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heal_swin_amd.parallel import GradBucketAllReduce
+
+    torch.set_num_threads(1)
+    model = _model()
+    dp = GradBucketAllReduce(model.parameters(), bucket_bytes=1024)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-1)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 2, 8, 12, generator=g)  # 2 steps x 2 micro-batches, global micro-batch 8
+    y = torch.randn(2, 2, 8, 7, generator=g)
+    err = None
+    try:
+        for step in range(2):
+            if mode == "set_to_none":
+                opt.zero_grad(set_to_none=True)  # the PyTorch / Lightning default: .grad views dropped, detected at the next backward
+            else:
+                dp.zero_grad()
+            for mb in range(2):
+                xs, ys = x[step, mb].chunk(world)[rank], y[step, mb].chunk(world)[rank]
+                if mode == "no_no_sync":  # accumulation WITHOUT no_sync(): the second backward must raise, not diverge
+                    torch.nn.functional.mse_loss(model(xs), ys).backward()
+                    dp.finish()
+                elif mb == 0:
+                    with dp.no_sync():
+                        torch.nn.functional.mse_loss(model(xs), ys).backward()
+                        dp.finish()
+                else:
+                    torch.nn.functional.mse_loss(model(xs), ys).backward()
+                    dp.finish()
+            assert all(p.grad.data_ptr() == dp._views[p].data_ptr() for p in dp.params)  # still bucket views
+            opt.step()
+    except RuntimeError as e:
+        err = str(e)
+    q.put((rank, [p.detach().numpy().copy() for p in model.parameters()], err))
+    dist.destroy_process_group()
+
+
+def _run_accum(mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("mode", ["dp_zero_grad", "set_to_none"])
+def test_gradient_accumulation_under_no_sync_matches_single_process(mode):
+    """Two micro-batches per step (the first under no_sync()): the replicas must end up with the gradients of the sum of
+    both micro-batch losses averaged over the ranks -- i.e. equal single-process training on the un-split micro-batches --
+    whether the caller zeroes with dp.zero_grad() or with optimizer.zero_grad(set_to_none=True)."""
+    results = _run_accum(mode)
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-1)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 2, 8, 12, generator=g)
+    y = torch.randn(2, 2, 8, 7, generator=g)
+    for step in range(2):
+        opt.zero_grad()
+        for mb in range(2):
+            torch.nn.functional.mse_loss(model(x[step, mb]), y[step, mb]).backward()
+        opt.step()
+    for rank, params, err in results:
+        assert err is None, err
+        for a, b in zip(params, model.parameters()):
+            assert torch.allclose(torch.from_numpy(a), b.detach(), atol=1e-6, rtol=1e-5), rank
+    for a, b in zip(results[0][1], results[1][1]):
+        assert (a == b).all()
+
+
+def test_second_backward_on_exchanged_gradients_raises():
+    for rank, params, err in _run_accum("no_no_sync"):
+        assert err is not None and "no_sync" in err, err
+
+
+def test_other_models_are_not_touched_by_the_sink():
+    """grad_buffer() answers only for the parameters registered with this instance."""
+    sys.path.insert(0, ROOT)
+    from heal_swin_amd.parallel import GradBucketAllReduce
+
+    model, other = _model(), _model()
+    dp = GradBucketAllReduce(model.parameters())
+    p_in, p_out = next(model.parameters()), next(other.parameters())
+    assert dp.grad_buffer(p_out) is None
+    assert dp.grad_buffer(p_in).data_ptr() == p_in.grad.data_ptr()
