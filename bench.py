@@ -167,9 +167,9 @@ def cpu_baseline(wl, budget_s=25.0):
     other = {}
     for key, batch in (("tiny", 1), ("T128", 1)):  # BASELINE configs[0] and configs[1] at full size
         w = WORKLOADS[key]
-        ts = _oracle_timing(w, w["nside"], batch, 1, 3)
+        ts = _oracle_timing(w, w["nside"], batch, 2, 3)
         other[key] = {"workload": w["name"], "images_per_s": batch * len(ts) / sum(ts), "s_per_iter": [round(v, 3) for v in ts],
-                      "batch": batch, "iters": "1 warm-up + 3 timed"}
+                      "batch": batch, "iters": "2 warm-up + 3 timed"}
     out["other_configs"] = other
     return out
 

@@ -1,0 +1,456 @@
+// bf16 "NT" GEMM with fused epilogues for the forward and input-gradient products of the path's Linear layers:
+//
+//     C[m, n] = sum_k A[m, k] * B[n, k]   (+ sum_k A2[m, k] * B2[n, k])   -> epilogue -> bf16
+//
+// A = activations (token rows, k contiguous), B = a weight as nn.Linear stores it ([out, in], k contiguous); the input
+// gradient uses the transposed bf16 weight copy, so it is the same product.  The optional second (A2, B2) segment is the
+// decoder's skip connection cat([x, skip]) W^T without the concatenation (swin_hp_transformer.py:772-775).
+// Epilogues (fp32 on the accumulators, before the single rounding to bf16):
+//     EPI_BIAS   c = acc + bias                                                    (qkv, proj, fc2, reduction, expand, head)
+//     EPI_GELU   h = acc + bias -> c ;  aux = dropout(gelu(h))                      (fc1 -> act -> drop, ref :39-41)
+//     EPI_DGELU  c = acc * mask * gelu'(aux)                                        (input gradient of fc2 through the GELU)
+//     EPI_RESID  c = acc + bias + aux                                               (residual gradient folded into a dgrad)
+// so the standalone GELU passes over the 4C-wide hidden tensor (13.5 % of the round-1 step) do not exist.
+//
+// Structure (gfx950):
+//   * workgroup tile BM x BN x 64, waves in WM x WN, each wave (BM/WM) x (BN/WN) as 32x32 accumulators of
+//     v_mfma_f32_32x32x16_bf16.  The product is formed TRANSPOSED (D = Bfrag * Afrag^T: accumulator column = m, rows = n),
+//     so a lane owns 4 consecutive n of one output row: 8-byte row-major stores, bias as a float4;
+//   * operands go global -> LDS by buffer_load ... lds (16 B per lane, 1 KB per wave-instruction), two stages, the loads of
+//     step s+1 in flight under the MFMAs of step s; the stream of steps runs ACROSS output tiles (persistent workgroups):
+//     the first loads of the next tile are in flight under the epilogue of the current one;
+//   * LDS image: tile rows of 128 B paired into 256-B super-rows, 16-byte chunk index XORed with the super-row number
+//     (applied to the per-lane SOURCE address of the DMA and to the fragment reads): the 16-lane groups of ds_read_b128
+//     touch 16 distinct 16-byte slots (conflict-free), and every 128-B global line is still fetched by 8 adjacent lanes;
+//   * tile ids are dealt to XCDs in contiguous ranges (block b runs on XCD b % 8), consecutive ids share the A row panel,
+//     so concurrently running workgroups of an XCD re-read A from that XCD's L2;
+//   * edges: rows beyond M / N fall outside the buffer descriptors (reads return 0, stores are dropped); a K tail and the
+//     n >= N columns are predicated per lane by pointing the access outside the descriptor.
+// 128 x 128 tiles run two workgroups per CU (64 KB LDS each): one's epilogue (VALU: erf GELU) overlaps the other's MFMAs.
+#include <cstdlib>
+#include <type_traits>
+
+#include "hs_gelu.h"
+
+namespace hs {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef unsigned int u32x2 __attribute__((__vector_size__(8)));    // the types the b64 / b128 buffer builtins take
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RESID = 3 };
+constexpr uint32_t kOob = 0x7FFFFF00u;      // a byte offset outside every descriptor below
+constexpr int64_t kMaxRecords = 0x7FFFFE00;  // descriptors are clamped to this many bytes (tiles address < 2 GiB from their origin)
+
+struct GemmParams {
+    const uint16_t *a, *b;
+    int64_t lda, ldb;
+    int k;
+    const uint16_t *a2, *b2;
+    int64_t lda2, ldb2;
+    int k2;
+    const float* bias;
+    uint16_t* c;
+    uint16_t* aux;
+    int64_t m;
+    int n;
+    int tiles_n, tiles, per_xcd, blocks_per_xcd;
+    float drop_p;
+    uint64_t seed;
+};
+
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 accumulators per wave along m / n
+    constexpr int AB = BM * 128, BB = BN * 128, STAGE = AB + BB;
+    constexpr int AI = AB / 1024 / NW, BI = BB / 1024 / NW;  // 1-KB DMA instructions per wave and stage
+    static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + NW * 4096];  // stages + one epilogue patch per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- this workgroup's tiles: XCD x owns ids [x * per_xcd, (x + 1) * per_xcd), dealt round-robin to its workgroups
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int id_end = min((xcd + 1) * p.per_xcd, p.tiles);
+    const int id0 = xcd * p.per_xcd + lb;
+    if (id0 >= id_end) return;
+    const int nk1 = (p.k + 63) >> 6, nk2 = (p.k2 + 63) >> 6, nk = nk1 + nk2;
+
+    // ---- DMA lane mapping: LDS position q (16-B units inside a tile) = (super-row R = q / 16, physical chunk q % 16);
+    // logical chunk = physical ^ (R & 15); tile row = 2 R + (logical >> 3), 16-byte column chunk = logical & 7
+    int a_row[AI], a_col[AI], b_row[BI], b_col[BI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int q = (wave * AI + j) * 64 + lane, R = q >> 4, lc = (q & 15) ^ (R & 15);
+        a_row[j] = 2 * R + (lc >> 3);
+        a_col[j] = (lc & 7) << 4;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int q = (wave * BI + j) * 64 + lane, R = q >> 4, lc = (q & 15) ^ (R & 15);
+        b_row[j] = 2 * R + (lc >> 3);
+        b_col[j] = (lc & 7) << 4;
+    }
+
+    // ---- issue side: the (tile, K segment) the DMA currently reads from.  Descriptors, row offsets and the row length are
+    // rebuilt only when the issue cursor enters a new tile or segment, not per k-step.
+    __amdgpu_buffer_rsrc_t ra, rb;
+    int a_off[AI], b_off[BI];  // byte offset of this lane's (row, chunk) inside the tile, k-step 0
+    int kseg = 0;              // bytes of a row of the current segment
+    auto retarget = [&](int id, bool s2) {
+        const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+        const int64_t m0 = (int64_t)tm * BM;
+        const int n0 = tn * BN;
+        const uint16_t* ap = s2 ? p.a2 : p.a;
+        const uint16_t* bp = s2 ? p.b2 : p.b;
+        const int64_t lda = s2 ? p.lda2 : p.lda, ldb = s2 ? p.ldb2 : p.ldb;
+        kseg = (s2 ? p.k2 : p.k) * 2;
+        int64_t abytes = (p.m - m0 - 1) * lda * 2 + kseg, bbytes = (int64_t)(p.n - n0 - 1) * ldb * 2 + kseg;
+        abytes = abytes > kMaxRecords ? kMaxRecords : abytes;
+        bbytes = bbytes > kMaxRecords ? kMaxRecords : bbytes;
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)(ap + m0 * lda), 0, (int)abytes, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + (int64_t)n0 * ldb), 0, (int)bbytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < AI; ++j) a_off[j] = a_row[j] * ((int)lda * 2) + a_col[j];
+#pragma unroll
+        for (int j = 0; j < BI; ++j) b_off[j] = b_row[j] * ((int)ldb * 2) + b_col[j];
+    };
+    // DMA pieces [first, first + count) of the AI + BI pieces of one k-step (byte offset kb inside the row) into stage `buf`
+    auto issue_pieces = [&](int kb, int buf, auto first_c, auto count_c) {
+        constexpr int first = decltype(first_c)::value, count = decltype(count_c)::value;
+        unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int q = first; q < first + count; ++q) {
+            if (q < AI) {
+                const uint32_t voff = kb + a_col[q] < kseg ? (uint32_t)(a_off[q] + kb) : kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (wave * AI + q) * 1024), 16, voff, 0, 0, 0);
+            } else {
+                const int j = q - AI;
+                const uint32_t voff = kb + b_col[j] < kseg ? (uint32_t)(b_off[j] + kb) : kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + AB + (wave * BI + j) * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addresses: operand row r (tile row), lane half h supplies k-chunk 2 ksub + h of the 16-deep MFMA step:
+    // byte = R * 256 + ((((r & 1) * 8 + 2 ksub + h) ^ (R & 15)) << 4) = frag_base ^ (ksub << 5)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t a_frag[TM], b_frag[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / WM) + i * 32 + l31, R = r >> 1;
+        a_frag[i] = lds0 + R * 256 + (((((r & 1) << 3) + half) ^ (R & 15)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * (BN / WN) + j * 32 + l31, R = r >> 1;
+        b_frag[j] = lds0 + AB + R * 256 + (((((r & 1) << 3) + half) ^ (R & 15)) << 4);
+    }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    // ---- one k-step out of stage buffer `buf`: two halves of two 16-deep MFMA sub-steps each; all fragment reads of the
+    // step are issued first (LDS returns in order), the second half's latency hides under the first half's MFMAs
+    auto compute = [&](int buf, bool prefetch, int kb_next) {
+        const uint32_t bo = buf * STAGE;
+        u32x4 fa[4][TM], fb[4][TN];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[ks][j] = lds_read_b128<0>((b_frag[j] ^ (ks << 5)) + bo);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[ks][i] = lds_read_b128<0>((a_frag[i] ^ (ks << 5)) + bo);
+        }
+        constexpr int PIECES = AI + BI, PQ = (PIECES + 3) / 4;  // DMA pieces of the next step issued behind each MFMA group
+        auto wait_and_mma = [&](auto ks_c, auto left_c) {
+            constexpr int ks = decltype(ks_c)::value, left = decltype(left_c)::value;
+            // reads of sub-step ks have landed once at most `left` later reads are outstanding
+            if constexpr (TM == 2 && TN == 2)
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0]), "+v"(fb[ks][1]) : "n"(left));
+            else if constexpr (TM == 4 && TN == 2)
+                asm volatile("s_waitcnt lgkmcnt(%6)"
+                             : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fa[ks][2]), "+v"(fa[ks][3]), "+v"(fb[ks][0]), "+v"(fb[ks][1])
+                             : "n"(left));
+            else
+                static_assert(TM == 2 || TM == 4, "add a wait form for this wave tile");
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[ks][j]),
+                                                                        __builtin_bit_cast(bf16x8, fa[ks][i]), acc[j][i], 0, 0, 0);
+            // the other stage buffer is free since the barrier: its DMA pieces are issued in the shadow of these MFMAs
+            constexpr int first = ks * PQ, cnt = first >= PIECES ? 0 : (first + PQ > PIECES ? PIECES - first : PQ);
+            if (prefetch) issue_pieces(kb_next, buf ^ 1, std::integral_constant<int, first>{}, std::integral_constant<int, cnt>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int PER = TM + TN;
+        constexpr int L0 = 3 * PER > 15 ? 15 : 3 * PER;  // lgkmcnt is a 4-bit counter: saturate
+        constexpr int L1 = 2 * PER > 15 ? 15 : 2 * PER;
+        wait_and_mma(std::integral_constant<int, 0>{}, std::integral_constant<int, L0>{});
+        wait_and_mma(std::integral_constant<int, 1>{}, std::integral_constant<int, L1>{});
+        wait_and_mma(std::integral_constant<int, 2>{}, std::integral_constant<int, PER>{});
+        wait_and_mma(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+    };
+
+    // ---- epilogue of tile `id`.  A lane owns output row m = l31 of each 32-row block and 4 consecutive n per register group.
+    // Row-per-lane 8-byte global stores touch 32 cache lines per instruction and are issue-bound (16 of them per lane cost
+    // thousands of cycles), so each wave passes its [32 rows][64 columns] block through a private 4 KB LDS patch
+    // (16-byte chunk ^ (row & 7): the 8-byte writes are 2-way, the 16-byte reads conflict-free) and stores / loads WHOLE
+    // 128-byte row segments: 4 dwordx4 instructions per block, 8 rows each.  All patch accesses are inline asm: a
+    // compiler-visible LDS access beside the DMA queue would be preceded by s_waitcnt vmcnt(0) and stall the epilogue
+    // behind the next tile's first loads.  Needs n % 8 == 0; otherwise (the 12-class head) the direct 8-byte form is used.
+    const uint32_t patch = lds0 + 2 * STAGE + wave * 4096;
+    const uint32_t own_addr = patch + l31 * 128 + 8 * half;          // + ((chunk ^ (l31 & 7)) << 4), chunk = 4 j + g
+    const uint32_t row_addr = patch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + t * 1024: row lane/8 + 8 t
+    auto epilogue = [&](int id) {
+        const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+        const int64_t m0 = (int64_t)tm * BM;
+        const int n0 = tn * BN;
+        const int n2 = p.n * 2;
+        int64_t cbytes = (p.m - m0) * (int64_t)n2;
+        cbytes = cbytes > kMaxRecords ? kMaxRecords : cbytes;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.c + m0 * p.n), 0, (int)(p.c ? cbytes : 0), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.aux + m0 * p.n), 0, (int)(p.aux ? cbytes : 0), 0x00020000);
+        const ElemRng rng(p.drop_p, p.seed);
+        const bool dropping = (EPI == EPI_GELU || EPI == EPI_DGELU) && p.drop_p > 0.f;
+        const bool wide = TN == 2 && (p.n & 7) == 0;  // whole-row-segment path
+        const int ncol0 = n0 + wn * (BN / WN);         // first of this wave's 64 columns
+        float4 bias4[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = ncol0 + j * 32 + 4 * half + 8 * g;
+                bias4[j][g] = (EPI != EPI_DGELU && p.bias && n < p.n) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        // row-lane view of a block: lane -> (row lane/8 + 8 t, 16-byte chunk lane % 8)
+        const int rl_col = ncol0 + (lane & 7) * 8;
+        auto row_voff = [&](int i, int t) -> uint32_t {
+            const int r = wm * (BM / WM) + i * 32 + (lane >> 3) + 8 * t;
+            return rl_col < p.n ? (uint32_t)(r * n2 + rl_col * 2) : kOob;
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * (BM / WM) + i * 32 + l31;
+            // ---- input block (h or the residual) in the own-lane view
+            u32x2 xin[TN][4];
+            if (EPI == EPI_DGELU || EPI == EPI_RESID) {
+                if (wide) {
+                    u32x4 rws[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        rws[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, row_voff(i, t), 0, 0));
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(row_addr), "v"(rws[0]) : "memory");
+                    asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(row_addr), "v"(rws[1]) : "memory");
+                    asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(row_addr), "v"(rws[2]) : "memory");
+                    asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(row_addr), "v"(rws[3]) : "memory");
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            asm volatile("ds_read_b64 %0, %1" : "=v"(xin[j][g]) : "v"(own_addr + (((4 * j + g) ^ (l31 & 7)) << 4)));
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(xin[0][0]), "+v"(xin[0][1]), "+v"(xin[0][2]), "+v"(xin[0][3]), "+v"(xin[TN - 1][0]),
+                                   "+v"(xin[TN - 1][1]), "+v"(xin[TN - 1][2]), "+v"(xin[TN - 1][3]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = ncol0 + j * 32 + 4 * half + 8 * g;
+                            xin[j][g] = __builtin_amdgcn_raw_buffer_load_b64(rx, n < p.n ? (uint32_t)(ml * n2 + n * 2) : kOob, 0, 0);
+                        }
+                }
+            }
+            // ---- arithmetic on the accumulators
+            u32x2 o1[TN][4], o2[TN][4];  // o1 -> c ; o2 -> aux (EPI_GELU only)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = ncol0 + j * 32 + 4 * half + 8 * g;
+                    float v[4] = {acc[j][i][4 * g] + bias4[j][g].x, acc[j][i][4 * g + 1] + bias4[j][g].y,
+                                  acc[j][i][4 * g + 2] + bias4[j][g].z, acc[j][i][4 * g + 3] + bias4[j][g].w};
+                    const int64_t e0 = (m0 + ml) * p.n + n;  // element index of v[0] in the [m, n] tensor (dropout counter)
+                    if (EPI == EPI_GELU) {
+                        o1[j][g] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            v[t] = gelu_f(v[t]);
+                            if (dropping) v[t] *= rng.mult(e0 + t);
+                        }
+                        o2[j][g] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    } else {
+                        if (EPI == EPI_DGELU || EPI == EPI_RESID) {
+                            const float x[4] = {__uint_as_float(xin[j][g][0] << 16), __uint_as_float(xin[j][g][0] & 0xffff0000u),
+                                                __uint_as_float(xin[j][g][1] << 16), __uint_as_float(xin[j][g][1] & 0xffff0000u)};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                if (EPI == EPI_DGELU) {
+                                    v[t] *= gelu_grad_f(x[t]);
+                                    if (dropping) v[t] *= rng.mult(e0 + t);
+                                } else {
+                                    v[t] += x[t];
+                                }
+                            }
+                        }
+                        o1[j][g] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][i][4 * g + r] = 0.f;
+                }
+            // ---- outputs
+            auto emit = [&](const __amdgpu_buffer_rsrc_t& rs, const u32x2 (&o)[TN][4]) {
+                if (wide) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(own_addr + (((4 * j + g) ^ (l31 & 7)) << 4)), "v"(o[j][g]) : "memory");
+                    u32x4 rws[4];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(rws[0]) : "v"(row_addr));
+                    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(rws[1]) : "v"(row_addr));
+                    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(rws[2]) : "v"(row_addr));
+                    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(rws[3]) : "v"(row_addr));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rws[0]), "+v"(rws[1]), "+v"(rws[2]), "+v"(rws[3]));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rws[t]), rs, row_voff(i, t), 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = ncol0 + j * 32 + 4 * half + 8 * g;
+                            __builtin_amdgcn_raw_buffer_store_b64(o[j][g], rs, n < p.n ? (uint32_t)(ml * n2 + n * 2) : kOob, 0, 0);
+                        }
+                }
+            };
+            if (EPI == EPI_GELU) {
+                if (p.c) emit(rc, o1);
+                emit(rx, o2);
+            } else {
+                emit(rc, o1);
+            }
+        }
+    };
+
+    // ---- the stream of k-steps over this workgroup's tiles; the issue cursor runs one step ahead of the compute cursor
+    const int stride = p.blocks_per_xcd;
+    int id_i = id0, ks_i = 0;  // next step to issue
+    int id_c = id0, ks_c = 0;  // step being computed
+    auto advance_issue = [&]() {
+        ++ks_i;
+        if (ks_i == nk) {
+            ks_i = 0;
+            id_i += stride;
+            if (id_i < id_end) retarget(id_i, nk1 == 0);
+        } else if (ks_i == nk1) {
+            retarget(id_i, true);
+        }
+    };
+    retarget(id_i, false);
+    issue_pieces(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, AI + BI>{});
+    advance_issue();
+    int buf = 0;
+    while (true) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the current step have landed
+        __builtin_amdgcn_s_barrier();                      // ... everyone's have; and everyone is done reading the other buffer
+        const bool more = id_i < id_end;
+        compute(buf, more, (ks_i >= nk1 ? ks_i - nk1 : ks_i) * 128);
+        if (more) advance_issue();
+        buf ^= 1;
+        if (++ks_c == nk) {
+            epilogue(id_c);
+            ks_c = 0;
+            id_c += stride;
+            if (id_c >= id_end) break;
+        }
+    }
+#endif
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
+    const int tiles_m = (int)((p.m + BM - 1) / BM);
+    p.tiles_n = (p.n + BN - 1) / BN;
+    const int64_t tiles = (int64_t)tiles_m * p.tiles_n;
+    if (tiles > 0x7fffffff) return fail(HS_ERR_UNSUPPORTED, "too many output tiles");
+    p.tiles = (int)tiles;
+    p.per_xcd = (p.tiles + 7) / 8;
+    const int resident = 32 * wgs_per_cu;  // workgroups per XCD in one resident round (32 CUs per XCD)
+    p.blocks_per_xcd = p.per_xcd < resident ? p.per_xcd : resident;
+    const dim3 grid((unsigned)(8 * p.blocks_per_xcd)), block(WM * WN * 64);
+    switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_BIAS>), grid, block, 0, s, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_GELU>), grid, block, 0, s, p); break;
+        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_DGELU>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_RESID>), grid, block, 0, s, p); break;
+    }
+    HS_LAUNCH_CHECK("gemm_nt");
+    return HS_OK;
+}
+
+}  // namespace
+}  // namespace hs
+
+namespace {
+int g_tile_variant = getenv("HS_GEMM_TILE") ? atoi(getenv("HS_GEMM_TILE")) : 0;  // A/B runs: 1 = 128x128, 2 = 256x128; 0 = heuristic
+}
+
+extern "C" {
+
+int hs_gemm_nt_set_tile(int variant) {
+    g_tile_variant = variant;
+    return HS_OK;
+}
+
+int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, const void* a2, int64_t lda2, const void* b2,
+               int64_t ldb2, int k2, const float* bias, void* c, void* aux, int64_t m, int n, int epilogue, float drop_p,
+               uint64_t seed, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(dtype == HS_BF16, "hs_gemm_nt: bf16 activations only (fp32 runs use the library GEMM)");
+    HS_CHECK_ARG(a && b && m > 0 && n > 0 && k > 0, "hs_gemm_nt: null operand or empty shape");
+    HS_CHECK_ARG(epilogue >= EPI_BIAS && epilogue <= EPI_RESID, "hs_gemm_nt: unknown epilogue %d", epilogue);
+    HS_CHECK_ARG(k2 == 0 || (a2 && b2 && k2 > 0), "hs_gemm_nt: second segment needs a2, b2, k2 > 0");
+    HS_CHECK_ARG(c || (epilogue == EPI_GELU && aux), "hs_gemm_nt: no output");
+    HS_CHECK_ARG(epilogue == EPI_BIAS || aux, "hs_gemm_nt: this epilogue needs aux");
+    HS_CHECK_ARG(drop_p >= 0.f && drop_p <= 1.f, "hs_gemm_nt: drop_p must be in [0, 1]");
+    // 16-byte operand chunks and 8-byte output groups
+    if (k % 8 || k2 % 8 || lda % 8 || ldb % 8 || (k2 && (lda2 % 8 || ldb2 % 8)) || n % 4)
+        return fail(HS_ERR_UNSUPPORTED, "hs_gemm_nt: k, k2 and the row strides must be multiples of 8, n a multiple of 4");
+    if (lda * 2 * 256 > kMaxRecords || ldb * 2 * 256 > kMaxRecords || (int64_t)n * 2 * 256 > kMaxRecords)
+        return fail(HS_ERR_UNSUPPORTED, "hs_gemm_nt: row stride too large");
+    GemmParams p{};
+    p.a = (const uint16_t*)a; p.b = (const uint16_t*)b; p.lda = lda; p.ldb = ldb; p.k = k;
+    p.a2 = (const uint16_t*)a2; p.b2 = (const uint16_t*)b2; p.lda2 = lda2; p.ldb2 = ldb2; p.k2 = k2;
+    p.bias = bias; p.c = (uint16_t*)c; p.aux = (uint16_t*)aux; p.m = m; p.n = n;
+    p.drop_p = drop_p; p.seed = seed;
+    const int variant = g_tile_variant ? g_tile_variant : 1;
+    if (variant == 2) return launch_tile<256, 128, 4, 2>(p, epilogue, 1, (hipStream_t)stream);
+    return launch_tile<128, 128, 2, 2>(p, epilogue, 2, (hipStream_t)stream);
+}
+
+}  // extern "C"

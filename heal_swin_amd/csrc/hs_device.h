@@ -51,7 +51,7 @@ struct ElemRng {
     float keep_scale;
     __device__ __forceinline__ ElemRng(float p, uint64_t seed) {
         key_lo = (uint32_t)seed;
-        key_hi = (uint32_t)(seed >> 32);
+        key_hi = mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu);  // pre-mixed once per thread
         thresh16 = p >= 1.f ? 65536u : (uint32_t)(p * 65536.f);  // drop probability in steps of 2^-16
         keep_scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
     }
@@ -59,9 +59,10 @@ struct ElemRng {
     // process 4 or 8 consecutive elements per lane, so half of the hashes are shared.
     __device__ __forceinline__ float mult(int64_t i) const {
         const uint64_t j = (uint64_t)i >> 1;
-        // keyed, two full rounds: the low counter word is mixed with key_lo BEFORE the high word / key_hi enter, so masks of
-        // different seeds are unrelated sequences (a single round over j ^ key made them XOR-translates of one sequence)
-        const uint32_t h = mix32(mix32((uint32_t)j + key_lo) ^ ((uint32_t)(j >> 32) * 0x9E3779B9u + key_hi));
+        // keyed, two full rounds with one key word entering BETWEEN them: masks of different seeds are then related by a
+        // pseudo-random index map, not by an index translation (j + key) or XOR-translation (j ^ key) as with a single
+        // keyed round
+        const uint32_t h = mix32(mix32((uint32_t)j ^ key_hi ^ ((uint32_t)(j >> 32) * 0x9E3779B9u)) ^ key_lo);
         const uint32_t bits = (i & 1) ? (h >> 16) : (h & 0xffffu);
         return bits >= thresh16 ? keep_scale : 0.f;
     }

@@ -54,8 +54,9 @@ struct DropRng {
     // row = ((b * nH + h) * N + shifted_row): one per (image, head, query)
     __device__ __forceinline__ DropRng(const AttnParams& p, int64_t row) {
         const uint64_t base = (uint64_t)row * 256u;  // up to 256 keys per window
-        // keyed with both seed words through two rounds (once per row): rows of different seeds get unrelated key streams
-        row_key = hash32(hash32((uint32_t)base + p.seed_lo) ^ ((uint32_t)(base >> 32) * 0x9E3779B9u + p.seed_hi));
+        // keyed with both seed words, one of them entering between the two rounds (once per row): rows of different seeds
+        // get unrelated key streams (no row translation between seeds)
+        row_key = hash32(hash32((uint32_t)base ^ hash32(p.seed_hi + (uint32_t)(base >> 32) * 0x9E3779B9u)) ^ p.seed_lo);
         const float pd = p.drop_p;
         thresh16 = pd >= 1.f ? 65536u : (uint32_t)(pd * 65536.f);  // drop probability in steps of 2^-16
         keep_scale = pd >= 1.f ? 0.f : 1.f / (1.f - pd);

@@ -269,6 +269,33 @@ int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in);
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace,
                     int64_t rows, int n_out, int k_in, int accumulate, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Forward and input-gradient product of the path's Linear layers with the elementwise step behind it fused into the
+ * epilogue (bf16 activations; replaces `F.linear` + `nn.GELU` + `nn.Dropout` at models_torch/swin_hp_transformer.py:38-44
+ * (Mlp.forward), :136/:172 (qkv, proj), :392 (PatchMerging.reduction), :425/:447 (expand), :772-775 (skip concat + Linear),
+ * :785-788 (1x1 head) and their autograd input gradients):
+ *     acc[m, n] = sum_k a[m, k] * b[n, k]   (+ sum_k a2[m, k] * b2[n, k]   when k2 > 0)
+ *   a  [dev] bf16, row m at a + m*lda (k valid elements); b [dev] bf16 [n rows], row n at b + n*ldb: a weight exactly as
+ *   nn.Linear stores it ([out, in]); for an input gradient pass the transposed bf16 copy of the weight.  The second segment
+ *   contracts a second operand pair into the same accumulator: cat([x, skip], -1) @ W^T without the concatenation
+ *   (b = W, b2 = W + k, ldb = ldb2 = k + k2).  bias [dev] f32[n] or NULL.  c, aux [dev] bf16 [m, n] contiguous.
+ *   epilogue HS_EPI_BIAS : c = acc + bias
+ *            HS_EPI_GELU : c = h = acc + bias (skipped when c == NULL), aux = dropout(gelu_erf(h), drop_p, seed) [written]
+ *            HS_EPI_DGELU: c = acc * dropout_mask * gelu_erf'(aux)          (aux = the saved h [read]; bias ignored)
+ *            HS_EPI_RESID: c = acc + bias + aux                              (aux = a residual term [read])
+ *   The dropout mask is the one hs_gelu_fwd/bwd draw for the same (seed, element index m*n_cols + n).
+ *   k, k2, lda, ldb multiples of 8; n a multiple of 4; dtype must be HS_BF16 (fp32 runs keep the library GEMM).
+ * hs_gemm_nt_set_tile: measurement hook (0 = built-in choice, 1 = 128x128 tiles, 2 = 256x128 tiles).
+ * ---------------------------------------------------------------------------------------------- */
+#define HS_EPI_BIAS 0
+#define HS_EPI_GELU 1
+#define HS_EPI_DGELU 2
+#define HS_EPI_RESID 3
+int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, const void* a2, int64_t lda2, const void* b2,
+               int64_t ldb2, int k2, const float* bias, void* c, void* aux, int64_t m, int n, int epilogue, float drop_p,
+               uint64_t seed, int dtype, void* stream);
+int hs_gemm_nt_set_tile(int variant);
+
 #ifdef __cplusplus
 }
 #endif

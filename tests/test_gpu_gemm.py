@@ -1,0 +1,107 @@
+"""hs_gemm_nt (bf16 NT GEMM with fused epilogues) through the C ABI vs fp32 torch on the same bf16-rounded operands:
+every epilogue, ragged M / N / K (tile tails, K not a multiple of the 64-deep step), the two-segment (skip-concat) form,
+both tile shapes, and the dropout mask against the standalone GELU kernel's."""
+import pytest
+import torch
+
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gemm(a, b, bias=None, epi=0, aux=None, a2=None, b2=None, want_c=True, p=0.0, seed=0):
+    from heal_swin_amd import _lib
+    from heal_swin_amd._lib import check, lib, ptr, stream_ptr
+    m, k = a.shape
+    n = b.shape[0]
+    c = torch.empty((m, n), dtype=torch.bfloat16, device=a.device) if want_c else None
+    if epi == _lib.HS_EPI_GELU:
+        aux = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    k2 = 0 if a2 is None else a2.shape[1]
+    check(lib.hs_gemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), k, ptr(a2), 0 if a2 is None else a2.stride(0), ptr(b2),
+                         0 if b2 is None else b2.stride(0), k2, ptr(bias), ptr(c), ptr(aux), m, n, epi, p, seed, _lib.HS_BF16,
+                         stream_ptr(a.device)), "hs_gemm_nt")
+    return c, aux
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x)
+
+
+def _dgelu(x):
+    return 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (300, 132, 96), (1000, 384, 200), (129, 12, 128), (4096, 512, 2048), (77, 260, 8)])
+def test_gemm_nt_epilogues_match_fp32(m, n, k, tile):
+    from heal_swin_amd import _lib
+    _lib.lib.hs_gemm_nt_set_tile(tile)
+    try:
+        g = torch.Generator().manual_seed(m + n + k)
+        a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+        b = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16).to(DEV)
+        bias = torch.randn(n, generator=g).to(DEV)
+        ref = a.float() @ b.float().t()
+        c, _ = _gemm(a, b)
+        assert_close(c, ref, 6e-3, "plain")
+        c, _ = _gemm(a, b, bias)
+        assert_close(c, ref + bias, 6e-3, "bias")
+        h, act = _gemm(a, b, bias, epi=_lib.HS_EPI_GELU)
+        assert_close(h, ref + bias, 6e-3, "gelu: h")
+        assert_close(act, _gelu(ref + bias), 6e-3, "gelu: act")
+        _, act2 = _gemm(a, b, bias, epi=_lib.HS_EPI_GELU, want_c=False)
+        assert torch.equal(act, act2)
+        hsaved = (ref + bias).to(torch.bfloat16)
+        d, _ = _gemm(a, b, None, epi=_lib.HS_EPI_DGELU, aux=hsaved)
+        assert_close(d, ref * _dgelu(hsaved.float()), 8e-3, "dgelu")
+        res = torch.randn(m, n, generator=g).to(torch.bfloat16).to(DEV)
+        r, _ = _gemm(a, b, bias, epi=_lib.HS_EPI_RESID, aux=res)
+        assert_close(r, ref + bias + res.float(), 6e-3, "resid")
+    finally:
+        _lib.lib.hs_gemm_nt_set_tile(0)
+
+
+@pytest.mark.parametrize("m,n,k1,k2", [(500, 96, 96, 96), (1024, 256, 256, 256), (130, 64, 40, 72)])
+def test_gemm_nt_two_segments_equal_the_concatenated_product(m, n, k1, k2):
+    g = torch.Generator().manual_seed(k1 * 7 + k2)
+    x = torch.randn(m, k1, generator=g).to(torch.bfloat16).to(DEV)
+    skip = torch.randn(m, k2, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(n, k1 + k2, generator=g) * (k1 + k2) ** -0.5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    ref = torch.cat([x, skip], 1).float() @ w.float().t() + bias
+    c, _ = _gemm(x, w[:, :k1], bias, a2=skip, b2=w[:, k1:])
+    assert_close(c, ref, 6e-3, "two segments")
+
+
+def test_gemm_nt_dropout_mask_equals_the_gelu_kernels():
+    """Same (seed, element index) -> same keep decision as hs_gelu_fwd, so a model may mix fused and unfused MLPs, and the
+    backward epilogue regenerates the forward's mask."""
+    from heal_swin_amd import _lib, ops
+    m, n, k, p, seed = 512, 384, 128, 0.3, 123456789012345
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(n, k, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    bias = torch.full((n,), 3.0, device=DEV)  # pre-activations well away from 0: every surviving gelu(h) is non-zero
+    h, act = _gemm(a, b, bias, epi=_lib.HS_EPI_GELU, p=p, seed=seed)
+    plain = ops.GeluDropoutFn.apply(h, p, seed)
+    assert torch.equal(act == 0, plain == 0)
+    assert abs(float((act != 0).float().mean()) - (1 - p)) < 5e-3
+    keep = (act != 0)
+    assert_close(act[keep], plain[keep], 1e-2, "survivors")
+    da = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)  # reuse shapes: d = (da b^T) * mask/(1-p) * gelu'(h)
+    d, _ = _gemm(da, b, None, epi=_lib.HS_EPI_DGELU, aux=h, p=p, seed=seed)
+    assert torch.equal(d == 0, act == 0)
+    ref = (da.float() @ b.float().t()) * _dgelu(h.float()) / (1 - p)
+    assert_close(d[keep], ref[keep], 1e-2, "dgelu survivors")
+
+
+def test_gemm_nt_rejects_unsupported_arguments():
+    from heal_swin_amd import _lib
+    a = torch.zeros(64, 12, dtype=torch.bfloat16, device=DEV)
+    b = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        _gemm(a, b)
+    with pytest.raises(AssertionError, match="needs aux"):
+        _gemm(a[:, :8].contiguous(), b[:, :8].contiguous(), epi=_lib.HS_EPI_RESID)

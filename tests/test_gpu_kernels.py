@@ -32,6 +32,10 @@ WA_CASES = [f"{a}_{m}" for a in ("scaled", "cos") for m in ("nomask", "rollmask"
 # kernel arithmetic itself is held to the tight bound against the oracle on identically rounded inputs
 # (test_attn_core_vs_oracle), and default-initialised cosine attention (x10) meets 1e-2 (test_gpu_model).
 def _bf16_slack(name, dtype):
+    """STRESS case, not the north_star bound: the cosine goldens pin one head's logit_scale at the x100 clamp (ref :144-146),
+    which turns bf16's 2^-9 rounding of q, k into O(0.4) logit noise; bf16 is bounded at 6e-2 here, the kernel arithmetic at
+    the tight bound in test_attn_core_vs_oracle (identically rounded inputs) and the 1e-2 logit bound on default-initialised
+    models in tests/test_gpu_baseline_configs.py."""
     return 6.0 if (dtype == torch.bfloat16 and name.startswith("cos")) else 1.0
 
 

@@ -25,7 +25,7 @@ def _check_depth(dev):
         loss = fn(pred, tgt)
         assert abs(float(loss) - float(z[f"depth/{tag}/loss"])) < 1e-6, tag
         loss.backward()
-        assert np.abs(pred.grad.cpu().numpy() - z[f"depth/{tag}/dpred"]).max() < 1e-7, tag
+        assert np.abs(pred.grad.cpu().numpy() - z[f"depth/{tag}/dpred"]).max() < 2.5e-7, tag  # GPU exp: 1 ulp of the fp32 gradient
     d = torch.from_numpy(z["depth/standardize/in"]).to(dev)
     assert np.allclose(L.depth_standardize(d).cpu().numpy(), z["depth/standardize/out"], rtol=1e-6, atol=1e-6)
     assert np.allclose(L.depth_unstandardize(L.depth_standardize(d)).cpu().numpy(), z["depth/standardize/back"], rtol=1e-6, atol=1e-5)
