@@ -93,17 +93,19 @@ class Mlp(nn.Module):
 
     def forward(self, x, apply_out_drop=True, residual_alias=False):
         """residual_alias: also return an alias of x whose gradient is folded into fc1's input-gradient GEMM."""
-        x_res = None
-        if residual_alias:
-            h, x_res = self.fc1.forward_passthrough(x)
+        exact_gelu = isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none"
+        if exact_gelu and x.dtype in (torch.bfloat16, torch.float32) and x.is_cuda:
+            # one autograd node: GELU (+ hidden dropout) ride on the GEMM epilogues, masks regenerated in backward (ops.MlpFn)
+            out = ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                          drop_p=self.drop.p if self.training else 0.0, passthrough=residual_alias)
+            y, x_res = out if residual_alias else (out, None)
         else:
-            h = self.fc1(x)
-        if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
-            # activation and the dropout behind it in one HIP pass (mask regenerated in backward)
-            a = ops.gelu_dropout(h, self.drop.p if self.training else 0.0)
-        else:
-            a = self.drop(self.act(h))
-        y = self.fc2(a)
+            x_res = None
+            if residual_alias:
+                h, x_res = self.fc1.forward_passthrough(x)
+            else:
+                h = self.fc1(x)
+            y = self.fc2(self.drop(self.act(h)))
         y = self.drop(y) if apply_out_drop else y  # the caller fuses the output dropout into the next norm kernel
         return (y, x_res) if residual_alias else y
 

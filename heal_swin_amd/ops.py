@@ -3,6 +3,8 @@
 PyTorch owns the memory (caching allocator), the stream and the autograd graph; every arithmetic step
 below runs in the HIP library.  All ops require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -429,6 +431,7 @@ class ParamCastCache:
         self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.versions = None
+        self.transposed = {}  # index -> (transposed shadow, the `versions` list object it was made from)
 
     def invalidate(self):
         self.versions = None
@@ -444,6 +447,19 @@ class ParamCastCache:
         i = self.index.get(id(p)) if dtype == self.dtype else None
         return None if i is None else self.shadows[i]
 
+    def get_t(self, p, dtype):
+        """[in, out] (transposed) activation-dtype copy of a 2-D weight: the B operand of its input-gradient product in
+        `hs_gemm_nt`.  Made on first use and re-made after every refresh that found changed parameters."""
+        i = self.index.get(id(p)) if dtype == self.dtype else None
+        if i is None:
+            return None
+        ent = self.transposed.get(i)
+        if ent is None or ent[1] is not self.versions:
+            t = self.shadows[i].t().contiguous() if ent is None else ent[0].copy_(self.shadows[i].t())
+            ent = (t, self.versions)
+            self.transposed[i] = ent
+        return ent[0]
+
 
 CAST_CACHE = None  # a refreshed ParamCastCache while a model forward is running (set by SwinHPTransformerSys.forward)
 
@@ -453,6 +469,98 @@ def _cast_param(p, dtype):
         return p
     c = CAST_CACHE.get(p, dtype) if CAST_CACHE is not None else None
     return p.to(dtype) if c is None else c
+
+
+# ----------------------------------------------------------------------------- hs_gemm_nt (own bf16 GEMM with fused epilogues)
+OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice below; "0": library GEMMs only; "1": own kernel wherever legal
+
+
+def own_gemm_ok(epi, n, k, dtype, k2=0):
+    """Whether `hs_gemm_nt` should run this product (else the library GEMM + the standalone elementwise kernel).
+    Measured on MI355X against hipBLASLt on the B / nside 256 / batch 8 shapes (tools/bench_gemm_nt.py,
+    profiles/r02_gemm_nt_vs_library.json): the own kernel wins where the product is HBM-bound (short reductions, narrow
+    outputs: stages 0-1) and wherever a GELU pass disappears into the epilogue with K <= 512; hipBLASLt's 256-wide tiles win
+    the MFMA-bound stage-2/3 shapes."""
+    if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 32:
+        return False  # (n % 8: whole-row-segment stores; narrower outputs such as the 12-class head stay with the library)
+    if OWN_GEMM == "1":
+        return True
+    kk = k + k2
+    if epi == _lib.HS_EPI_DGELU:
+        return kk <= 512
+    if epi == _lib.HS_EPI_GELU:
+        return kk <= 128
+    return (kk <= 128 and n <= 384) or n <= 128
+
+
+def gemm_nt(a2d, w, bias=None, epi=0, aux=None, a2=None, w2=None, want_c=True, drop_p=0.0, seed=0):
+    """c = epilogue(a2d @ w^T (+ a2 @ w2^T) + bias) through `hs_gemm_nt`; returns (c, aux).  a2d [m, k] bf16 (row stride free),
+    w [n, k] bf16 (row stride free), bias fp32 [n] or None."""
+    m, k = a2d.shape
+    n = w.shape[0]
+    assert a2d.stride(1) == 1 and w.stride(1) == 1 and a2d.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    c = torch.empty((m, n), dtype=torch.bfloat16, device=a2d.device) if want_c else None
+    if epi == _lib.HS_EPI_GELU:
+        aux = torch.empty((m, n), dtype=torch.bfloat16, device=a2d.device)
+    k2 = 0 if a2 is None else a2.shape[1]
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    with _timed("gemm_nt", a2d.device, 2 * (m * (k + k2) + n * (k + k2) + m * n * (2 if (epi and want_c) else 1)), 2 * m * n * (k + k2)):
+        check(lib.hs_gemm_nt(ptr(a2d), a2d.stride(0), ptr(w), w.stride(0), k, ptr(a2), 0 if a2 is None else a2.stride(0), ptr(w2),
+                             0 if w2 is None else w2.stride(0), k2, ptr(bias), ptr(c), ptr(aux), m, n, epi, float(drop_p), int(seed),
+                             _lib.HS_BF16, stream_ptr(a2d.device)), "hs_gemm_nt")
+    return c, aux
+
+
+def _cast_param_t(p, dtype):
+    """[in, out] copy of weight p ([out, in, ...]) in `dtype` for the input-gradient product."""
+    c = CAST_CACHE.get_t(p, dtype) if (CAST_CACHE is not None and p.dim() == 2) else None
+    if c is None:
+        n_out = p.shape[0]
+        c = p.detach().to(dtype).view(n_out, -1).t().contiguous()
+    return c
+
+
+def _param_grads(dy2, x2, weight, bias, want_w, want_b):
+    """Weight / bias gradient of y = x W^T + b from dy2 [rows, n_out], x2 [rows, k_in]: deposited straight into the gradient
+    sink's buffers when one knows the parameters (returns (None, None)), else returned in the parameters' dtype."""
+    n_out = weight.shape[0]
+    k_in = weight.numel() // n_out
+    if not (want_w or want_b):
+        return None, None
+    hip_ok = (x2.is_contiguous() and dy2.is_contiguous() and n_out % 4 == 0 and
+              ((x2.dtype == torch.bfloat16 and k_in % 8 == 0) or (x2.dtype == torch.float32 and k_in % 4 == 0)))
+    wbuf = _sink_buffer(weight) if (hip_ok and want_w) else None
+    bbuf = _sink_buffer(bias) if (wbuf is not None and want_b) else None
+    if wbuf is not None and (not want_b or bbuf is not None):
+        # accumulate dW (and db) straight into the sink's gradient buffers (no autograd AccumulateGrad kernels, no dtype
+        # round trip); optionally on the side stream
+        aw = ASYNC_WGRAD
+        wbuf = wbuf.view(n_out, k_in)
+        if aw is not None:
+            cur = torch.cuda.current_stream(x2.device)
+            aw.stream.wait_stream(cur)
+            dy2.record_stream(aw.stream)
+            x2.record_stream(aw.stream)
+            with torch.cuda.stream(aw.stream):
+                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
+        else:
+            LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
+        GRAD_SINK.deposited(weight)
+        if want_b:
+            GRAD_SINK.deposited(bias)
+        return None, None
+    dw = db = None
+    if hip_ok:
+        dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b)
+        dw = dw32.to(weight.dtype).view(weight.shape) if want_w else None
+        db = db32.to(bias.dtype) if want_b else None
+    else:  # odd widths: library GEMM
+        if want_w:
+            dw = (dy2.t() @ x2).to(weight.dtype).view(weight.shape)
+        if want_b:
+            db = dy2.sum(0).to(bias.dtype)
+    return dw, db
 
 
 class LinearFn(torch.autograd.Function):
@@ -467,12 +575,14 @@ class LinearFn(torch.autograd.Function):
         n_out = weight.shape[0]
         k_in = weight.numel() // n_out
         w = _cast_param(weight, x.dtype).view(n_out, k_in)
-        b = None if bias is None else _cast_param(bias, x.dtype)
         ctx.save_for_backward(x, weight)
         ctx.bias_param = bias
         ctx.w_cast = w if w.dtype != weight.dtype else None  # activation-dtype copy, reused by the input-gradient GEMM
         ctx.passthrough = passthrough
-        y = torch.nn.functional.linear(x, w, b)
+        if own_gemm_ok(_lib.HS_EPI_BIAS, n_out, k_in, x.dtype) and x.is_contiguous():
+            y = gemm_nt(x.reshape(-1, k_in), w, bias)[0].view(x.shape[:-1] + (n_out,))  # fp32 master bias added in the epilogue
+        else:
+            y = torch.nn.functional.linear(x, w, None if bias is None else _cast_param(bias, x.dtype))
         # passthrough: also hand x back (an alias) for the block's residual connection.  The gradient of that second use then
         # arrives HERE together with dy, and the input-gradient GEMM adds it as its beta * C term instead of autograd
         # launching a separate add over the whole activation (v2 norm placement: x + LN(branch(x)), ref :334-335)
@@ -506,51 +616,27 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, k_in)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dx = dw = db = None
+        dx = None
         if ctx.needs_input_grad[0]:
-            w = ctx.w_cast if (ctx.w_cast is not None and ctx.w_cast.dtype == dy.dtype) else (
-                weight if weight.dtype == dy.dtype else weight.to(dy.dtype)).view(n_out, k_in)
-            if dx_res is not None:
-                dx = torch.addmm(dx_res.reshape(-1, k_in).to(dy2.dtype), dy2, w).reshape(x.shape)
-            else:
-                dx = (dy2 @ w).reshape(x.shape)
+            dx = _input_grad(dy2, weight, ctx.w_cast, None if dx_res is None else dx_res.reshape(-1, k_in)).reshape(x.shape)
         ctx.w_cast = None
-        want_w = ctx.needs_input_grad[1]
-        want_b = bias is not None and ctx.needs_input_grad[2]
-        if not (want_w or want_b):
-            return dx, None, None, None
-        hip_ok = (x2.is_contiguous() and n_out % 4 == 0 and
-                  ((x.dtype == torch.bfloat16 and k_in % 8 == 0) or (x.dtype == torch.float32 and k_in % 4 == 0)))
-        wbuf = _sink_buffer(weight) if (hip_ok and want_w) else None
-        bbuf = _sink_buffer(bias) if (wbuf is not None and want_b) else None
-        if wbuf is not None and (not want_b or bbuf is not None):
-            # accumulate dW (and db) straight into the sink's gradient buffers (no autograd AccumulateGrad kernels, no dtype
-            # round trip); optionally on the side stream
-            aw = ASYNC_WGRAD
-            wbuf = wbuf.view(n_out, k_in)
-            if aw is not None:
-                cur = torch.cuda.current_stream(x.device)
-                aw.stream.wait_stream(cur)
-                dy2.record_stream(aw.stream)
-                x2.record_stream(aw.stream)
-                with torch.cuda.stream(aw.stream):
-                    LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
-            else:
-                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
-            GRAD_SINK.deposited(weight)
-            if want_b:
-                GRAD_SINK.deposited(bias)
-            return dx, None, None, None
-        if hip_ok:
-            dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b)
-            dw = dw32.to(weight.dtype).view(weight.shape) if want_w else None
-            db = db32.to(bias.dtype) if want_b else None
-        else:  # odd widths: library GEMM
-            if want_w:
-                dw = (dy2.t() @ x2).to(weight.dtype).view(weight.shape)
-            if want_b:
-                db = dy2.sum(0).to(bias.dtype)
+        dw, db = _param_grads(dy2, x2, weight, bias, ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2])
         return dx, dw, db, None
+
+
+def _input_grad(dy2, weight, w_cast, dx_res2=None):
+    """dx = dy2 @ W (+ dx_res2): `hs_gemm_nt` on the transposed weight copy where that wins, else the library GEMM."""
+    n_out = weight.shape[0]
+    k_in = weight.numel() // n_out
+    epi = _lib.HS_EPI_BIAS if dx_res2 is None else _lib.HS_EPI_RESID
+    if own_gemm_ok(epi, k_in, n_out, dy2.dtype):
+        res = None if dx_res2 is None else dx_res2.to(dy2.dtype).contiguous()
+        return gemm_nt(dy2, _cast_param_t(weight, dy2.dtype), None, epi, aux=res)[0]
+    w = w_cast if (w_cast is not None and w_cast.dtype == dy2.dtype) else (
+        weight if weight.dtype == dy2.dtype else weight.to(dy2.dtype)).view(n_out, k_in)
+    if dx_res2 is not None:
+        return torch.addmm(dx_res2.to(dy2.dtype), dy2, w)
+    return dy2 @ w
 
 
 def linear(x, weight, bias=None):
@@ -560,6 +646,78 @@ def linear(x, weight, bias=None):
 def linear_passthrough(x, weight, bias=None):
     """(x W^T + b, alias of x): use the alias for a residual connection around the branch this Linear opens."""
     return LinearFn.apply(x, weight, bias, True)
+
+
+class MlpFn(torch.autograd.Function):
+    """fc1 -> GELU(erf) -> dropout -> fc2 (reference Mlp.forward, swin_hp_transformer.py:38-44, without the output dropout,
+    which the caller fuses into the next norm kernel) as ONE autograd node, so that the elementwise steps ride on the GEMMs
+    around them: forward `hs_gemm_nt(EPI_GELU)` writes the pre-activation h and dropout(gelu(h)) from one accumulator pass;
+    backward `hs_gemm_nt(EPI_DGELU)` turns dy W2 into dh = dy W2 * mask * gelu'(h) in its epilogue.  Where the library GEMM is
+    faster (own_gemm_ok) the standalone `hs_gelu_*` kernels are used instead; both forms draw the same dropout mask."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, drop_p, seed, passthrough):
+        _require_gpu(x, w1, b1, w2, b2)
+        c_in, hid = w1.shape[1], w1.shape[0]
+        x2 = x.reshape(-1, c_in)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        dt = x.dtype
+        w1c, w2c = _cast_param(w1, dt), _cast_param(w2, dt)
+        need_grad = any(ctx.needs_input_grad[:5])
+        if own_gemm_ok(_lib.HS_EPI_GELU, hid, c_in, dt):
+            h, a = gemm_nt(x2, w1c, b1, _lib.HS_EPI_GELU, want_c=need_grad, drop_p=drop_p, seed=seed)
+        else:
+            h = torch.nn.functional.linear(x2, w1c, None if b1 is None else _cast_param(b1, dt))
+            a = torch.empty_like(h)
+            check(lib.hs_gelu_fwd(ptr(h), ptr(a), h.numel(), float(drop_p), int(seed), _lib.dtype_code(dt), stream_ptr(h.device)),
+                  "hs_gelu_fwd")
+        if own_gemm_ok(_lib.HS_EPI_BIAS, w2.shape[0], hid, dt):
+            y = gemm_nt(a, w2c, b2)[0]
+        else:
+            y = torch.nn.functional.linear(a, w2c, None if b2 is None else _cast_param(b2, dt))
+        ctx.save_for_backward(x2, h, a, w1, w2)
+        ctx.biases = (b1, b2)
+        ctx.casts = (w1c if w1c.dtype != w1.dtype else None, w2c if w2c.dtype != w2.dtype else None)
+        ctx.meta = (float(drop_p), int(seed), x.shape)
+        y = y.view(x.shape[:-1] + (w2.shape[0],))
+        return (y, x.view_as(x)) if passthrough else y
+
+    @staticmethod
+    def backward(ctx, dy, dx_res=None):
+        x2, h, a, w1, w2 = ctx.saved_tensors
+        b1, b2 = ctx.biases
+        w1c, w2c = ctx.casts
+        p, seed, xshape = ctx.meta
+        if dy is None:  # only the passthrough alias was used downstream
+            return dx_res, None, None, None, None, None, None, None
+        c_out, hid, c_in = w2.shape[0], w1.shape[0], w1.shape[1]
+        dy2 = dy.reshape(-1, c_out)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dt = dy2.dtype
+        # dh = (dy W2) * mask * gelu'(h)
+        if own_gemm_ok(_lib.HS_EPI_DGELU, hid, c_out, dt):
+            dh = gemm_nt(dy2, _cast_param_t(w2, dt), None, _lib.HS_EPI_DGELU, aux=h, drop_p=p, seed=seed)[0]
+        else:
+            da = dy2 @ (w2c if (w2c is not None and w2c.dtype == dt) else w2.to(dt))
+            dh = torch.empty_like(h)
+            check(lib.hs_gelu_bwd(ptr(da), ptr(h), ptr(dh), h.numel(), p, seed, _lib.dtype_code(dt), stream_ptr(h.device)), "hs_gelu_bwd")
+            del da
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _input_grad(dh, w1, w1c, None if dx_res is None else dx_res.reshape(-1, c_in)).reshape(xshape)
+        ctx.casts = None
+        dw2, db2 = _param_grads(dy2, a, w2, b2, ctx.needs_input_grad[3], b2 is not None and ctx.needs_input_grad[4])
+        dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[1], b1 is not None and ctx.needs_input_grad[2])
+        return dx, dw1, db1, dw2, db2, None, None, None
+
+
+def mlp(x, w1, b1, w2, b2, drop_p=0.0, seed=None, passthrough=False):
+    """fc2(dropout(gelu(fc1(x)))) (+ an alias of x when passthrough, see LinearFn)."""
+    if drop_p > 0.0 and seed is None:
+        seed = _draw_seed()
+    return MlpFn.apply(x, w1, b1, w2, b2, float(drop_p), int(seed or 0), bool(passthrough))
 
 
 class ConcatLinearFn(torch.autograd.Function):
@@ -574,8 +732,11 @@ class ConcatLinearFn(torch.autograd.Function):
         w = _cast_param(weight, x.dtype)
         b = None if bias is None else _cast_param(bias, x.dtype)
         x2, s2 = x.reshape(-1, c), skip.reshape(-1, skip.shape[-1])
-        y = torch.addmm(b, x2, w[:, :c].t()) if b is not None else x2 @ w[:, :c].t()
-        y.addmm_(s2, w[:, c:].t())
+        if own_gemm_ok(_lib.HS_EPI_BIAS, weight.shape[0], c, x.dtype, k2=s2.shape[1]) and x2.is_contiguous() and s2.is_contiguous():
+            y = gemm_nt(x2, w[:, :c], bias, a2=s2, w2=w[:, c:])[0]  # both K segments into one accumulator
+        else:
+            y = torch.addmm(b, x2, w[:, :c].t()) if b is not None else x2 @ w[:, :c].t()
+            y.addmm_(s2, w[:, c:].t())
         ctx.save_for_backward(x, skip, weight)
         ctx.bias_param = bias
         ctx.w_cast = w if w is not weight else None
@@ -593,8 +754,13 @@ class ConcatLinearFn(torch.autograd.Function):
         x2, s2 = x.reshape(-1, c), skip.reshape(-1, cs)
         w = ctx.w_cast if (ctx.w_cast is not None and ctx.w_cast.dtype == dy.dtype) else _cast_param(weight, dy.dtype)
         ctx.w_cast = None
-        dx = (dy2 @ w[:, :c]).reshape(x.shape) if ctx.needs_input_grad[0] else None
-        dskip = (dy2 @ w[:, c:]).reshape(skip.shape) if ctx.needs_input_grad[1] else None
+        if own_gemm_ok(_lib.HS_EPI_BIAS, c, n_out, dy2.dtype) and own_gemm_ok(_lib.HS_EPI_BIAS, cs, n_out, dy2.dtype):
+            wt = _cast_param_t(weight, dy2.dtype)  # [c + cs, n_out]: the two row blocks are the B operands
+            dx = gemm_nt(dy2, wt[:c])[0].reshape(x.shape) if ctx.needs_input_grad[0] else None
+            dskip = gemm_nt(dy2, wt[c:])[0].reshape(skip.shape) if ctx.needs_input_grad[1] else None
+        else:
+            dx = (dy2 @ w[:, :c]).reshape(x.shape) if ctx.needs_input_grad[0] else None
+            dskip = (dy2 @ w[:, c:]).reshape(skip.shape) if ctx.needs_input_grad[1] else None
         want_w = ctx.needs_input_grad[2]
         want_b = bias is not None and ctx.needs_input_grad[3]
         if not (want_w or want_b):

@@ -105,3 +105,76 @@ def test_gemm_nt_rejects_unsupported_arguments():
         _gemm(a, b)
     with pytest.raises(AssertionError, match="needs aux"):
         _gemm(a[:, :8].contiguous(), b[:, :8].contiguous(), epi=_lib.HS_EPI_RESID)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("passthrough", [False, True])
+def test_mlp_node_own_and_library_paths_agree_with_fp32(p, passthrough):
+    """ops.MlpFn (fc1 -> GELU -> dropout -> fc2 as one autograd node) through `hs_gemm_nt` epilogues (HS_OWN_GEMM=1) and through
+    library GEMMs + standalone GELU kernels (=0): same dropout mask, outputs and all gradients within bf16 rounding of an
+    fp32 torch MLP that uses the recovered mask."""
+    from heal_swin_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, c, hid = 640, 96, 384
+    x = torch.randn(2, rows // 2, c, generator=g)
+    w1, b1 = torch.randn(hid, c, generator=g) * c ** -0.5, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(c, hid, generator=g) * hid ** -0.5, torch.randn(c, generator=g) * 0.1
+    dy = torch.randn(2, rows // 2, c, generator=g)
+    seed = 4242
+    out = {}
+    prev = ops.OWN_GEMM
+    try:
+        for mode in ("1", "0"):
+            ops.OWN_GEMM = mode
+            xs = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+            ps = [t.to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2)]
+            r = ops.mlp(xs, *ps, drop_p=p, seed=seed, passthrough=passthrough)
+            y = r[0] + r[1] if passthrough else r  # the alias carries the residual connection's gradient
+            y.backward(dy.to(DEV).to(torch.bfloat16))
+            out[mode] = (y.detach().float().cpu(), xs.grad.float().cpu(), [t.grad.float().cpu() for t in ps])
+    finally:
+        ops.OWN_GEMM = prev
+    # fp32 reference on the bf16-rounded input, with the mask recovered from a probe call (mask depends only on seed, index)
+    xr = x.to(torch.bfloat16).float().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    h = xr.reshape(-1, c) @ pr[0].t() + pr[1]
+    if p > 0:
+        probe = ops.GeluDropoutFn.apply(torch.full((rows, hid), 3.0, device=DEV), p, seed).cpu()
+        mask = (probe != 0).float() / (1 - p)
+    else:
+        mask = torch.ones(rows, hid)
+    yr = ((torch.nn.functional.gelu(h) * mask) @ pr[2].t() + pr[3]).view(2, rows // 2, c)
+    if passthrough:
+        yr = yr + xr
+    yr.backward(dy.to(torch.bfloat16).float())
+    for mode in ("1", "0"):
+        y, dx, grads = out[mode]
+        assert_close(y, yr, 1.5e-2, f"mlp[{mode}] y")
+        assert_close(dx, xr.grad, 2e-2, f"mlp[{mode}] dx")
+        for got, ref, nm in zip(grads, pr, ("w1", "b1", "w2", "b2")):
+            assert_close(got, ref.grad, 2e-2, f"mlp[{mode}] d{nm}")
+
+
+def test_linear_and_concat_linear_own_kernel_vs_library():
+    from heal_swin_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 200, 128, generator=g).to(torch.bfloat16)
+    skip = torch.randn(3, 200, 128, generator=g).to(torch.bfloat16)
+    w, b = torch.randn(128, 128, generator=g) * 0.1, torch.randn(128, generator=g) * 0.1
+    wc, bc = torch.randn(128, 256, generator=g) * 0.08, torch.randn(128, generator=g) * 0.1
+    dy = torch.randn(3, 200, 128, generator=g).to(torch.bfloat16)
+    res = {}
+    prev = ops.OWN_GEMM
+    try:
+        for mode in ("1", "0"):
+            ops.OWN_GEMM = mode
+            xs, ss = x.to(DEV).requires_grad_(True), skip.to(DEV).requires_grad_(True)
+            ps = [t.to(DEV).requires_grad_(True) for t in (w, b, wc, bc)]
+            y, alias = ops.linear_passthrough(xs, ps[0], ps[1])
+            z = ops.concat_linear(y + alias, ss, ps[2], ps[3])
+            z.backward(dy.to(DEV))
+            res[mode] = [z.detach().float().cpu(), xs.grad.float().cpu(), ss.grad.float().cpu()] + [t.grad.float().cpu() for t in ps]
+    finally:
+        ops.OWN_GEMM = prev
+    for a, bb, nm in zip(res["1"], res["0"], ("z", "dx", "dskip", "dw", "db", "dwc", "dbc")):
+        assert_close(a, bb, 2e-2, "own vs library " + nm)
