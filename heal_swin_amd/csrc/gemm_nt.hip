@@ -43,7 +43,7 @@ typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RESID = 3 };
-constexpr uint32_t kOob = 0x7FFFFF00u;      // a byte offset outside every descriptor below
+__device__ constexpr uint32_t kOob = 0x7FFFFF00u;  // a byte offset outside every descriptor below
 constexpr int64_t kMaxRecords = 0x7FFFFE00;  // descriptors are clamped to this many bytes (tiles address < 2 GiB from their origin)
 
 struct GemmParams {
@@ -70,7 +70,9 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// NSTAGE LDS stage buffers (the DMA runs NSTAGE - 1 k-steps ahead of the MFMAs); ALIAS: the epilogue's per-wave patches lie
+// inside the stage buffer that was just consumed (one extra barrier per tile) instead of in LDS of their own
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI>
 __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN;
@@ -78,7 +80,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     constexpr int AB = BM * 128, BB = BN * 128, STAGE = AB + BB;
     constexpr int AI = AB / 1024 / NW, BI = BB / 1024 / NW;  // 1-KB DMA instructions per wave and stage
     static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + NW * 4096];  // stages + one epilogue patch per wave
+    static_assert(!ALIAS || NW * 4096 <= STAGE, "patches do not fit a stage buffer");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096)];  // stages (+ epilogue patches)
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,48 +173,68 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-    // ---- one k-step out of stage buffer `buf`: two halves of two 16-deep MFMA sub-steps each; all fragment reads of the
-    // step are issued first (LDS returns in order), the second half's latency hides under the first half's MFMAs
-    auto compute = [&](int buf, bool prefetch, int kb_next) {
+    // ---- one k-step out of stage buffer `buf`: four 16-deep MFMA sub-steps, their fragment reads streamed ahead of them, and
+    // the DMA pieces of a later k-step (into stage buffer `buf_next`, free since the barrier) issued behind each MFMA group
+    auto compute = [&](int buf, bool prefetch, int kb_next, int buf_next) {
         const uint32_t bo = buf * STAGE;
-        u32x4 fa[4][TM], fb[4][TN];
+        // fragment reads are streamed one or two 16-deep sub-steps ahead of their MFMAs through a ring of NSET register sets
+        // (two for the 128 x 64 wave tile, whose 128 accumulator registers leave no room for a third)
+        constexpr int NSET = TM == 4 ? 2 : 3;
+        u32x4 fa[NSET][TM], fb[NSET][TN];
+        auto read_frags = [&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value, set = ks % NSET;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+            for (int j = 0; j < TN; ++j) fb[set][j] = lds_read_b128<0>((b_frag[j] ^ (ks << 5)) + bo);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[ks][j] = lds_read_b128<0>((b_frag[j] ^ (ks << 5)) + bo);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[ks][i] = lds_read_b128<0>((a_frag[i] ^ (ks << 5)) + bo);
-        }
-        constexpr int PIECES = AI + BI, PQ = (PIECES + 3) / 4;  // DMA pieces of the next step issued behind each MFMA group
-        auto wait_and_mma = [&](auto ks_c, auto left_c) {
-            constexpr int ks = decltype(ks_c)::value, left = decltype(left_c)::value;
-            // reads of sub-step ks have landed once at most `left` later reads are outstanding
+            for (int i = 0; i < TM; ++i) fa[set][i] = lds_read_b128<0>((a_frag[i] ^ (ks << 5)) + bo);
+        };
+        constexpr int PIECES = AI + BI;
+        constexpr int PER = TM + TN;
+        auto wait_frags = [&](auto ks_c, auto left_c) {
+            constexpr int ks = decltype(ks_c)::value, left = decltype(left_c)::value, set = ks % NSET;
+            (void)fa;  // (named outside the if-constexpr branches: clang otherwise refuses the implicit capture)
+            (void)fb;
+            // reads of sub-step ks have landed once at most `left` later reads are outstanding (LDS returns in order)
             if constexpr (TM == 2 && TN == 2)
-                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0]), "+v"(fb[ks][1]) : "n"(left));
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0]), "+v"(fb[set][1]) : "n"(left));
             else if constexpr (TM == 4 && TN == 2)
                 asm volatile("s_waitcnt lgkmcnt(%6)"
-                             : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fa[ks][2]), "+v"(fa[ks][3]), "+v"(fb[ks][0]), "+v"(fb[ks][1])
+                             : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1])
                              : "n"(left));
             else
                 static_assert(TM == 2 || TM == 4, "add a wait form for this wave tile");
+        };
+        // MFMAs of sub-step ks, then DMA pieces [first, first + cnt) of a later step in their shadow
+        auto mma = [&](auto ks_c, auto first_c, auto cnt_c) {
+            constexpr int ks = decltype(ks_c)::value, set = ks % NSET;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[ks][j]),
-                                                                        __builtin_bit_cast(bf16x8, fa[ks][i]), acc[j][i], 0, 0, 0);
-            // the other stage buffer is free since the barrier: its DMA pieces are issued in the shadow of these MFMAs
-            constexpr int first = ks * PQ, cnt = first >= PIECES ? 0 : (first + PQ > PIECES ? PIECES - first : PQ);
-            if (prefetch) issue_pieces(kb_next, buf ^ 1, std::integral_constant<int, first>{}, std::integral_constant<int, cnt>{});
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[set][j]),
+                                                                        __builtin_bit_cast(bf16x8, fa[set][i]), acc[j][i], 0, 0, 0);
+            if (decltype(cnt_c)::value > 0 && prefetch) issue_pieces(kb_next, buf_next, first_c, cnt_c);
             __builtin_amdgcn_sched_barrier(0);
         };
-        constexpr int PER = TM + TN;
-        constexpr int L0 = 3 * PER > 15 ? 15 : 3 * PER;  // lgkmcnt is a 4-bit counter: saturate
-        constexpr int L1 = 2 * PER > 15 ? 15 : 2 * PER;
-        wait_and_mma(std::integral_constant<int, 0>{}, std::integral_constant<int, L0>{});
-        wait_and_mma(std::integral_constant<int, 1>{}, std::integral_constant<int, L1>{});
-        wait_and_mma(std::integral_constant<int, 2>{}, std::integral_constant<int, PER>{});
-        wait_and_mma(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        using IPER = std::integral_constant<int, PER>;
+        read_frags(I0{});
+        read_frags(I1{});
+        constexpr int PQ = (PIECES + 3) / 4;  // a quarter of the next free buffer's pieces behind each MFMA group
+        constexpr int c3 = PIECES - 3 * PQ > 0 ? PIECES - 3 * PQ : 0;
+        wait_frags(I0{}, IPER{});
+        mma(I0{}, I0{}, std::integral_constant<int, PQ>{});
+        read_frags(I2{});
+        wait_frags(I1{}, IPER{});
+        mma(I1{}, std::integral_constant<int, PQ>{}, std::integral_constant<int, PQ>{});
+        read_frags(I3{});  // re-uses the set of a group whose MFMAs have all been issued
+        wait_frags(I2{}, IPER{});
+        mma(I2{}, std::integral_constant<int, 2 * PQ>{}, std::integral_constant<int, (3 * PQ <= PIECES ? PQ : PIECES - 2 * PQ)>{});
+        wait_frags(I3{}, I0{});
+        mma(I3{}, std::integral_constant<int, 3 * PQ>{}, std::integral_constant<int, c3>{});
     };
 
     // ---- epilogue of tile `id`.  A lane owns output row m = l31 of each 32-row block and 4 consecutive n per register group.
@@ -221,10 +244,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     // 128-byte row segments: 4 dwordx4 instructions per block, 8 rows each.  All patch accesses are inline asm: a
     // compiler-visible LDS access beside the DMA queue would be preceded by s_waitcnt vmcnt(0) and stall the epilogue
     // behind the next tile's first loads.  Needs n % 8 == 0; otherwise (the 12-class head) the direct 8-byte form is used.
-    const uint32_t patch = lds0 + 2 * STAGE + wave * 4096;
-    const uint32_t own_addr = patch + l31 * 128 + 8 * half;          // + ((chunk ^ (l31 & 7)) << 4), chunk = 4 j + g
-    const uint32_t row_addr = patch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + t * 1024: row lane/8 + 8 t
-    auto epilogue = [&](int id) {
+    const uint32_t own_rel = wave * 4096 + l31 * 128 + 8 * half;     // + ((chunk ^ (l31 & 7)) << 4), chunk = 4 j + g
+    const uint32_t row_rel = wave * 4096 + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + t * 1024: row lane/8 + 8 t
+    auto epilogue = [&](int id, int buf_done) {
+        const uint32_t patch0 = lds0 + (ALIAS ? buf_done * STAGE : NSTAGE * STAGE);
+        const uint32_t own_addr = patch0 + own_rel, row_addr = patch0 + row_rel;
+        if (ALIAS) __builtin_amdgcn_s_barrier();  // every wave is done reading the stage buffer the patches live in
         const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
         const int64_t m0 = (int64_t)tm * BM;
         const int n0 = tn * BN;
@@ -357,7 +382,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         }
     };
 
-    // ---- the stream of k-steps over this workgroup's tiles; the issue cursor runs one step ahead of the compute cursor
+    // ---- the stream of k-steps over this workgroup's tiles; the issue cursor runs NSTAGE - 1 steps ahead of the compute cursor
     const int stride = p.blocks_per_xcd;
     int id_i = id0, ks_i = 0;  // next step to issue
     int id_c = id0, ks_c = 0;  // step being computed
@@ -371,28 +396,53 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
             retarget(id_i, true);
         }
     };
+    auto kb_of = [&](int ks) { return (ks >= nk1 ? ks - nk1 : ks) * 128; };
     retarget(id_i, false);
-    issue_pieces(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, AI + BI>{});
-    advance_issue();
-    int buf = 0;
+    constexpr int AHEAD = NSTAGE - 1, PIECES_ALL = AI + BI;
+    int issued = 0;  // steps issued and not yet computed
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) {
+        if (id_i < id_end) {
+            issue_pieces(kb_of(ks_i), q, std::integral_constant<int, 0>{}, std::integral_constant<int, PIECES_ALL>{});
+            advance_issue();
+            ++issued;
+        }
+    }
+    int buf = 0, buf_free = AHEAD;  // buffer being computed; buffer the next issue goes to
+    bool drained = false;  // an epilogue's stores are in the queue: the counted wait below would be wrong
     while (true) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the current step have landed
-        __builtin_amdgcn_s_barrier();                      // ... everyone's have; and everyone is done reading the other buffer
+        // this wave's loads of the current step have landed: everything older than the steps still allowed in flight
+        if (AHEAD > 1 && issued == AHEAD && !drained)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PIECES_ALL) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        drained = false;
+        __builtin_amdgcn_s_barrier();  // ... everyone's have; and everyone is done reading the buffer that is re-filled next
         const bool more = id_i < id_end;
-        compute(buf, more, (ks_i >= nk1 ? ks_i - nk1 : ks_i) * 128);
-        if (more) advance_issue();
-        buf ^= 1;
-        if (++ks_c == nk) {
-            epilogue(id_c);
+        const bool last = ks_c + 1 == nk;
+        compute(buf, more, kb_of(ks_i), buf_free);
+        --issued;
+        if (more) {
+            advance_issue();
+            ++issued;
+        }
+        const int buf_done = buf;
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+        buf_free = buf_free + 1 == NSTAGE ? 0 : buf_free + 1;
+        if (last) {
+            epilogue(id_c, buf_done);
+            drained = true;
             ks_c = 0;
             id_c += stride;
             if (id_c >= id_end) break;
+        } else {
+            ++ks_c;
         }
     }
 #endif
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS>
 int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
     const int tiles_m = (int)((p.m + BM - 1) / BM);
     p.tiles_n = (p.n + BN - 1) / BN;
@@ -404,10 +454,10 @@ int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
     p.blocks_per_xcd = p.per_xcd < resident ? p.per_xcd : resident;
     const dim3 grid((unsigned)(8 * p.blocks_per_xcd)), block(WM * WN * 64);
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_BIAS>), grid, block, 0, s, p); break;
-        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_GELU>), grid, block, 0, s, p); break;
-        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_DGELU>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI_RESID>), grid, block, 0, s, p); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_BIAS>), grid, block, 0, s, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_GELU>), grid, block, 0, s, p); break;
+        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_DGELU>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_RESID>), grid, block, 0, s, p); break;
     }
     HS_LAUNCH_CHECK("gemm_nt");
     return HS_OK;
@@ -448,9 +498,30 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     p.a2 = (const uint16_t*)a2; p.b2 = (const uint16_t*)b2; p.lda2 = lda2; p.ldb2 = ldb2; p.k2 = k2;
     p.bias = bias; p.c = (uint16_t*)c; p.aux = (uint16_t*)aux; p.m = m; p.n = n;
     p.drop_p = drop_p; p.seed = seed;
-    const int variant = g_tile_variant ? g_tile_variant : 1;
-    if (variant == 2) return launch_tile<256, 128, 4, 2>(p, epilogue, 1, (hipStream_t)stream);
-    return launch_tile<128, 128, 2, 2>(p, epilogue, 2, (hipStream_t)stream);
+    // tile variants (hs_gemm_nt_set_tile): 1 = 128x128, 2 stages, own patches, two workgroups per CU (the default: wins the
+    // HBM-bound shapes, epilogue VALU of one workgroup under the other's MFMAs); 2 = 256x128 x 3 stages; 3 = 256x256 x 2 stages
+    // (one 8-wave workgroup per CU, patches inside the consumed stage buffer)
+    // Tile variants: 1 = 128x128 x 2 stages, own epilogue patches, two 4-wave workgroups per CU; 2 = 256x128 x 3 stages and
+    // 3 = 256x256 x 2 stages: one 8-wave workgroup per CU, patches inside the consumed stage buffer.  Measured choice
+    // (tools/bench_gemm_nt.py, profiles/r02_gemm_nt_vs_library.*): 256x128 x 3 is the all-round shape; 256x256 halves the
+    // L2 -> LDS fill per flop and wins wide outputs with k >= 512, but its GELU epilogue spills (128 accumulator registers);
+    // 128x128 when the launch would not fill the chip otherwise.  (hs_gemm_nt_set_tile forces a variant for A/B runs.)
+    int variant = g_tile_variant;
+    if (!variant) {
+        const int64_t tiles2 = ((m + 255) / 256) * ((n + 127) / 128);
+        if (tiles2 < 256)
+            variant = 1;
+        else if (epilogue != EPI_GELU && n >= 1024 && k + k2 >= 512)
+            variant = 3;
+        else
+            variant = 2;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 2: return launch_tile<256, 128, 4, 2, 3, true>(p, epilogue, 1, st);
+        case 3: return launch_tile<256, 256, 2, 4, 2, true>(p, epilogue, 1, st);
+        default: return launch_tile<128, 128, 2, 2, 2, false>(p, epilogue, 2, st);
+    }
 }
 
 }  // extern "C"

@@ -285,7 +285,7 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
  *            HS_EPI_RESID: c = acc + bias + aux                              (aux = a residual term [read])
  *   The dropout mask is the one hs_gelu_fwd/bwd draw for the same (seed, element index m*n_cols + n).
  *   k, k2, lda, ldb multiples of 8; n a multiple of 4; dtype must be HS_BF16 (fp32 runs keep the library GEMM).
- * hs_gemm_nt_set_tile: measurement hook (0 = built-in choice, 1 = 128x128 tiles, 2 = 256x128 tiles).
+ * hs_gemm_nt_set_tile: measurement hook (0 = built-in choice, 1 = 128x128 tiles, 2 = 256x128 x 3 stages, 3 = 256x256).
  * ---------------------------------------------------------------------------------------------- */
 #define HS_EPI_BIAS 0
 #define HS_EPI_GELU 1

@@ -30,8 +30,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--only", default="")
+    ap.add_argument("--variants", default="1,2,3")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
+    global VARIANTS
+    VARIANTS = [int(v) for v in args.variants.split(",")]
     dev = torch.device("cuda")
     rows = []
     for name, m, n, k in shapes(args.embed, args.tokens0, args.batch):
@@ -47,7 +50,7 @@ def main():
         variants = {"lib": lambda: torch.nn.functional.linear(a, w, biasb)}
         if "fc1" in name:
             variants["lib+gelu"] = lambda: torch.nn.functional.gelu(torch.nn.functional.linear(a, w, biasb))
-        for tile in (1, 2):
+        for tile in VARIANTS:
             for epi, tag in ((_lib.HS_EPI_BIAS, "bias"),) + (((_lib.HS_EPI_GELU, "gelu"),) if "fc1" in name else ()) + (
                     ((_lib.HS_EPI_DGELU, "dgelu"),) if "fc1" in name else ()):
                 def run(tile=tile, epi=epi):
