@@ -479,19 +479,19 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     """Whether `hs_gemm_nt` should run this product (else the library GEMM + the standalone elementwise kernel).
     Measured on MI355X against hipBLASLt on the B / nside 256 / batch 8 shapes (tools/bench_gemm_nt.py,
     profiles/r02_gemm_nt_vs_library.*): the own kernel wins where the product is HBM-bound (short reductions, narrow outputs:
-    stages 0-1), ties hipBLASLt on the K = 512 shapes and loses the long reductions (K >= 1024: 0.96-1.06 vs 1.26 PFLOP/s);
-    a GELU forward epilogue pays up to K = 512 (it has to write h AND gelu(h): at K = 1024 the library GEMM plus the
-    standalone kernel is faster), the GELU-gradient epilogue (reads h, writes once) always."""
+    stages 0-1), ties the untuned hipBLASLt on the K = 512 shapes (and loses to the TunableOp-selected solutions bench.py
+    loads) and loses the long reductions (K >= 1024: 0.96-1.06 vs 1.26 PFLOP/s).  A GELU forward epilogue pays while the
+    product is HBM-bound (it has to write h AND gelu(h)); the GELU-gradient epilogue (reads h, writes once) up to K = 512."""
     if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 32:
         return False  # (n % 8: whole-row-segment stores; narrower outputs such as the 12-class head stay with the library)
     if OWN_GEMM == "1":
         return True
     kk = k + k2
     if epi == _lib.HS_EPI_DGELU:
-        return True
-    if epi == _lib.HS_EPI_GELU:
         return kk <= 512
-    return kk <= 128 or (n <= 512 and kk <= 512)
+    if epi == _lib.HS_EPI_GELU:
+        return kk <= 256
+    return kk <= 128 or n <= 128 or (n <= 256 and kk <= 256)
 
 
 def gemm_nt(a2d, w, bias=None, epi=0, aux=None, a2=None, w2=None, want_c=True, drop_p=0.0, seed=0):
