@@ -18,6 +18,7 @@ def family(n):
     if "gather_rows" in n: return "hs gather_rows"
     if "wgrad" in n: return "hs linear_wgrad"
     if "reduce_slices" in n: return "hs linear_wgrad slice reduce"
+    if "gemm_nt" in n: return "hs gemm_nt (own GEMM + epilogues)"
     if "gelu" in n: return "hs gelu fwd/bwd"
     if "hs::" in n: return "hs other"
     if n.startswith("Cijk") or n.startswith("Custom_Cijk"): return "hipBLASLt GEMM"
