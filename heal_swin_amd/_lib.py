@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libhealswin.so")
 HS_F32, HS_BF16 = 0, 1
 HS_ATTN_COSINE = 1
 HS_ATTN_FORCE_VALU = 2
+HS_ATTN_RESIDUAL = 4
 HS_EPI_BIAS, HS_EPI_GELU, HS_EPI_DGELU, HS_EPI_RESID = 0, 1, 2, 3
 
 c_i64 = ctypes.c_int64
@@ -58,6 +59,9 @@ _SIGNATURES = {
     "hs_gemm_nt": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int,
                    ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_gemm_nt_set_tile": [c_int],
+    "hs_window_attn_module_supported": [c_int, c_int, c_int, c_int],
+    "hs_window_attn_module_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_i64,
+                                  c_int, c_int, c_int, c_uint, c_int, c_ptr],
     "hs_layernorm_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_ptr],
 }
 _OTHER = {

@@ -1,0 +1,570 @@
+// Fused WindowAttention MODULE forward for the stages whose weights fit the LDS (C = 96 / 128: stage 0 of HEAL-SWIN-T / -B):
+//
+//     out = [x +] proj( window_attention( qkv( [LayerNorm](x) ) ) )        one launch, x read once, out written once
+//
+// i.e. reference WindowAttention.forward (models_torch/swin_hp_transformer.py:124-174) together with the shift / window
+// partition / reverse / shift back around it (:319-330) and, optionally, the block's norm1 in front (:315, v1 placement)
+// and its residual add behind (:316).  qkv [B, N, 3C], the attention output and the probabilities never exist in HBM:
+// per token 2 C * 2 B of traffic instead of 10 C * 2 B for  qkv GEMM -> hs_window_attn_fwd -> proj GEMM  (SURVEY 8d).
+// Inference / no-grad path: nothing is saved for a backward (training keeps the three-kernel path, whose backward needs
+// qkv and the attention output).
+//
+// Workgroup = nH wavefronts (one per SIMD, up to 512 registers each), persistent, one 64-token window at a time:
+//   * the bf16 weights of qkv ([3C, C], 96 KB at C = 128) stay in LDS for the whole launch, proj's ([C, C]) in REGISTERS
+//     (wave w owns output channels 32 w .. 32 w + 31: 8 k-steps x 4 registers), the relative-position bias of head w too;
+//   * x tiles arrive by buffer_load ... lds (row gather through the shift table / roll), the next window's in flight under
+//     the current window's arithmetic; LayerNorm, if requested, is applied in place on the tile;
+//   * wave h = head h, and every contraction is oriented so that its result is, after bf16 packing, DIRECTLY the MFMA operand
+//     of the next one -- no LDS round trip between them (v_mfma_f32_32x32x16_bf16; lane = l, half = l / 32):
+//         q^T[d][tok] = Wq x^T   (A = Wq rows d,  B = x rows tok)     lane = token, registers = 16 of the 32 features
+//         k^T[d][tok] = Wk x^T                                        (same layout)
+//         v  [tok][d] = x Wv^T   (A = x rows tok, B = Wv rows d)      lane = feature, registers = 16 of the 32 tokens
+//         S^T[key][q] = k q^T    A = k^T registers (lane = key, 8 features per step), B = q^T registers (lane = query);
+//                                the feature ORDER inside a step is whatever the accumulator layout gives -- it is the
+//                                same for q and k, and a contraction does not care
+//         softmax over the keys of each query: in registers + one lane^32 exchange (as hs_window_attn_fwd)
+//         O^T[d][q]   = v^T P^T  A = v registers (lane = feature, 8 keys per step), B = P registers (lane = query)
+//         Y^T[n][tok] = Wp O^T   A = Wp registers, B = O rows from an LDS tile the head waves fill (8-byte writes)
+//     80 MFMAs per head and window: 48 (qkv) + 8 (scores) + 8 (P V) + 16 (proj);
+//   * Y^T has lane = token and 4 consecutive channels per register group: staged through the (dead) x tile and stored as
+//     whole 2C-byte token rows to out[token] (the scatter half of the shift).
+// All LDS traffic of the main phases is inline asm: a compiler-visible LDS access beside the DMA queue would be preceded by
+// s_waitcnt vmcnt(0) and serialise the next window's loads behind every phase.
+#include <type_traits>
+
+#include "window_attn.h"
+
+namespace hs {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef unsigned int u32x2v __attribute__((__vector_size__(8)));
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kWs = 64;
+constexpr int kRowB = 256;  // bytes per LDS tile row (C <= 128 bf16; rows of C = 96 are padded)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kNormEps = 1e-12f;
+constexpr float kMaskLog2 = -100.f * kLog2e;
+constexpr float kLnEps = 1e-5f;
+__device__ constexpr uint32_t kOob = 0x7FFFFF00u;
+
+struct ModParams {
+    const uint16_t* x;
+    uint16_t* out;
+    const uint16_t* qkv_w;   // [3C, C] bf16
+    const float* qkv_b;      // [3C] or null
+    const uint16_t* proj_w;  // [C, C] bf16
+    const float* proj_b;     // [C] or null
+    const float* ln_g;       // [C] or null: LayerNorm(x) in front
+    const float* ln_b;
+    const float* bias;        // [nH, 64, 64] or null
+    const float* head_scale;  // [nH]
+    const int32_t* idx;
+    int64_t roll;
+    const uint8_t* labels;
+    int B;
+    int64_t N;
+    int slots;
+    unsigned flags;
+};
+constexpr unsigned kFlagResidual = 4u;  // out = x + module(x)   (HS_ATTN_RESIDUAL)
+
+__device__ __forceinline__ uint32_t swz(int row, int chunk) { return row * kRowB + ((chunk ^ (row & 15)) << 4); }
+
+__device__ __forceinline__ u32x4 ld128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void st64(uint32_t addr, uint32_t a, uint32_t b) {
+    const u32x2v v = {a, b};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+// 8 consecutive accumulator registers -> one bf16 MFMA operand
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int r0) {
+    const u32x4 v = {pack_bf16x2(a[r0], a[r0 + 1]), pack_bf16x2(a[r0 + 2], a[r0 + 3]), pack_bf16x2(a[r0 + 4], a[r0 + 5]),
+                     pack_bf16x2(a[r0 + 6], a[r0 + 7])};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NH, bool COS>
+__global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int C = 32 * NH, NT = NH * 64, KS = C / 16, NCH = C / 8;  // channels, threads, 16-deep k-steps, 16-byte chunks per row
+    constexpr int W_OFF = 0, X_OFF = 3 * C * kRowB, O_OFF = X_OFF + 2 * kWs * kRowB, M_OFF = O_OFF + kWs * kRowB;
+    constexpr int XP = (16 + NH - 1) / NH;  // x-tile DMA pieces (1 KB = 4 rows) per wave
+    // + two 256-B label patches (64 bytes used) + fp32 parameter block: LayerNorm gamma | beta, qkv bias (q | k rows), proj bias
+    constexpr int P_OFF = M_OFF + 2 * 256, P_LNG = 0, P_LNB = 128, P_BQ = 256, P_BK = 384, P_BP = 512;  // float offsets, 128 each
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P_OFF + 5 * 128 * 4];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = head index h = proj channel block
+    const int64_t N = p.N;
+    const int nW = (int)(N / kWs);
+    const int64_t total_windows = (int64_t)p.B * nW;
+    const bool residual = (p.flags & kFlagResidual) != 0;
+    const bool has_ln = p.ln_g != nullptr;
+    if ((int64_t)blockIdx.x >= total_windows) return;
+
+    // ---------------------------------------------------------------- one-off: weights, biases, LayerNorm parameters
+    {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.qkv_w, 0, 3 * C * C * 2, 0x00020000);
+        for (int pc = wave; pc < 3 * C * 16 / 64; pc += NH) {  // 1-KB pieces: 4 weight rows each
+            const int q = pc * 64 + lane, row = q >> 4, chunk = (q & 15) ^ (row & 15);
+            const uint32_t voff = chunk < NCH ? (uint32_t)(row * C * 2 + chunk * 16) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(smem + W_OFF + pc * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+    // small fp32 parameters -> LDS (read back per window with inline-asm LDS reads: registers are the scarce resource here)
+    constexpr int CPQ = NCH / 4;  // LayerNorm: thread -> quarter row = CPQ chunks of 8 channels: 4 (C = 128) or 3 (C = 96)
+    {
+        float* ps = (float*)(smem + P_OFF);
+        for (int i = tid; i < C; i += NT) {
+            ps[P_LNG + i] = has_ln ? p.ln_g[i] : 1.f;
+            ps[P_LNB + i] = has_ln ? p.ln_b[i] : 0.f;
+            ps[P_BQ + i] = p.qkv_b ? p.qkv_b[i] : 0.f;
+            ps[P_BK + i] = p.qkv_b ? p.qkv_b[C + i] : 0.f;
+            ps[P_BP + i] = p.proj_b ? p.proj_b[i] : 0.f;
+        }
+    }
+    const uint32_t pbase = lds0 + P_OFF;
+    // proj weights of this wave's 32 output channels, as A operands: lane (row n = 32 w + l31) holds k = 16 ks + 8 half ..
+    bf16x8 wp[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wp[ks] = *(const bf16x8*)(p.proj_w + (int64_t)(32 * wave + l31) * C + 16 * ks + 8 * half);
+    const float bv = p.qkv_b ? p.qkv_b[2 * C + 32 * wave + l31] : 0.f;  // v bias: column d = l31 of the v accumulators
+    // relative-position bias of this head (x log2 e) in the S^T layout: tile (kt, qt), register r: query qt*32 + l31, key kt*32 + d(r)
+    float biasr[2][2][16];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, qq = qt * 32 + l31;
+                biasr[kt][qt][r] = p.bias ? p.bias[((int64_t)wave * kWs + qq) * kWs + key] * kLog2e : 0.f;
+            }
+    const float hscale = p.head_scale[wave];
+
+    // ---------------------------------------------------------------- x-tile pieces of this wave: (row, logical chunk), token offsets
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (int)(((int64_t)p.B * N * C * 2) > 0x7FFFFE00ll ? 0x7FFFFE00ll : (int64_t)p.B * N * C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)p.labels, 0, p.labels ? (int)N : 0, 0x00020000);
+    int prow[XP], pchunk[XP];
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+        const int q = (wave + NH * j) * 64 + lane;
+        prow[j] = q >> 4;
+        pchunk[j] = (q & 15) ^ (prow[j] & 15);
+    }
+    int64_t tok[XP], tok_next[XP];  // token (global row) of this lane's piece rows: current / next window
+    auto tokens_of = [&](int64_t wi, int64_t (&t)[XP]) {
+        const int b = (int)(wi / nW);
+        const int64_t j0 = (wi - (int64_t)b * nW) * kWs;
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            const int64_t js = j0 + (prow[j] & 63);  // shifted position -> natural-order token (gather = scatter map)
+            int64_t src;
+            if (p.idx) src = p.idx[js];
+            else {
+                src = js + p.roll;
+                if (src >= N) src -= N;
+            }
+            t[j] = (int64_t)b * N + src;
+        }
+    };
+    auto issue_x = [&](const int64_t (&t)[XP], int64_t wi, int buf) {
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            const int pc = wave + NH * j;
+            if (pc < 16) {
+                const uint32_t voff = pchunk[j] < NCH ? (uint32_t)(t[j] * (C * 2) + pchunk[j] * 16) : kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(smem + X_OFF + buf * (kWs * kRowB) + pc * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+        if (wave == 0 && p.labels) {  // 64 label bytes = 16 dwords; the other lanes read past the descriptor (zeros)
+            const int64_t j0 = (wi % nW) * kWs;
+            const uint32_t voff = lane < 16 ? (uint32_t)(j0 + lane * 4) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void*)(smem + M_OFF + buf * 256), 4, voff, 0, 0, 0);
+        }
+    };
+
+    int64_t wi = blockIdx.x;
+    tokens_of(wi, tok);
+    issue_x(tok, wi, 0);
+    int cur = 0;
+    const uint32_t wbase = lds0 + W_OFF, obase = lds0 + O_OFF;
+
+    for (; wi < total_windows; wi += p.slots) {
+        const bool more = wi + p.slots < total_windows;
+        if (more) tokens_of(wi + p.slots, tok_next);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights (first pass) and this window's x rows have landed
+        __builtin_amdgcn_s_barrier();
+        const uint32_t xbase = lds0 + X_OFF + cur * (kWs * kRowB);
+        // region labels of this window (fetched with its x tile into label patch `cur`): 16 words, every lane reads all
+        uint32_t labw[16];
+        bool mixed = false;
+        if (p.labels) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(labw[i]) : "v"(lds0 + M_OFF + cur * 256), "n"(4 * i));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(labw[0]), "+v"(labw[1]), "+v"(labw[2]), "+v"(labw[3]), "+v"(labw[4]), "+v"(labw[5]), "+v"(labw[6]),
+                           "+v"(labw[7]), "+v"(labw[8]), "+v"(labw[9]), "+v"(labw[10]), "+v"(labw[11]), "+v"(labw[12]),
+                           "+v"(labw[13]), "+v"(labw[14]), "+v"(labw[15]));
+            const uint32_t first = (labw[0] & 0xffu) * 0x01010101u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mixed |= labw[i] != first;
+        }
+        if (more) issue_x(tok_next, wi + p.slots, cur ^ 1);  // in flight during everything below
+
+        // ------------------------------------------------------------ optional LayerNorm of the 64 rows, in place
+        if (has_ln) {
+            // thread -> (row tid / 4 [+ NT / 4 per pass], quarter tid % 4 = CPQ chunks of 8 channels)
+            for (int row = tid >> 2; row < kWs; row += NT / 4) {
+                const int qd = tid & 3;
+                u32x4 v[CPQ];
+#pragma unroll
+                for (int c = 0; c < CPQ; ++c) asm volatile("ds_read_b128 %0, %1" : "=v"(v[c]) : "v"(xbase + swz(row, qd * CPQ + c)));
+                if constexpr (CPQ == 4)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+                float s1 = 0.f, s2 = 0.f, f[CPQ][8];
+#pragma unroll
+                for (int c = 0; c < CPQ; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[c][2 * e] = __uint_as_float(v[c][e] << 16);
+                        f[c][2 * e + 1] = __uint_as_float(v[c][e] & 0xffff0000u);
+                        s1 += f[c][2 * e] + f[c][2 * e + 1];
+                    }
+                s1 += __shfl_xor(s1, 1, 64);
+                s1 += __shfl_xor(s1, 2, 64);
+                const float mean = s1 * (1.f / C);
+#pragma unroll
+                for (int c = 0; c < CPQ; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[c][e] -= mean;
+                        s2 += f[c][e] * f[c][e];
+                    }
+                s2 += __shfl_xor(s2, 1, 64);
+                s2 += __shfl_xor(s2, 2, 64);
+                const float rstd = rsqrtf(s2 * (1.f / C) + kLnEps);
+#pragma unroll
+                for (int c = 0; c < CPQ; ++c) {
+                    const uint32_t ga = pbase + (P_LNG + (qd * CPQ + c) * 8) * 4, ba = pbase + (P_LNB + (qd * CPQ + c) * 8) * 4;
+                    u32x4 g0 = ld128(ga), g1 = ld128(ga + 16), b0 = ld128(ba), b1 = ld128(ba + 16);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1));
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ga0 = __uint_as_float(e < 2 ? g0[2 * e] : g1[2 * e - 4]), ga1 = __uint_as_float(e < 2 ? g0[2 * e + 1] : g1[2 * e - 3]);
+                        const float be0 = __uint_as_float(e < 2 ? b0[2 * e] : b1[2 * e - 4]), be1 = __uint_as_float(e < 2 ? b0[2 * e + 1] : b1[2 * e - 3]);
+                        o[e] = pack_bf16x2(fmaf(f[c][2 * e] * rstd, ga0, be0), fmaf(f[c][2 * e + 1] * rstd, ga1, be1));
+                    }
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(xbase + swz(row, qd * CPQ + c)), "v"(o) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+
+        // ------------------------------------------------------------ q^T, k^T, v of this head: 6 accumulators, KS k-steps
+        f32x16 aq[2], ak[2], av[2];
+        {   // accumulators start at the bias: q^T / k^T rows d = 8 g + 4 half + 0..3 (group g = r / 4), v column d = l31
+            u32x4 bqv[4], bkv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bqv[g] = ld128(pbase + (P_BQ + 32 * wave + 8 * g + 4 * half) * 4);
+                bkv[g] = ld128(pbase + (P_BK + 32 * wave + 8 * g + 4 * half) * 4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(bqv[0]), "+v"(bqv[1]), "+v"(bqv[2]), "+v"(bqv[3]), "+v"(bkv[0]), "+v"(bkv[1]), "+v"(bkv[2]), "+v"(bkv[3]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    aq[t][r] = __uint_as_float(bqv[r >> 2][r & 3]);
+                    ak[t][r] = __uint_as_float(bkv[r >> 2][r & 3]);
+                    av[t][r] = bv;
+                }
+        }
+        {
+            const uint32_t xa0 = xbase + l31 * kRowB, xa1 = xbase + (32 + l31) * kRowB;
+            const uint32_t wq = wbase + (32 * wave + l31) * kRowB, wk = wq + C * kRowB, wv = wk + C * kRowB;
+            const int sx = l31 & 15;  // (row & 15) of every operand row of this lane: rows differ by multiples of 32 and 16 | C
+            u32x4 fx[2][2], fw[2][3];
+            auto reads = [&](int ks, int set) {
+                const uint32_t co = (uint32_t)(((2 * ks + half) ^ sx) << 4);
+                fx[set][0] = ld128(xa0 + co);
+                fx[set][1] = ld128(xa1 + co);
+                fw[set][0] = ld128(wq + co);
+                fw[set][1] = ld128(wk + co);
+                fw[set][2] = ld128(wv + co);
+            };
+            reads(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int set = ks & 1;
+                if (ks + 1 < KS) {
+                    reads(ks + 1, set ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fx[set][0]), "+v"(fx[set][1]), "+v"(fw[set][0]), "+v"(fw[set][1]), "+v"(fw[set][2]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[set][0]), "+v"(fx[set][1]), "+v"(fw[set][0]), "+v"(fw[set][1]), "+v"(fw[set][2]));
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    aq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fw[set][0]), as_frag(fx[set][t]), aq[t], 0, 0, 0);
+                    ak[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fw[set][1]), as_frag(fx[set][t]), ak[t], 0, 0, 0);
+                    av[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fx[set][t]), as_frag(fw[set][2]), av[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // cosine attention: k rows normalised, 1 / |q| folded into the per-query score factor
+        float qinv[2] = {1.f, 1.f};
+        if constexpr (COS) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float sq = 0.f, sk = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sq = fmaf(aq[t][r], aq[t][r], sq);
+                    sk = fmaf(ak[t][r], ak[t][r], sk);
+                }
+                sq += __shfl_xor(sq, 32, 64);
+                sk += __shfl_xor(sk, 32, 64);
+                qinv[t] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ak[t][r] *= kinv;
+            }
+        }
+        bf16x8 qf[2][2], kf[2][2], vf[2][2];  // [token tile][8-register step]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                qf[t][c] = pack8(aq[t], 8 * c);
+                kf[t][c] = pack8(ak[t], 8 * c);
+                vf[t][c] = pack8(av[t], 8 * c);
+            }
+
+        // ------------------------------------------------------------ S^T = k q^T, softmax over keys (log2 domain)
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[kt][qt][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][c], qf[qt][c], acc[kt][qt], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float fq = hscale * kLog2e * qinv[qt];
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = fmaf(acc[kt][qt][r], fq, biasr[kt][qt][r]);
+                    acc[kt][qt][r] = t;
+                    m = fmaxf(m, t);
+                }
+            if (mixed) {  // rare: windows cut by the shift boundary
+                uint32_t mine = 0;  // the word holding this lane's query label: index qt * 8 + l31 / 4 is lane-dependent
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mine = (l31 >> 2) == i ? labw[qt * 8 + i] : mine;
+                const uint32_t mylab = (mine >> (8 * (l31 & 3))) & 0xffu;
+                m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // key = kt * 32 + (r & 3) + 8 (r >> 2) + 4 half: word kt * 8 + 2 (r >> 2) + half, byte r & 3
+                        const uint32_t word = half ? labw[kt * 8 + 2 * (r >> 2) + 1] : labw[kt * 8 + 2 * (r >> 2)];
+                        const uint32_t klab = (word >> (8 * (r & 3))) & 0xffu;
+                        float t = acc[kt][qt][r];
+                        if (klab != mylab) t += kMaskLog2;
+                        acc[kt][qt][r] = t;
+                        m = fmaxf(m, t);
+                    }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(acc[kt][qt][r] - m);
+                    acc[kt][qt][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 32, 64);
+            const float linv = 1.f / l;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv;
+        }
+
+        // ------------------------------------------------------------ O^T = v^T P^T  (rows = features, columns = queries)
+        f32x16 ao[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ao[qt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    ao[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][c], pack8(acc[kt][qt], 8 * c), ao[qt], 0, 0, 0);
+        // -> O tile [token][channel 32 h + d]: lane (token, half) writes 4 consecutive channels per register group
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int row = qt * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                st64(obase + swz(row, 4 * wave + g) + 8 * half, pack_bf16x2(ao[qt][4 * g], ao[qt][4 * g + 1]),
+                     pack_bf16x2(ao[qt][4 * g + 2], ao[qt][4 * g + 3]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // O tile complete; every wave is done with the x tile
+
+        // ------------------------------------------------------------ Y^T = Wp O^T for this wave's 32 output channels
+        f32x16 ay[2];
+        {
+            u32x4 bpv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bpv[g] = ld128(pbase + (P_BP + 32 * wave + 8 * g + 4 * half) * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bpv[0]), "+v"(bpv[1]), "+v"(bpv[2]), "+v"(bpv[3]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ay[t][r] = __uint_as_float(bpv[r >> 2][r & 3]);
+        }
+        {
+            const uint32_t oa0 = obase + l31 * kRowB, oa1 = obase + (32 + l31) * kRowB;
+            const int sx = l31 & 15;
+            u32x4 fo[2][2];
+            fo[0][0] = ld128(oa0 + (uint32_t)(((0 + half) ^ sx) << 4));
+            fo[0][1] = ld128(oa1 + (uint32_t)(((0 + half) ^ sx) << 4));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int set = ks & 1;
+                if (ks + 1 < KS) {
+                    const uint32_t co = (uint32_t)(((2 * (ks + 1) + half) ^ sx) << 4);
+                    fo[set ^ 1][0] = ld128(oa0 + co);
+                    fo[set ^ 1][1] = ld128(oa1 + co);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fo[set][0]), "+v"(fo[set][1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fo[set][0]), "+v"(fo[set][1]));
+                }
+                ay[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[ks], as_frag(fo[set][0]), ay[0], 0, 0, 0);
+                ay[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[ks], as_frag(fo[set][1]), ay[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // -> staging in the (dead) x tile: lane (token, half), channels 32 w + 8 g + 4 half ..
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                st64(xbase + swz(row, 4 * wave + g) + 8 * half, pack_bf16x2(ay[t][4 * g], ay[t][4 * g + 1]),
+                     pack_bf16x2(ay[t][4 * g + 2], ay[t][4 * g + 3]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // staged tile complete; every wave is done with the O tile
+
+        // ------------------------------------------------------------ whole token rows -> out[token] (the scatter half of the shift)
+        {
+            u32x4 rows[XP];
+#pragma unroll
+            for (int j = 0; j < XP; ++j)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(rows[j]) : "v"(xbase + (uint32_t)((wave + NH * j) * 1024 + lane * 16)));
+#pragma unroll
+            for (int j = 0; j < XP; ++j) {
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(rows[j]) : "n"(XP - 1 - j));
+                if (wave + NH * j < 16 && pchunk[j] < NCH) {
+                    const int64_t e = tok[j] * C + pchunk[j] * 8;
+                    u32x4 v = rows[j];
+                    if (residual) {
+                        const u32x4v xr = __builtin_nontemporal_load((const u32x4v*)(p.x + e));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            v[i] = pack_bf16x2(__uint_as_float(v[i] << 16) + __uint_as_float(xr[i] << 16),
+                                               __uint_as_float(v[i] & 0xffff0000u) + __uint_as_float(xr[i] & 0xffff0000u));
+                    }
+                    *(u32x4*)(p.out + e) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XP; ++j) tok[j] = tok_next[j];
+        cur ^= 1;
+    }
+#endif
+}
+
+template <int NH>
+int launch_module(const ModParams& p0, bool cosine, hipStream_t stream) {
+    ModParams p = p0;
+    const int64_t windows = (int64_t)p.B * (p.N / kWs);
+    p.slots = (int)(windows < 256 ? windows : 256);  // one persistent workgroup per CU (144 KB of LDS each)
+    if (cosine)
+        hipLaunchKernelGGL((attn_module_fwd_kernel<NH, true>), dim3(p.slots), dim3(NH * 64), 0, stream, p);
+    else
+        hipLaunchKernelGGL((attn_module_fwd_kernel<NH, false>), dim3(p.slots), dim3(NH * 64), 0, stream, p);
+    HS_LAUNCH_CHECK("attn_module_fwd");
+    return HS_OK;
+}
+
+}  // namespace
+}  // namespace hs
+
+extern "C" {
+
+int hs_window_attn_module_supported(int channels, int num_heads, int window_size, int dtype) {
+    return dtype == HS_BF16 && window_size == hs::kWs && num_heads * 32 == channels && (channels == 96 || channels == 128);
+}
+
+int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
+                              const float* ln_gamma, const float* ln_beta, const float* bias, const float* head_scale,
+                              const int32_t* idx, int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens, int channels,
+                              int num_heads, int window_size, unsigned flags, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(x && out && qkv_w && proj_w && head_scale, "hs_window_attn_module_fwd: null pointer");
+    HS_CHECK_ARG(batch > 0 && n_tokens > 0 && n_tokens % kWs == 0, "hs_window_attn_module_fwd: n_tokens must be a positive multiple of 64");
+    HS_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "hs_window_attn_module_fwd: ln_gamma and ln_beta go together");
+    HS_CHECK_ARG(roll >= 0 && roll < n_tokens, "hs_window_attn_module_fwd: roll must be in [0, n_tokens)");
+    if (!hs_window_attn_module_supported(channels, num_heads, window_size, dtype))
+        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_fwd: bf16, window 64, head_dim 32 and C = 96 or 128 only (got C = %d, "
+                    "heads %d, window %d): the qkv weights must fit the LDS", channels, num_heads, window_size);
+    if ((int64_t)batch * n_tokens * channels * 2 > 0x7FFFFE00ll)
+        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_fwd: activation tensor beyond the 2 GiB buffer-offset range");
+    ModParams p{};
+    p.x = (const uint16_t*)x; p.out = (uint16_t*)out; p.qkv_w = (const uint16_t*)qkv_w; p.qkv_b = qkv_b;
+    p.proj_w = (const uint16_t*)proj_w; p.proj_b = proj_b; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.bias = bias;
+    p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = batch; p.N = n_tokens;
+    p.flags = flags;
+    const bool cosine = (flags & HS_ATTN_COSINE) != 0;
+    return num_heads == 4 ? launch_module<4>(p, cosine, (hipStream_t)stream) : launch_module<3>(p, cosine, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -171,6 +171,10 @@ class WindowAttention(nn.Module):
         if self.rel_pos_bias is not None and window_size != self.window_size:
             raise AssertionError("relative position bias needs input_resolution >= window_size")  # ref quirk :243-251
         x_res = None
+        if self.fusable(x, window_size):
+            # no-grad forward of a stage whose qkv weights fit the LDS: qkv -> attention -> proj in ONE kernel
+            y = self.fused_module(x, window_size, idx, roll, labels)
+            return (y, x) if residual_alias else y
         if residual_alias:
             qkv, x_res = self.qkv.forward_passthrough(x)
         else:
@@ -180,6 +184,19 @@ class WindowAttention(nn.Module):
         y = self.proj(o)
         y = self.proj_drop(y) if apply_proj_drop else y  # the caller fuses proj_drop into the next norm kernel
         return (y, x_res) if residual_alias else y
+
+    def fusable(self, x, window_size):
+        """The one-launch inference kernel applies: no gradient wanted, supported shape, nothing stochastic switched on."""
+        return (ops.window_attn_module_ok(x, self.num_heads, window_size) and
+                not (self.training and (self.attn_drop.p > 0 or self.proj_drop.p > 0)) and
+                (self.rel_pos_bias is None or window_size == self.window_size))
+
+    def fused_module(self, x, window_size, idx, roll, labels, norm=None, residual=False):
+        """[x +] proj(attention(qkv([norm](x)))) by `hs_window_attn_module_fwd` (inference only; ops.window_attn_module_ok)."""
+        return ops.window_attn_module(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.bias(),
+                                      self.head_scale(), idx, roll, labels, self.num_heads, window_size, self.use_cos_attn,
+                                      ln_weight=None if norm is None else norm.weight, ln_bias=None if norm is None else norm.bias,
+                                      residual=residual)
 
     def forward(self, x, mask=None):
         """Reference-compatible entry: x [num_windows*B, Ws, C], mask [nW, Ws, Ws] in {0,-100} or None."""
@@ -268,10 +285,26 @@ class SwinTransformerBlock(nn.Module):
         ride on the LayerNorm kernel that consumes the sum."""
         return not self.use_v2_norm_placement and self._hs_norms()
 
+    def _shift_args(self, x):
+        if not self._shifted:
+            return None, 0, None
+        idx, _, labels = self.shifter.tables(x.device)
+        if self._is_roll:
+            return None, self.shift_size % x.shape[1], labels
+        return idx, 0, labels
+
     def forward_deferred(self, x, pending):
         """v1 block on the input `x + rs*drop(p)` for pending = (p, rs, drop_p) (or None); returns (x1, pending') with the
         block output = x1 + rs'*drop(m) (ref :337-338 and :316 of the next block)."""
         train = self.training
+        if self.attn.fusable(x, self.window_size) and not (train and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0):
+            # no-grad forward: x1 = xs + proj(attn(qkv(norm1(xs)))) is ONE launch (norm1 as the kernel's prologue, the
+            # residual add as its epilogue), xs = x + previous block's MLP branch
+            xs = self.resolve_pending(x, pending)
+            idx, roll, labels = self._shift_args(xs)
+            x1 = self.attn.fused_module(xs, self.window_size, idx, roll, labels, norm=self.norm1, residual=True)
+            m = self.mlp(self.norm2(x1), apply_out_drop=False)
+            return x1, (m, None, 0.0)
         if pending is None:  # x feeds norm1 AND the residual add below: the alias keeps the two gradients in one kernel
             n1, x = ops.layer_norm_passthrough(x, self.norm1.weight, self.norm1.bias)
         else:

@@ -150,6 +150,37 @@ def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window
                                   float(attn_drop), int(seed or 0))
 
 
+FUSED_ATTN_MODULE = os.environ.get("HS_FUSED_ATTN_MODULE", "1") != "0"  # A/B switch of the no-grad fused module path
+
+
+def window_attn_module_ok(x, num_heads, window_size):
+    """Whether `hs_window_attn_module_fwd` covers this call: no gradient needed, bf16, window 64, head_dim 32, C in {96, 128}."""
+    return (FUSED_ATTN_MODULE and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and
+            bool(lib.hs_window_attn_module_supported(x.shape[-1], num_heads, window_size, _lib.HS_BF16)))
+
+
+def window_attn_module(x, qkv_w, qkv_b, proj_w, proj_b, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine,
+                       ln_weight=None, ln_bias=None, residual=False):
+    """[x +] proj(window_attention(qkv([LayerNorm](x)))) in one launch (inference; see include/healswin.h).  x [B, N, C] bf16 in
+    natural order; qkv_w / proj_w in any float dtype (bf16 copies come from the weight cache)."""
+    _require_gpu(x, qkv_w, proj_w, bias, head_scale, idx, labels)
+    B, N, C = x.shape
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    wq, wp = _cast_param(qkv_w, torch.bfloat16).contiguous(), _cast_param(proj_w, torch.bfloat16).contiguous()
+    hs = _f32(head_scale).reshape(-1)
+    flags = (_lib.HS_ATTN_COSINE if cosine else 0) | (_lib.HS_ATTN_RESIDUAL if residual else 0)
+    # algorithmic traffic: x in, out written (+ x again for the residual); flops: qkv + scores + P V + proj
+    nbytes = (3 if residual else 2) * B * N * C * 2
+    flops = B * N * (8 * C * C + 4 * window_size * C)
+    with _timed("window_attn_module_fwd", x.device, nbytes, flops):
+        check(lib.hs_window_attn_module_fwd(ptr(x), ptr(out), ptr(wq), ptr(_f32(qkv_b)), ptr(wp), ptr(_f32(proj_b)), ptr(_f32(ln_weight)),
+                                            ptr(_f32(ln_bias)), ptr(_f32(bias)), ptr(hs), ptr(idx), int(roll), ptr(labels), B, N, C,
+                                            num_heads, window_size, flags, _lib.HS_BF16, stream_ptr(x.device)),
+              "hs_window_attn_module_fwd")
+    return out
+
+
 # ----------------------------------------------------------------------------- row LayerNorm (+ residual, + train-mode extras)
 def _extras(x, row_scale, drop_p, seed):
     """(row_scale fp32 or None, rows_per_sample, drop_p, seed) for the *_drop_* kernels; None if nothing stochastic is on."""

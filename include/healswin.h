@@ -39,6 +39,7 @@ typedef enum { HS_F32 = 0, HS_BF16 = 1 } hs_dtype;
 /* flags of hs_window_attn_* */
 #define HS_ATTN_COSINE 1u      /* cosine attention: L2-normalise q,k (eps 1e-12), per-head scale */
 #define HS_ATTN_FORCE_VALU 2u  /* run the generic fp32-VALU kernels even where an MFMA kernel exists (cross-checks, A/B) */
+#define HS_ATTN_RESIDUAL 4u    /* hs_window_attn_module_fwd: out = x + module(x) (the block's residual add, :316) */
 
 const char* hs_version(void);
 /* human-readable message of the last failing call on this thread ("" if none) */
@@ -268,6 +269,30 @@ int hs_seg_ce_bwd(const void* logits, const void* labels, const float* class_wei
 int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in);
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace,
                     int64_t rows, int n_out, int k_in, int accumulate, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused WindowAttention MODULE forward (inference / no-grad): the whole of WindowAttention.forward,
+ * models_torch/swin_hp_transformer.py:124-174 -- qkv Linear, head split, (cosine | scaled) scores, relative-position bias,
+ * shift mask, softmax, P V, head merge, proj Linear -- with the shift / window partition / reverse / shift back of
+ * SwinTransformerBlock.forward (:319-330) and optionally the block's norm1 in front (:315) and residual add behind (:316):
+ *     out[b, t, :] = [x[b, t, :] +] proj( attention( qkv( [LayerNorm](x) ) ) )[b, t, :]
+ * in ONE launch: x is read once, out written once; qkv [B, N, 3C] and the attention output never exist in HBM
+ * (SURVEY 8b's proposed entry point, 8d's fused-module roofline).
+ *   x, out      [dev] bf16 [batch, n_tokens, channels], natural order; out may not alias x
+ *   qkv_w       [dev] bf16 [3 * channels, channels] (nn.Linear layout, rows [q | k | v][head][32]); qkv_b [dev] f32 or NULL
+ *   proj_w      [dev] bf16 [channels, channels]; proj_b [dev] f32 [channels] or NULL
+ *   ln_gamma/ln_beta [dev] f32 [channels] or both NULL (eps 1e-5)
+ *   bias, head_scale, idx, roll, labels: as hs_window_attn_fwd.  flags: HS_ATTN_COSINE, HS_ATTN_RESIDUAL.
+ * Supported where the qkv weights fit the LDS: dtype HS_BF16, window_size 64, head_dim 32, channels 96 or 128 (stage 0 of
+ * HEAL-SWIN-T / -B); everything else returns HS_ERR_UNSUPPORTED (hs_window_attn_module_supported tells beforehand) and the
+ * caller composes hs_gemm_nt / hs_window_attn_fwd / hs_gemm_nt.  No dropout (inference).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_window_attn_module_supported(int channels, int num_heads, int window_size, int dtype);
+int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const float* qkv_b, const void* proj_w,
+                              const float* proj_b, const float* ln_gamma, const float* ln_beta, const float* bias,
+                              const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels, int batch,
+                              int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Forward and input-gradient product of the path's Linear layers with the elementwise step behind it fused into the
