@@ -228,13 +228,22 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             // thread -> (row tid / 4 [+ NT / 4 per pass], quarter tid % 4 = CPQ chunks of 8 channels)
             for (int row = tid >> 2; row < kWs; row += NT / 4) {
                 const int qd = tid & 3;
-                u32x4 v[CPQ];
+                // the row quarter and its gamma / beta are requested together: one LDS round trip for the whole phase
+                u32x4 v[CPQ], gw[CPQ][2], bw[CPQ][2];
 #pragma unroll
-                for (int c = 0; c < CPQ; ++c) asm volatile("ds_read_b128 %0, %1" : "=v"(v[c]) : "v"(xbase + swz(row, qd * CPQ + c)));
+                for (int c = 0; c < CPQ; ++c) v[c] = ld128(xbase + swz(row, qd * CPQ + c));
+#pragma unroll
+                for (int c = 0; c < CPQ; ++c) {
+                    const uint32_t ga = pbase + (P_LNG + (qd * CPQ + c) * 8) * 4, ba = pbase + (P_LNB + (qd * CPQ + c) * 8) * 4;
+                    gw[c][0] = ld128(ga);
+                    gw[c][1] = ld128(ga + 16);
+                    bw[c][0] = ld128(ba);
+                    bw[c][1] = ld128(ba + 16);
+                }
                 if constexpr (CPQ == 4)
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+                    asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));  // (4-bit counter: 15 of the 16 parameter reads may be pending)
                 else
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+                    asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
                 float s1 = 0.f, s2 = 0.f, f[CPQ][8];
 #pragma unroll
                 for (int c = 0; c < CPQ; ++c)
@@ -244,8 +253,9 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                         f[c][2 * e + 1] = __uint_as_float(v[c][e] & 0xffff0000u);
                         s1 += f[c][2 * e] + f[c][2 * e + 1];
                     }
-                s1 += __shfl_xor(s1, 1, 64);
-                s1 += __shfl_xor(s1, 2, 64);
+                // sums over the 4 lanes of a row: DPP quad permutes (1 VALU each) instead of LDS-routed shuffles
+                s1 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+                s1 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
                 const float mean = s1 * (1.f / C);
 #pragma unroll
                 for (int c = 0; c < CPQ; ++c)
@@ -254,19 +264,17 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                         f[c][e] -= mean;
                         s2 += f[c][e] * f[c][e];
                     }
-                s2 += __shfl_xor(s2, 1, 64);
-                s2 += __shfl_xor(s2, 2, 64);
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s2), 0xB1, 0xF, 0xF, true));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s2), 0x4E, 0xF, 0xF, true));
                 const float rstd = rsqrtf(s2 * (1.f / C) + kLnEps);
 #pragma unroll
                 for (int c = 0; c < CPQ; ++c) {
-                    const uint32_t ga = pbase + (P_LNG + (qd * CPQ + c) * 8) * 4, ba = pbase + (P_LNB + (qd * CPQ + c) * 8) * 4;
-                    u32x4 g0 = ld128(ga), g1 = ld128(ga + 16), b0 = ld128(ba), b1 = ld128(ba + 16);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1));
+                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(gw[c][0]), "+v"(gw[c][1]), "+v"(bw[c][0]), "+v"(bw[c][1]) : "n"(4 * (CPQ - 1 - c)));
                     u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float ga0 = __uint_as_float(e < 2 ? g0[2 * e] : g1[2 * e - 4]), ga1 = __uint_as_float(e < 2 ? g0[2 * e + 1] : g1[2 * e - 3]);
-                        const float be0 = __uint_as_float(e < 2 ? b0[2 * e] : b1[2 * e - 4]), be1 = __uint_as_float(e < 2 ? b0[2 * e + 1] : b1[2 * e - 3]);
+                        const float ga0 = __uint_as_float(gw[c][e >> 1][(2 * e) & 3]), ga1 = __uint_as_float(gw[c][e >> 1][(2 * e + 1) & 3]);
+                        const float be0 = __uint_as_float(bw[c][e >> 1][(2 * e) & 3]), be1 = __uint_as_float(bw[c][e >> 1][(2 * e + 1) & 3]);
                         o[e] = pack_bf16x2(fmaf(f[c][2 * e] * rstd, ga0, be0), fmaf(f[c][2 * e + 1] * rstd, ga1, be1));
                     }
                     asm volatile("ds_write_b128 %0, %1" ::"v"(xbase + swz(row, qd * CPQ + c)), "v"(o) : "memory");
