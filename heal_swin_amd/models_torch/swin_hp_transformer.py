@@ -645,6 +645,7 @@ class SwinHPTransformerSys(nn.Module):
             raise RuntimeError("SwinHPTransformerSys (heal_swin_amd) runs only on an MI355X (HIP) device; there is no CPU path")
         dt = self._activation_dtype(x)
         prev, ops.CAST_CACHE = ops.CAST_CACHE, self._param_casts(dt)
+        ops.LAST_CAST_CACHE = ops.CAST_CACHE
         try:
             with torch.autocast(device_type="cuda", enabled=False):
                 x, x_downsample = self.forward_features(x.to(dt))

@@ -478,6 +478,11 @@ class ParamCastCache:
         i = self.index.get(id(p)) if dtype == self.dtype else None
         return None if i is None else self.shadows[i]
 
+    def current(self, p):
+        """The shadow of p still reflects p (p unchanged since the last refresh)."""
+        i = self.index.get(id(p))
+        return i is not None and self.versions is not None and self.versions[i] == (p.data_ptr(), p._version)
+
     def get_t(self, p, dtype):
         """[in, out] (transposed) activation-dtype copy of a 2-D weight: the B operand of its input-gradient product in
         `hs_gemm_nt`.  Made on first use and re-made after every refresh that found changed parameters."""
@@ -493,6 +498,9 @@ class ParamCastCache:
 
 
 CAST_CACHE = None  # a refreshed ParamCastCache while a model forward is running (set by SwinHPTransformerSys.forward)
+# the cache of the most recent forward: the BACKWARD of that forward takes the transposed weight copies from it (the
+# parameters have not changed in between: an optimizer step bumps the versions and the next forward refreshes)
+LAST_CAST_CACHE = None
 
 
 def _cast_param(p, dtype):
@@ -546,7 +554,8 @@ def gemm_nt(a2d, w, bias=None, epi=0, aux=None, a2=None, w2=None, want_c=True, d
 
 def _cast_param_t(p, dtype):
     """[in, out] copy of weight p ([out, in, ...]) in `dtype` for the input-gradient product."""
-    c = CAST_CACHE.get_t(p, dtype) if (CAST_CACHE is not None and p.dim() == 2) else None
+    cache = CAST_CACHE if CAST_CACHE is not None else LAST_CAST_CACHE
+    c = cache.get_t(p, dtype) if (cache is not None and p.dim() == 2 and cache.current(p)) else None
     if c is None:
         n_out = p.shape[0]
         c = p.detach().to(dtype).view(n_out, -1).t().contiguous()
