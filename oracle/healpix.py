@@ -10,8 +10,10 @@ the `nest2xyf / xyf2ring / ring2xyf / xyf2nest` decomposition of the HEALPix C++
   ring number   jr = jrll[face]*nside - ix - iy - 1            (1 .. 4*nside-1, north to south)
   in-ring index jp = (jpll[face]*nr + ix - iy + 1 + kshift)/2  wrapped to 1 .. 4*nr
 
-PARITY UNPINNED against healpy itself; pinned only by healpy's docstring examples
-(tests/test_oracle_tables.py::test_healpix_known_answers) and by bijection/inverse properties.
+PARITY UNPINNED against healpy itself (it cannot be run here); pinned by healpy's docstring examples
+(tests/test_oracle_tables.py::test_healpix_known_answers), by bijection/inverse properties, and by an independent geometric
+derivation of the pixel centres in both schemes (tests/test_healpix_geometry.py: closed-form ring-index formulas vs the HEALPix
+projection plane for the nested index agree to 1e-12 under these maps for every pixel at nside 1..256).
 """
 import numpy as np
 
