@@ -428,6 +428,41 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
     float dscale_acc = 0.f;
 
+    // Software pipeline (non-cosine variants; the cosine ones are at the register limit): the q, k, v, dO, O rows of window
+    // i+1 are requested into registers right after window i's MFMA phases, when the accumulators are dead, and land while
+    // window i's partial sums are exchanged and its results stored.  The workgroup barriers of that tail are RAW s_barrier
+    // instructions behind an explicit lgkmcnt(0): __syncthreads() would also wait for the loads in flight (vmcnt(0)) and
+    // undo the overlap -- PMC had the waves parked 62 % of their cycles (SQ_WAIT_ANY).
+    constexpr bool PREFETCH = !COS;
+    uint4 ldq[2], ldk[2], ldv[2], lddo[2], ldo[2];
+    int64_t tok_next[2];
+    auto issue_loads = [&](int64_t wi_l) {
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));  // (keeps the address arithmetic out of long-lived registers, see below)
+        const int srow_l = tid_l / (4 * HG), sc_l = tid_l % (4 * HG);
+        const int64_t col_l = (int64_t)by * HG * kHd + sc_l * 8;
+        const int b_l = (int)(wi_l / nW);
+        const int64_t j_l = (wi_l - (int64_t)b_l * nW) * kWs;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            tok_next[rb] = (int64_t)b_l * N + shifted_source(p, j_l + rb * 32 + srow_l);
+            ldq[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + col_l);
+            ldk[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + C + col_l);
+            ldv[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + 2 * (int64_t)C + col_l);
+            lddo[rb] = *(const uint4*)(dout + tok_next[rb] * C + col_l);
+            ldo[rb] = *(const uint4*)(fo + tok_next[rb] * C + col_l);
+        }
+    };
+    auto lds_barrier = [&]() {  // workgroup barrier that orders LDS traffic only (global loads may stay in flight)
+        if constexpr (PREFETCH) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
+    if (PREFETCH && (int64_t)bx < total_windows) issue_loads(bx);
+
     for (int64_t wi = bx; wi < total_windows; wi += slots) {
         // staging geometry: 128*HG threads move 32 rows x HG*64 B per pass, 2 passes per tile.  Derived from an opaque
         // copy of the thread id inside the loop so that the ~40 VGPRs of per-thread addresses are not hoisted and pinned.
@@ -449,17 +484,18 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 
         // ------------------------------------------------------------ stage q, k^, v, dO; D = dO.O; norms
         int64_t tok[2];
+        if constexpr (!PREFETCH) issue_loads(wi);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) tok[rb] = (int64_t)b * N + shifted_source(p, j0 + rb * 32 + srow);
+        for (int rb = 0; rb < 2; ++rb) tok[rb] = tok_next[rb];
         if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int row = rb * 32 + srow;
-            const uint4 vq = *(const uint4*)(qkv + tok[rb] * 3 * C + col0);
-            uint4 vk = *(const uint4*)(qkv + tok[rb] * 3 * C + C + col0);
-            const uint4 vv = *(const uint4*)(qkv + tok[rb] * 3 * C + 2 * (int64_t)C + col0);
-            const uint4 vdo = *(const uint4*)(dout + tok[rb] * C + col0);
-            const uint4 vo = *(const uint4*)(fo + tok[rb] * C + col0);
+            const uint4 vq = ldq[rb];
+            uint4 vk = ldk[rb];
+            const uint4 vv = ldv[rb];
+            const uint4 vdo = lddo[rb];
+            const uint4 vo = ldo[rb];
             const uint32_t wq[4] = {vq.x, vq.y, vq.z, vq.w}, wdo[4] = {vdo.x, vdo.y, vdo.z, vdo.w}, wo[4] = {vo.x, vo.y, vo.z, vo.w};
             uint32_t wk[4] = {vk.x, vk.y, vk.z, vk.w};
             float ds = 0.f, sq = 0.f, sk = 0.f;
@@ -660,7 +696,8 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 
         __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ exchange the query-sum partials between the head's waves
-        __syncthreads();  // every wave is done with the V / dO tiles and with the scratch
+        lds_barrier();  // every wave is done with the V / dO tiles and with the scratch
+        if (PREFETCH && wi + slots < total_windows) issue_loads(wi + slots);  // in flight during the exchange and the stores
         float4* xch_v = (float4*)v_tile;  // 8 KB = V + dO tiles: wave 1 -> wave 0, [kt][r / 4][lane] x 4 floats (b128 accesses)
         float4* xch_k = (float4*)scr;     // 8 KB of the scratch:  wave 0 -> wave 1
         if (qt == 1) {
@@ -676,7 +713,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 for (int rg = 0; rg < 4; ++rg)
                     xch_k[(kt * 4 + rg) * 64 + lane] = make_float4(dk[kt][4 * rg], dk[kt][4 * rg + 1], dk[kt][4 * rg + 2], dk[kt][4 * rg + 3]);
         }
-        __syncthreads();
+        lds_barrier();
         if (qt == 0) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -704,7 +741,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                     }
                 }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ------------------------------------------------------------ staged results -> global (cosine: normalisation Jacobian)
 #pragma unroll
@@ -743,7 +780,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             *(uint4*)(dst + C) = xk;
             *(uint4*)(dst + 2 * (int64_t)C) = xv;
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ------------------------------------------------------------ per-workgroup partial parameter gradients
