@@ -521,8 +521,8 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     stages 0-1), ties the untuned hipBLASLt on the K = 512 shapes (and loses to the TunableOp-selected solutions bench.py
     loads) and loses the long reductions (K >= 1024: 0.96-1.06 vs 1.26 PFLOP/s).  A GELU forward epilogue pays while the
     product is HBM-bound (it has to write h AND gelu(h)); the GELU-gradient epilogue (reads h, writes once) up to K = 512."""
-    if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 32:
-        return False  # (n % 8: whole-row-segment stores; narrower outputs such as the 12-class head stay with the library)
+    if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 16:
+        return False  # (n % 8: whole-row-segment stores; the model pads the 12-class head to 16 rows)
     if OWN_GEMM == "1":
         return True
     kk = k + k2

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--workload", default="B256")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--check", action="store_true", help="compare with a float32 matmul")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
     cfg = full_cfg(wl["cfg"])
@@ -34,17 +35,18 @@ def main():
     shapes += [("final expand", a.batch * N0, cfg["embed_dim"], 4 * cfg["embed_dim"], 1)]
     tot = 0.0
     for name, M, K, N, cnt in shapes:
-        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
-        dy = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
+        dt, code = (torch.bfloat16, 1) if a.dtype == "bf16" else (torch.float32, 0)
+        x = torch.randn(M, K, device="cuda", dtype=dt)
+        dy = torch.randn(M, N, device="cuda", dtype=dt)
         dw = torch.empty(N, K, device="cuda")
         db = torch.empty(N, device="cuda")
         ws = torch.empty(int(lib.hs_linear_wgrad_workspace(M, N, K)), device="cuda")
-        th = t_of(lambda: check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), M, N, K, 0, 1, None), "wgrad"))
-        fl, hbm = 2.0 * M * K * N, 2.0 * M * (N + K)
+        th = t_of(lambda: check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), M, N, K, 0, code, None), "wgrad"))
+        fl, hbm = 2.0 * M * K * N, x.element_size() * M * (N + K)
         err = ""
         if a.check:
             Mc = min(M, 65536)
-            check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), Mc, N, K, 0, 1, None), "wgrad")
+            check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), Mc, N, K, 0, code, None), "wgrad")
             ref = dy[:Mc].float().t() @ x[:Mc].float()
             eb = float((db - dy[:Mc].float().sum(0)).abs().max())
             err = f"  max|dw err| {float((dw - ref).abs().max()):.2e} (scale {float(ref.abs().max()):.1f})  max|db err| {eb:.2e}"
