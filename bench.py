@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-shape table of the event-timed launches to stderr")
     ap.add_argument("--no-fp32-companion", action="store_true", help="skip the fp32 run of the same workload (N = 1 only)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd + loss + bwd + Adam) in one HIP graph and replay it (single GPU, no "
@@ -282,7 +283,12 @@ def main():
         if world > 1:
             out["rccl"] = res.rccl
         if res.timings:
-            out["roofline"] = roofline_of(res.timings, elapsed)
+            out["roofline"] = roofline_of(res.timings, elapsed, detail=args.kernel_table)
+            if args.kernel_table:
+                per = out["roofline"]["per_kernel"]
+                for tag, v in sorted(per.items(), key=lambda kv: -kv[1]["share_of_step"]):
+                    print(f"{1e3 * v['share_of_step'] * elapsed / args.steps:8.3f} ms/step {v['launches'] / args.steps:6.1f} x {v['avg_us']:8.1f} us "
+                          f"{v['TFLOP/s']:7.0f} TF/s {v['GB/s']:6.0f} GB/s  {tag}", file=sys.stderr)
     # the reference trains in fp32 (training/train_config.py:95 `precision: int = 32`): same workload, same batch, fp32
     # activations, a few steps -- so the reference's own precision is measured next to the bf16 headline
     if world == 1 and args.dtype == "bf16" and not args.no_fp32_companion and not args.graph and not args.tune_gemm:
@@ -299,7 +305,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_of(timings, elapsed):
+def roofline_of(timings, elapsed, detail=False):
     """attention roofline = attention flops of the timed launches (fwd + bwd) / their measured time against the
     dense bf16 MFMA peak; the HBM view of the same launches (algorithmic bytes / time against 8 TB/s) is kept beside it
     because a core-only attention kernel (32 flop/B) is bandwidth-bound by construction."""
@@ -331,8 +337,21 @@ def roofline_of(timings, elapsed):
         "avg_launch_us": 1e6 * tot_t / launches, "launches": launches, "share_of_step": tot_t / elapsed,
         "per_kernel": {tag: {"launches": a[3], "avg_us": 1e6 * a[0] / a[3], "GB/s": a[1] / a[0] / 1e9,
                              "TFLOP/s": a[2] / a[0] / 1e12, "share_of_step": a[0] / elapsed}
-                       for tag, a in agg.items()},
+                       for tag, a in (agg if detail else fold_gemm_tags(agg)).items()},
     }
+
+
+def fold_gemm_tags(agg):
+    """The GEMM launches are tagged per shape (`--kernel-table`); the JSON line carries one entry per family."""
+    out = {}
+    for tag, a in agg.items():
+        fam = "hs_gemm_nt" if tag.startswith("hs_gemm_nt") else ("library_gemm (hipBLASLt)" if tag.startswith("lib ") else tag)
+        o = out.setdefault(fam, [0.0, 0, 0, 0, {}])
+        o[0] += a[0]
+        o[1] += a[1]
+        o[2] += a[2]
+        o[3] += a[3]
+    return out
 
 
 def run_workload(ctx, dtype_name, steps, warmup, timing):

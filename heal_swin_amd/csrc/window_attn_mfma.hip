@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     constexpr bool PREFETCH = !COS;
     uint4 ldq[2], ldk[2], ldv[2], lddo[2], ldo[2];
     int64_t tok_next[2];
+    float lse_next = 0.f;
     auto issue_loads = [&](int64_t wi_l) {
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));  // (keeps the address arithmetic out of long-lived registers, see below)
@@ -452,6 +453,8 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             lddo[rb] = *(const uint4*)(dout + tok_next[rb] * C + col_l);
             ldo[rb] = *(const uint4*)(fo + tok_next[rb] * C + col_l);
         }
+        // this lane's query row of the saved log-sum-exp (needed first thing in the P / dS' phase)
+        lse_next = p.lse[((int64_t)b_l * p.nH + h) * N + j_l + qt * 32 + (lane & 31)];
     };
     auto lds_barrier = [&]() {  // workgroup barrier that orders LDS traffic only (global loads may stay in flight)
         if constexpr (PREFETCH) {
@@ -487,6 +490,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         if constexpr (!PREFETCH) issue_loads(wi);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) tok[rb] = tok_next[rb];
+        const float lse_cur = lse_next;
         if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
             const float fqn = hscale * qinv;  // d s / d (q . k^)
             const float fq2 = fqn * kLog2e;
-            const float lse2 = p.lse[((int64_t)b * p.nH + h) * N + j0 + qq] * kLog2e;
+            const float lse2 = lse_cur * kLog2e;
             const float dsum = dsum_s[g * kWs + qq];
             const DropRng rng(p, ((int64_t)b * p.nH + h) * N + j0 + qq);
             // bias (log2 domain) and, in the rare windows cut by the shift boundary, the mask: folded into one additive term
