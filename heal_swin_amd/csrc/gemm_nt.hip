@@ -72,7 +72,7 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
 
 // NSTAGE LDS stage buffers (the DMA runs NSTAGE - 1 k-steps ahead of the MFMAs); ALIAS: the epilogue's per-wave patches lie
 // inside the stage buffer that was just consumed (one extra barrier per tile) instead of in LDS of their own
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI, bool DROP>
 __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN;
@@ -259,7 +259,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.c + m0 * p.n), 0, (int)(p.c ? cbytes : 0), 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.aux + m0 * p.n), 0, (int)(p.aux ? cbytes : 0), 0x00020000);
         const ElemRng rng(p.drop_p, p.seed);
-        const bool dropping = (EPI == EPI_GELU || EPI == EPI_DGELU) && p.drop_p > 0.f;
         const bool wide = TN == 2 && (p.n & 7) == 0;  // whole-row-segment path
         const int ncol0 = n0 + wn * (BN / WN);         // first of this wave's 64 columns
         float4 bias4[TN][4];
@@ -309,43 +308,46 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                         }
                 }
             }
-            // ---- arithmetic on the accumulators
+            // ---- arithmetic on the accumulators, two elements at a time (packed fp32, hs_gelu.h).  Dropout (DROP) is a
+            // kernel instantiation of its own: next to the branch-free p = 0 arithmetic its counter hashes cost the
+            // 128 x 64 wave tile ~70 spilled registers, some of them inside the main loop
             u32x2 o1[TN][4], o2[TN][4];  // o1 -> c ; o2 -> aux (EPI_GELU only)
+            {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = ncol0 + j * 32 + 4 * half + 8 * g;
-                    float v[4] = {acc[j][i][4 * g] + bias4[j][g].x, acc[j][i][4 * g + 1] + bias4[j][g].y,
-                                  acc[j][i][4 * g + 2] + bias4[j][g].z, acc[j][i][4 * g + 3] + bias4[j][g].w};
-                    const int64_t e0 = (m0 + ml) * p.n + n;  // element index of v[0] in the [m, n] tensor (dropout counter)
-                    if (EPI == EPI_GELU) {
-                        o1[j][g] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = ncol0 + j * 32 + 4 * half + 8 * g;
+                        f32x2 v[2] = {f32x2{acc[j][i][4 * g], acc[j][i][4 * g + 1]} + f32x2{bias4[j][g].x, bias4[j][g].y},
+                                      f32x2{acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]} + f32x2{bias4[j][g].z, bias4[j][g].w}};
+                        const int64_t e0 = (m0 + ml) * p.n + n;  // element index of v[0].x in the [m, n] tensor (dropout counter)
+                        if (EPI == EPI_GELU) {
+                            o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            v[t] = gelu_f(v[t]);
-                            if (dropping) v[t] *= rng.mult(e0 + t);
-                        }
-                        o2[j][g] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    } else {
-                        if (EPI == EPI_DGELU || EPI == EPI_RESID) {
-                            const float x[4] = {__uint_as_float(xin[j][g][0] << 16), __uint_as_float(xin[j][g][0] & 0xffff0000u),
-                                                __uint_as_float(xin[j][g][1] << 16), __uint_as_float(xin[j][g][1] & 0xffff0000u)};
+                            for (int t = 0; t < 2; ++t) {
+                                v[t] = gelu2(v[t]);
+                                if (DROP) v[t] *= f32x2{rng.mult(e0 + 2 * t), rng.mult(e0 + 2 * t + 1)};
+                            }
+                            o2[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
+                        } else {
+                            if (EPI == EPI_DGELU || EPI == EPI_RESID) {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                if (EPI == EPI_DGELU) {
-                                    v[t] *= gelu_grad_f(x[t]);
-                                    if (dropping) v[t] *= rng.mult(e0 + t);
-                                } else {
-                                    v[t] += x[t];
+                                for (int t = 0; t < 2; ++t) {
+                                    const f32x2 x = {__uint_as_float(xin[j][g][t] << 16), __uint_as_float(xin[j][g][t] & 0xffff0000u)};
+                                    if (EPI == EPI_DGELU) {
+                                        v[t] *= gelu_grad2(x);
+                                        if (DROP) v[t] *= f32x2{rng.mult(e0 + 2 * t), rng.mult(e0 + 2 * t + 1)};
+                                    } else {
+                                        v[t] += x;
+                                    }
                                 }
                             }
+                            o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
                         }
-                        o1[j][g] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[j][i][4 * g + r] = 0.f;
-                }
+                        for (int r = 0; r < 4; ++r) acc[j][i][4 * g + r] = 0.f;
+                    }
+            }
             // ---- outputs
             auto emit = [&](const __amdgpu_buffer_rsrc_t& rs, const u32x2 (&o)[TN][4]) {
                 if (wide) {
@@ -453,12 +455,21 @@ int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
     const int resident = 32 * wgs_per_cu;  // workgroups per XCD in one resident round (32 CUs per XCD)
     p.blocks_per_xcd = p.per_xcd < resident ? p.per_xcd : resident;
     const dim3 grid((unsigned)(8 * p.blocks_per_xcd)), block(WM * WN * 64);
+    const bool drop = p.drop_p > 0.f;
+#define HS_GEMM_LAUNCH(E, D) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, E, D>), grid, block, 0, s, p)
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_BIAS>), grid, block, 0, s, p); break;
-        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_GELU>), grid, block, 0, s, p); break;
-        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_DGELU>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, EPI_RESID>), grid, block, 0, s, p); break;
+        case EPI_BIAS: HS_GEMM_LAUNCH(EPI_BIAS, false); break;
+        case EPI_GELU:
+            if (drop) HS_GEMM_LAUNCH(EPI_GELU, true);
+            else HS_GEMM_LAUNCH(EPI_GELU, false);
+            break;
+        case EPI_DGELU:
+            if (drop) HS_GEMM_LAUNCH(EPI_DGELU, true);
+            else HS_GEMM_LAUNCH(EPI_DGELU, false);
+            break;
+        default: HS_GEMM_LAUNCH(EPI_RESID, false); break;
     }
+#undef HS_GEMM_LAUNCH
     HS_LAUNCH_CHECK("gemm_nt");
     return HS_OK;
 }
@@ -498,20 +509,18 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     p.a2 = (const uint16_t*)a2; p.b2 = (const uint16_t*)b2; p.lda2 = lda2; p.ldb2 = ldb2; p.k2 = k2;
     p.bias = bias; p.c = (uint16_t*)c; p.aux = (uint16_t*)aux; p.m = m; p.n = n;
     p.drop_p = drop_p; p.seed = seed;
-    // tile variants (hs_gemm_nt_set_tile): 1 = 128x128, 2 stages, own patches, two workgroups per CU (the default: wins the
-    // HBM-bound shapes, epilogue VALU of one workgroup under the other's MFMAs); 2 = 256x128 x 3 stages; 3 = 256x256 x 2 stages
-    // (one 8-wave workgroup per CU, patches inside the consumed stage buffer)
     // Tile variants: 1 = 128x128 x 2 stages, own epilogue patches, two 4-wave workgroups per CU; 2 = 256x128 x 3 stages and
     // 3 = 256x256 x 2 stages: one 8-wave workgroup per CU, patches inside the consumed stage buffer.  Measured choice
     // (tools/bench_gemm_nt.py, profiles/r02_gemm_nt_vs_library.*): 256x128 x 3 is the all-round shape; 256x256 halves the
-    // L2 -> LDS fill per flop and wins wide outputs with k >= 512, but its GELU epilogue spills (128 accumulator registers);
+    // L2 -> LDS fill per flop and wins wide outputs with k >= 512 and every GELU / GELU' epilogue with n >= 512 (fewer,
+    // larger tiles: the VALU-bound epilogue is paid per output element, the barrier / drain around it per tile);
     // 128x128 when the launch would not fill the chip otherwise.  (hs_gemm_nt_set_tile forces a variant for A/B runs.)
     int variant = g_tile_variant;
     if (!variant) {
         const int64_t tiles2 = ((m + 255) / 256) * ((n + 127) / 128);
         if (tiles2 < 256)
             variant = 1;
-        else if (epilogue != EPI_GELU && n >= 1024 && k + k2 >= 512)
+        else if ((epilogue == EPI_GELU || epilogue == EPI_DGELU) ? n >= 512 : (n >= 1024 && k + k2 >= 512))
             variant = 3;
         else
             variant = 2;

@@ -514,6 +514,10 @@ def _cast_param(p, dtype):
 OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice below; "0": library GEMMs only; "1": own kernel wherever legal
 
 
+OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "256"))
+OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "512"))
+
+
 def own_gemm_ok(epi, n, k, dtype, k2=0):
     """Whether `hs_gemm_nt` should run this product (else the library GEMM + the standalone elementwise kernel).
     Measured on MI355X against hipBLASLt on the B / nside 256 / batch 8 shapes (tools/bench_gemm_nt.py,
@@ -527,9 +531,9 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
         return True
     kk = k + k2
     if epi == _lib.HS_EPI_DGELU:
-        return kk <= 512
+        return kk <= OWN_DGELU_MAX_K
     if epi == _lib.HS_EPI_GELU:
-        return kk <= 256
+        return kk <= OWN_GELU_MAX_K
     return kk <= 128 or n <= 128 or (n <= 256 and kk <= 256)
 
 
