@@ -38,6 +38,9 @@ _SIGNATURES = {
     "hs_window_attn_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
                            c_int, c_i64, c_int, c_int, c_int, c_uint, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_gather_rows": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr],
+    "hs_pix2ang_nest": [c_int, c_i64, c_i64, c_ptr, c_ptr],
+    "hs_sample_bilinear_u8": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
+    "hs_sample_mask_u8": [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr],
     "hs_gelu_fwd": [c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_gelu_bwd": [c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_residual_drop": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],

@@ -295,4 +295,41 @@ int hs_attn_mask_from_labels(const uint8_t* labels, int64_t n, int window_size, 
     return HS_OK;
 }
 
+/* healpy.pixelfunc.pix2ang(nside, ipix, nest=True) for ipix = first .. first + count - 1 (reference
+ * data/segmentation/project_on_s2.py:347-354): pixel centres after the HEALPix C++ pix2loc -- polar caps
+ * z = +-(1 - nr^2 fact2), belt z = (2 nside - jr) fact1, phi = (pi/4) (jpll nr + ix - iy) / nr, theta = acos z or
+ * atan2(sqrt(tmp (2 - tmp)), z) where |z| > 0.99.  Same operation order as oracle/healpix.py:pix2ang_nest. */
+int hs_pix2ang_nest(int nside, int64_t first, int64_t count, double* theta, double* phi) {
+    if (int st = check_nside(nside)) return st;
+    const int64_t npix = 12 * (int64_t)nside * nside;
+    HS_CHECK_ARG(theta && phi && first >= 0 && count >= 0 && first + count <= npix, "pixel range outside [0, 12 nside^2)");
+    const double fact2 = 4.0 / (double)npix, fact1 = (double)(nside << 1) * fact2, halfpi = 0.5 * M_PI;
+    for (int64_t k = 0; k < count; ++k) {
+        const Xyf c = nest_to_xyf(nside, first + k);
+        const int64_t jr = (int64_t)kJrll[c.face] * nside - c.ix - c.iy - 1;
+        int64_t nr;
+        double z, th;
+        if (jr < nside) {
+            nr = jr;
+            const double tmp = (double)(nr * nr) * fact2;
+            z = 1.0 - tmp;
+            th = z > 0.99 ? std::atan2(std::sqrt(tmp * (2.0 - tmp)), z) : std::acos(z);
+        } else if (jr > 3 * (int64_t)nside) {
+            nr = 4 * (int64_t)nside - jr;
+            const double tmp = (double)(nr * nr) * fact2;
+            z = tmp - 1.0;
+            th = z < -0.99 ? std::atan2(std::sqrt(tmp * (2.0 - tmp)), z) : std::acos(z);
+        } else {
+            nr = nside;
+            z = (double)(2 * (int64_t)nside - jr) * fact1;
+            th = std::acos(z);
+        }
+        int64_t t = (int64_t)kJpll[c.face] * nr + c.ix - c.iy;
+        if (t < 0) t += 8 * nr;
+        theta[k] = th;
+        phi[k] = nr == nside ? 0.75 * halfpi * (double)t * fact1 : (0.5 * halfpi * (double)t) / (double)nr;
+    }
+    return HS_OK;
+}
+
 }  // extern "C"

@@ -1,8 +1,9 @@
 """Input side of the hot path (first half): the reference's on-disk sample format and the hand-over to the
 GPU.  A projected WoodScape sample is one `.npz` with `hp_img` uint8 [3, Npix] (RGB on the first `base_pix` HEALPix base
 pixels, nested order) and `hp_mask` uint8 [Npix] (class ids), written at heal_swin/data/segmentation/project_on_s2.py:365-372
-and read back at heal_swin/data/segmentation/hp_datasets.py:92-98.  The fisheye -> sphere projection itself (project_on_s2.py,
-needs `pix2ang`) is out of scope; samples are consumed (or synthesised for tests / benchmarks) in this format.
+and read back at heal_swin/data/segmentation/hp_datasets.py:92-98.  The fisheye -> sphere projection that produces such samples is
+heal_swin_amd/projection.py (`HPProjector`, HIP sampling kernels); here they are consumed (or synthesised for tests /
+benchmarks) in this format.
 
 The model takes the uint8 batch as it is: `SwinHPTransformerSys.forward` converts to the activation dtype on the GPU, so the
 3-bytes-per-pixel tensor is what crosses PCIe (the reference's caller does `.float()` on the host side of the model call,

@@ -515,7 +515,7 @@ OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice bel
 
 
 OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "256"))
-OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "512"))
+OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "1024"))
 
 
 def own_gemm_ok(epi, n, k, dtype, k2=0):
@@ -524,7 +524,10 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     profiles/r02_gemm_nt_vs_library.*): the own kernel wins where the product is HBM-bound (short reductions, narrow outputs:
     stages 0-1), ties the untuned hipBLASLt on the K = 512 shapes (and loses to the TunableOp-selected solutions bench.py
     loads) and loses the long reductions (K >= 1024: 0.96-1.06 vs 1.26 PFLOP/s).  A GELU forward epilogue pays while the
-    product is HBM-bound (it has to write h AND gelu(h)); the GELU-gradient epilogue (reads h, writes once) up to K = 512."""
+    product is HBM-bound (it has to write h AND gelu(h): at K = 512 the 256x256 tile needs 355-368 us against 197 us tuned
+    library GEMM + 141 us standalone GELU pass); the GELU-gradient epilogue (reads h, writes once) wins at every stage
+    (K = 1024: 265 us against 175-188 us library GEMM + 105 us GELU' pass).  HS_OWN_GELU_MAX_K / HS_OWN_DGELU_MAX_K move the
+    two thresholds for A/B runs."""
     if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 16:
         return False  # (n % 8: whole-row-segment stores; the model pads the 12-class head to 16 rows)
     if OWN_GEMM == "1":

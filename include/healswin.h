@@ -321,6 +321,25 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
                uint64_t seed, int dtype, void* stream);
 int hs_gemm_nt_set_tile(int variant);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fisheye image -> HEALPix projection, the input pipeline in front of the model.  Replaces, per image, the
+ * sampling of data/segmentation/project_on_s2.py:344-372; the coordinate table (u, v) of a calibration is built once on
+ * the host (heal_swin_amd/projection.py, the reference's project_s2_points_to_img :141-183) and stays resident.
+ *   hs_pix2ang_nest     [host] healpy.pixelfunc.pix2ang(nside, ipix, nest=True) (:350) for ipix = first .. first+count-1:
+ *                       theta, phi [host] f64[count].
+ *   hs_sample_bilinear_u8   sample_bilinear(img, rx, ry).astype(np.uint8) (:38-73, :361): img [dev] u8[batch, channels,
+ *                       height, width]; rx (along height), ry (along width) [dev] f64[n]; out [dev] u8[batch, channels, n].
+ *                       float64, the reference's operation order, no FMA contraction: bit-exact.  Integer coordinates give 0
+ *                       (both of the reference's weights vanish), neighbours outside the image contribute 0.
+ *   hs_sample_mask_u8   sample_mask(mask, rx, ry, background) (:76-80, :362): nearest pixel by round-half-to-even,
+ *                       outside the image -> background.  mask [dev] u8[batch, height, width]; out [dev] u8[batch, n].
+ * ---------------------------------------------------------------------------------------------- */
+int hs_pix2ang_nest(int nside, int64_t first, int64_t count, double* theta, double* phi);
+int hs_sample_bilinear_u8(const void* img, int batch, int channels, int height, int width, const double* rx, const double* ry,
+                          int64_t n, void* out, void* stream);
+int hs_sample_mask_u8(const void* mask, int batch, int height, int width, const double* rx, const double* ry, int64_t n,
+                      int background, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

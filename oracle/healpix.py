@@ -160,3 +160,40 @@ def ring2nest(nside, ipix):
     """Restates healpy.pixelfunc.ring2nest (used at reference hp_shifting.py:329)."""
     ix, iy, face = ring2xyf(nside, ipix)
     return xyf2nest(nside, ix, iy, face)
+
+
+def pix2ang_nest(nside, ipix):
+    """(theta, phi) of the centres of nested pixels, float64: restates healpy.pixelfunc.pix2ang(nside, ipix, nest=True)
+    (reference data/segmentation/project_on_s2.py:350) after the HEALPix C++ `T_Healpix_Base::pix2loc`:
+        ring jr = jrll[face] nside - ix - iy - 1;   polar caps: z = +-(1 - nr^2 fact2), nr = jr or 4 nside - jr;
+        belt: z = (2 nside - jr) fact1;   phi = (pi/4) (jpll[face] nr + ix - iy) / nr;   theta = acos z, or
+        atan2(sqrt(tmp (2 - tmp)), z) with tmp = nr^2 fact2 where |z| > 0.99 (the library's accurate form near the poles).
+    PARITY UNPINNED against healpy (absent here); pinned by healpy's docstring examples (tests/test_projection.py) and by the
+    independent ring-centre formulas of tests/test_healpix_geometry.py."""
+    nside = _check_nside(nside)
+    ipix = np.asarray(ipix, dtype=np.int64)
+    npix = 12 * nside * nside
+    if ipix.size and (ipix.min() < 0 or ipix.max() >= npix):
+        raise ValueError("pixel index out of range")
+    ix, iy, face = nest2xyf(nside, ipix)
+    fact2 = 4.0 / npix
+    fact1 = (nside << 1) * fact2
+    jr = _JRLL[face] * nside - ix - iy - 1
+    north = jr < nside
+    south = jr > 3 * nside
+    nr = np.where(north, jr, np.where(south, 4 * nside - jr, nside))
+    tmp = (nr * nr).astype(np.float64) * fact2
+    z = np.where(north, 1.0 - tmp, np.where(south, tmp - 1.0, (2 * nside - jr).astype(np.float64) * fact1))
+    sth = np.sqrt(tmp * (2.0 - tmp))
+    near_pole = (north & (z > 0.99)) | (south & (z < -0.99))
+    theta = np.where(near_pole, np.arctan2(sth, z), np.arccos(z))
+    t = _JPLL[face] * nr + ix - iy
+    t = np.where(t < 0, t + 8 * nr, t)
+    halfpi = 0.5 * np.pi
+    phi = np.where(nr == nside, 0.75 * halfpi * t.astype(np.float64) * fact1, (0.5 * halfpi * t.astype(np.float64)) / nr)
+    return theta, phi
+
+
+def pix2ang_ring(nside, ipix):
+    """healpy.pixelfunc.pix2ang(nside, ipix) in the (default) ring scheme, through ring2nest."""
+    return pix2ang_nest(nside, ring2nest(nside, ipix))

@@ -292,10 +292,87 @@ def make_losses():
     print("losses.npz", len(out), "arrays")
 
 
+# ------------------------------------------------------------------ fisheye -> HEALPix projection
+PROJ_CALS = {
+    # WoodScape-like calibrations (polynomial fisheye model, quaternion scalar last); the small ones scale the optics to small
+    # synthetic images so that the fixtures stay small
+    "fv_966x1280": dict(name="FV", intrinsic=dict(aspect_ratio=1.0, cx_offset=3.942, cy_offset=-0.472, width=1280.0, height=966.0,
+                                                  poly_order=4, k1=339.749, k2=-31.988, k3=48.275, k4=-7.201),
+                        extrinsic=dict(quaternion=[0.5946970238045494, -0.5837953694518585, 0.39063952590941586, -0.39195666481783994])),
+    "mvl_96x128": dict(name="MVL", intrinsic=dict(aspect_ratio=1.0005, cx_offset=0.731, cy_offset=-0.613, width=128.0, height=96.0,
+                                                  poly_order=4, k1=33.97, k2=-3.2, k3=4.83, k4=-0.72),
+                       extrinsic=dict(quaternion=[0.1215, -0.8817, 0.4417, 0.1153])),
+    "rv_60x80": dict(name="RV", intrinsic=dict(aspect_ratio=0.9991, cx_offset=-1.25, cy_offset=0.75, width=80.0, height=60.0,
+                                               poly_order=4, k1=21.2, k2=-2.0, k3=3.0, k4=-0.45),
+                     extrinsic=dict(quaternion=[-0.4057, -0.4038, 0.5817, 0.5789])),
+}
+
+
+def _import_projection():
+    """project_on_s2 imports the dataset / plotting stack (torchvision, matplotlib paths ...) at module level; none of it is
+    used by the four functions exercised here, so those modules are replaced by empty ones for the import."""
+    import types
+
+    for name in ("heal_swin.data.segmentation.flat_datasets", "heal_swin.utils.utils", "heal_swin.utils.get_paths",
+                 "heal_swin.utils.healpy_utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import heal_swin.data.segmentation as DS
+    import heal_swin.utils as U
+
+    DS.flat_datasets = sys.modules["heal_swin.data.segmentation.flat_datasets"]
+    for n in ("utils", "get_paths", "healpy_utils"):
+        setattr(U, n, sys.modules["heal_swin.utils." + n])
+    import heal_swin.data.segmentation.project_on_s2 as P
+
+    return P
+
+
+def make_projection():
+    """Outputs of the reference's project_s2_points_to_img / sample_bilinear / sample_mask (project_on_s2.py:38-80, :141-183)
+    on synthetic images.  The grid (theta, phi) is an INPUT here (healpy's pix2ang is absent: the grid comes from
+    oracle/healpix.py:pix2ang_nest and is stored with the case)."""
+    from oracle.healpix import pix2ang_nest
+
+    P = _import_projection()
+    rng = np.random.default_rng(20260929)
+    out = {}
+    for key, nside, base_pix, rotate in (("mvl_96x128", 16, 8, False), ("mvl_96x128", 16, 8, True), ("rv_60x80", 8, 12, True),
+                                         ("rv_60x80", 32, 8, False), ("fv_966x1280", 32, 8, True)):
+        cal = PROJ_CALS[key]
+        H, W = int(cal["intrinsic"]["height"]), int(cal["intrinsic"]["width"])
+        theta, phi = pix2ang_nest(nside, np.arange(nside * nside * base_pix))
+        tag = f"{key}/n{nside}_bp{base_pix}_{'rot' if rotate else 'plain'}"
+        if H <= 128:
+            img = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+            img[:, : H // 3, : W // 3] = 200  # a constant patch: the reference's truncation of c (1 - eps) to c - 1 shows here
+            mask = rng.integers(0, 10, (H, W), dtype=np.uint8)
+            out[tag + "/img"], out[tag + "/mask"] = img, mask
+        else:  # the full-size case stores a seed instead of a 3.7 MB image
+            r2 = np.random.default_rng(7)
+            img = r2.integers(0, 256, (3, H, W), dtype=np.uint8)
+            mask = r2.integers(0, 10, (H, W), dtype=np.uint8)
+            out[tag + "/img_seed"] = np.array(7)
+        u, v = P.project_s2_points_to_img(theta, phi, cal, rotate)
+        out[tag + "/theta"], out[tag + "/phi"], out[tag + "/u"], out[tag + "/v"] = theta, phi, u, v
+        out[tag + "/hp_img"] = P.sample_bilinear(torch.from_numpy(img), v, u).astype(np.uint8)
+        out[tag + "/hp_mask"] = P.sample_mask(torch.from_numpy(mask), v, u, 3)
+    # sampling edge cases on hand-made coordinates: integer coordinates (both weights zero), the image border, far outside,
+    # exact .5 (round half to even in the mask), NaN
+    img = rng.integers(1, 256, (3, 7, 9), dtype=np.uint8)
+    mask = rng.integers(0, 10, (7, 9), dtype=np.uint8)
+    rx = np.array([0.0, 2.0, 2.5, 3.5, 6.0, 6.2, -0.3, -1.0, 5.999999, 1e9, -1e9, 0.5, 1.5, np.nan, 3.25, 6.5, 2.0])
+    ry = np.array([0.0, 3.0, 0.5, 1.5, 8.0, 8.4, 0.4, 2.0, 7.999999, 1.0, 1.0, 8.5, -0.5, 1.0, np.nan, 7.5, 4.75])
+    out["edge/img"], out["edge/mask"], out["edge/rx"], out["edge/ry"] = img, mask, rx, ry
+    out["edge/bilinear"] = P.sample_bilinear(torch.from_numpy(img), rx, ry)  # float64, before the uint8 truncation
+    out["edge/hp_mask"] = P.sample_mask(torch.from_numpy(mask), rx, ry, 5)
+    np.savez_compressed(os.path.join(HERE, "projection.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     only = [a for a in sys.argv[1:] if not a.startswith("-")]  # e.g. `make_golden.py losses` regenerates one file
-    for name, fn in (("tables", make_tables), ("modules", make_modules), ("models", make_models), ("losses", make_losses)):
+    for name, fn in (("tables", make_tables), ("modules", make_modules), ("models", make_models), ("losses", make_losses),
+                     ("projection", make_projection)):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(HERE)):
