@@ -39,6 +39,9 @@ _SIGNATURES = {
                            c_int, c_i64, c_int, c_int, c_int, c_uint, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_gather_rows": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr],
     "hs_pix2ang_nest": [c_int, c_i64, c_i64, c_ptr, c_ptr],
+    "hs_ln_head_supported": [c_int, c_int, c_int],
+    "hs_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
+    "hs_ln_head_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
     "hs_sample_bilinear_u8": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "hs_sample_mask_u8": [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr],
     "hs_gelu_fwd": [c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
@@ -74,6 +77,7 @@ _OTHER = {
     "hs_device_count": ([], c_int),
     "hs_layernorm_bwd_workspace": ([c_i64, c_int], c_i64),
     "hs_seg_ce_partials": ([c_i64, c_i64], c_i64),
+    "hs_ln_head_partials": ([c_i64], c_i64),
     "hs_linear_wgrad_workspace": ([c_i64, c_int, c_int], c_i64),
     "hs_window_attn_bwd_workspace": ([c_int, c_i64, c_int, c_int, c_int, c_int], c_i64),
 }

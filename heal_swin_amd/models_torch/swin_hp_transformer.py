@@ -538,9 +538,17 @@ class UnetDecoder(nn.Module):
             x = layer_up(x)
             if dbg:
                 print(f"feature shape after decoder layer {inx}: {x.size()}")
-        x = self.up(self.norm_up(x))  # B, Npix, C
         w = self.output.weight  # 1x1 conv without bias (ref :756-761) as the [f_out, C] matrix it is (ops.LinearFn)
         f_out = w.shape[0]
+        up = self.up
+        if isinstance(up.norm, HSLayerNorm) and ops.ln_head_ok(x, up.dim, f_out):
+            # the tail's LayerNorm and the class head in one pass over the expanded rows (hs_ln_head_*): the normalised
+            # [B, Npix, C] tensor is neither written nor kept for the backward
+            x = up.expand(self.norm_up(x))  # B, N0, p * C: row (b, n) holds the p children of token n back to back
+            B, N0, _ = x.shape
+            x = ops.ln_head(x.reshape(B * N0 * up.patch_size, up.dim), up.norm.weight, up.norm.bias, w)
+            return x.view(B, N0 * up.patch_size, -1)[..., :f_out].transpose(1, 2)  # B, f_out, Npix
+        x = up(self.norm_up(x))  # B, Npix, C
         if x.dtype == torch.bfloat16 and f_out % 8 and f_out > 8:
             # 12 classes: rows padded to 16 so that the input gradient (K = 12 -> 16) runs in hs_gemm_nt: 0.33 ms instead of the
             # library's 0.85 ms; the caller sees the [.., :f_out] view (the loss kernels read logits through their strides)

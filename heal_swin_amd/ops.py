@@ -713,6 +713,79 @@ def linear_passthrough(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias, True)
 
 
+FUSED_LN_HEAD = os.environ.get("HS_FUSED_LN_HEAD", "1") != "0"
+
+
+def ln_head_ok(x, width, n_classes):
+    """Whether `ln_head` (hs_ln_head_*) runs this decoder tail: bf16 rows on the GPU, C in 64..256 (multiple of 32), <= 16 classes."""
+    return bool(FUSED_LN_HEAD and x.is_cuda and x.dtype == torch.bfloat16 and
+                lib.hs_ln_head_supported(int(width), int(n_classes), _lib.HS_BF16))
+
+
+class LnHeadFn(torch.autograd.Function):
+    """LayerNorm(C) + bias-free 1x1 head as one pass over the rows, forward and backward (reference: the `norm` of
+    FinalPatchExpand_X4, swin_hp_transformer.py:448-452, followed by `self.output`, :785-788): the normalised [rows, C] tensor is
+    neither written nor saved.  Returns the padded logits [rows, 16] (columns >= f_out are zero); backward takes their gradient.
+    Parameter gradients come from ONE weight-gradient product over the raw rows (see csrc/ln_head.hip):
+        X[k, c] = sum_rows dlogits[row, k] xhat[row, c] = hs_linear_wgrad(dlogits * rstd, y)[k, c] - sum_rows dlogits rstd mean
+        dW = gamma X + beta u,   dgamma_c = sum_k W X,   dbeta_c = sum_k W u,   u[k] = sum_rows dlogits[row, k]."""
+
+    KP = 16
+
+    @staticmethod
+    def forward(ctx, y2, gamma, beta, weight):
+        _require_gpu(y2, gamma, beta, weight)
+        rows, C = y2.shape
+        f_out = weight.shape[0]
+        w = weight.detach().reshape(f_out, C).float()
+        g32, b32 = gamma.detach().float(), beta.detach().float()
+        wfold = torch.zeros((32, C), dtype=torch.bfloat16, device=y2.device)
+        wfold[:f_out] = (w * g32).to(torch.bfloat16)
+        bvec = torch.zeros(32, dtype=torch.float32, device=y2.device)
+        bvec[:f_out] = w @ b32
+        logits = torch.empty((rows, LnHeadFn.KP), dtype=torch.bfloat16, device=y2.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=y2.device)
+        rstd = torch.empty_like(mean)
+        with _timed("ln_head_fwd", y2.device, 2 * rows * (C + LnHeadFn.KP) + 8 * rows, 2 * rows * C * 32):
+            check(lib.hs_ln_head_fwd(ptr(y2), ptr(wfold), ptr(bvec), ptr(logits), ptr(mean), ptr(rstd), rows, C, _lib.HS_BF16,
+                                     stream_ptr(y2.device)), "hs_ln_head_fwd")
+        ctx.save_for_backward(y2, mean, rstd, gamma, beta, weight)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        y2, mean, rstd, gamma, beta, weight = ctx.saved_tensors
+        rows, C = y2.shape
+        f_out, KP = weight.shape[0], LnHeadFn.KP
+        dev = y2.device
+        w = weight.detach().reshape(f_out, C).float()
+        g32, b32 = gamma.detach().float(), beta.detach().float()
+        afold = torch.zeros((C, KP), dtype=torch.bfloat16, device=dev)
+        afold[:, :f_out] = (w * g32).t().to(torch.bfloat16)
+        dlogits = dlogits.to(torch.bfloat16).contiguous()
+        dy = torch.empty_like(y2)
+        dprime = torch.empty_like(dlogits)
+        part = torch.empty((int(lib.hs_ln_head_partials(rows)), 32), dtype=torch.float32, device=dev)
+        with _timed("ln_head_bwd", dev, 2 * rows * (2 * C + 2 * KP) + 8 * rows, 2 * rows * C * KP):
+            check(lib.hs_ln_head_bwd(ptr(y2), ptr(mean), ptr(rstd), ptr(dlogits), ptr(afold), ptr(dy), ptr(dprime), ptr(part), rows, C,
+                                     _lib.HS_BF16, stream_ptr(dev)), "hs_ln_head_bwd")
+        ut = part.sum(0)
+        u, t = ut[:f_out], ut[KP:KP + f_out]
+        dgamma = dbeta = dw = None
+        if any(ctx.needs_input_grad[1:]):
+            G = LinearFn._wgrad_hip(dprime, y2, KP, C, False)[0][:f_out]
+            X = G - t[:, None]
+            dw = (g32 * X + b32 * u[:, None]).to(weight.dtype).view(weight.shape)
+            dgamma = (w * X).sum(0).to(gamma.dtype)
+            dbeta = (w * u[:, None]).sum(0).to(beta.dtype)
+        return (dy if ctx.needs_input_grad[0] else None), dgamma, dbeta, dw
+
+
+def ln_head(y2, gamma, beta, weight):
+    """Padded logits [rows, 16] of head(LayerNorm(y2)); the caller slices [..., :f_out]."""
+    return LnHeadFn.apply(y2, gamma, beta, weight)
+
+
 class MlpFn(torch.autograd.Function):
     """fc1 -> GELU(erf) -> dropout -> fc2 (reference Mlp.forward, swin_hp_transformer.py:38-44, without the output dropout,
     which the caller fuses into the next norm kernel) as ONE autograd node, so that the elementwise steps ride on the GEMMs

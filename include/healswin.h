@@ -340,6 +340,26 @@ int hs_sample_bilinear_u8(const void* img, int batch, int channels, int height, 
 int hs_sample_mask_u8(const void* mask, int batch, int height, int width, const double* rx, const double* ry, int64_t n,
                       int background, void* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Decoder tail: LayerNorm(C) of FinalPatchExpand_X4 + the 1x1 class head in one pass, so that the normalised
+ * [B, 4 N0, C] tensor is never written.  Replaces `self.norm(x)` (models_torch/swin_hp_transformer.py:448-452) followed by
+ * `self.output(x)` (:756-761, :785-788) and their backward.  bf16 rows, C in {64, 96, ..., 256}, <= 16 classes.
+ *   y [dev] bf16[rows, C] (the expanded rows); logits [dev] bf16[rows, 16] (columns >= n_classes are 0).
+ *   forward : wfold [dev] bf16[32, C] = gamma * W[k, :] (rows >= n_classes zero), bvec [dev] f32[32] = sum_c beta_c W[k, c];
+ *             mean, rstd [dev] f32[rows] are saved for the backward.
+ *   backward: afold [dev] bf16[C, 16] = (gamma * W)^T (columns >= n_classes zero); dlogits [dev] bf16[rows, 16];
+ *             dy [dev] bf16[rows, C] = LayerNorm input gradient; dprime [dev] bf16[rows, 16] = dlogits * rstd;
+ *             partials [dev] f32[hs_ln_head_partials(rows), 32]: per-wave sums u[k] = sum dlogits (0..15) and
+ *             t[k] = sum dprime * mean (16..31).  With X = hs_linear_wgrad(dprime, y) - t:  dW = gamma X + beta u,
+ *             dgamma_c = sum_k W X, dbeta_c = sum_k W u   (heal_swin_amd/ops.py:LnHeadFn).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_ln_head_supported(int width, int n_classes, int dtype);
+int64_t hs_ln_head_partials(int64_t rows);
+int hs_ln_head_fwd(const void* y, const void* wfold, const float* bvec, void* logits, float* mean, float* rstd, int64_t rows,
+                   int width, int dtype, void* stream);
+int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const void* dlogits, const void* afold, void* dy,
+                   void* dprime, float* partials, int64_t rows, int width, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+"""Fused decoder tail `hs_ln_head_fwd/bwd` (LayerNorm(C) + 1x1 class head) against an fp32 torch composition of
+the reference's two modules (nn.LayerNorm, swin_hp_transformer.py:448-452; Conv1d(C, f_out, 1, bias=False), :785-788):
+logits and every gradient (rows, gamma, beta, head weight), bf16 tolerance 1e-2 / 3e-2 of the tensor's scale."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests._util import GRAD_TOL, TOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def reference(y, gamma, beta, w, dlogits):
+    y = y.float().detach().requires_grad_(True)
+    gamma, beta, w = (t.detach().clone().requires_grad_(True) for t in (gamma, beta, w))
+    out = F.linear(F.layer_norm(y, (y.shape[-1],), gamma, beta, 1e-5), w)
+    out.backward(dlogits.float())
+    return out, y.grad, gamma.grad, beta.grad, w.grad
+
+
+@pytest.mark.parametrize("rows,C,f_out", [(4096, 128, 12), (1000, 96, 12), (33, 64, 5), (2050, 256, 16), (40000, 128, 1)])
+def test_ln_head_matches_the_composition(rows, C, f_out):
+    from heal_swin_amd import ops
+
+    torch.manual_seed(rows + C)
+    dev = "cuda"
+    y = (torch.randn(rows, C, device=dev) * 1.7 + 0.6 * torch.randn(rows, 1, device=dev) + 0.3).to(torch.bfloat16)
+    gamma = (1 + 0.3 * torch.randn(C, device=dev)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, device=dev)).requires_grad_(True)
+    w = (torch.randn(f_out, C, 1, device=dev) * C ** -0.5).requires_grad_(True)
+    dlog = torch.randn(rows, f_out, device=dev).to(torch.bfloat16)
+    assert ops.ln_head_ok(y, C, f_out)
+    yq = y.clone().requires_grad_(True)
+    out = ops.ln_head(yq, gamma, beta, w)
+    assert out.shape == (rows, 16) and not out[:, f_out:].any()
+    out[:, :f_out].backward(dlog)
+    ref_out, ref_dy, ref_dg, ref_db, ref_dw = reference(y, gamma, beta, w.reshape(f_out, C), dlog)
+    tag = f"ln_head[{rows}x{C}->{f_out}]"
+    assert_close(out[:, :f_out], ref_out, TOL[torch.bfloat16], tag + " logits")
+    assert_close(yq.grad, ref_dy, GRAD_TOL[torch.bfloat16], tag + " dy")
+    assert_close(gamma.grad, ref_dg, GRAD_TOL[torch.bfloat16], tag + " dgamma")
+    assert_close(beta.grad, ref_db, GRAD_TOL[torch.bfloat16], tag + " dbeta")
+    assert_close(w.grad.reshape(f_out, C), ref_dw, GRAD_TOL[torch.bfloat16], tag + " dW")
+
+
+def test_ln_head_with_a_large_row_mean():
+    """Rows whose mean is 50x their spread: the weight-gradient algebra subtracts sum(D' mean) from sum(D' y) -- the
+    cancellation must stay harmless in fp32."""
+    from heal_swin_amd import ops
+
+    torch.manual_seed(3)
+    rows, C, f_out = 8192, 128, 12
+    y = (torch.randn(rows, C, device="cuda") * 0.1 + 5.0).to(torch.bfloat16)
+    gamma = torch.ones(C, device="cuda", requires_grad=True)
+    beta = torch.zeros(C, device="cuda", requires_grad=True)
+    w = (torch.randn(f_out, C, device="cuda") * C ** -0.5).requires_grad_(True)
+    dlog = torch.randn(rows, f_out, device="cuda").to(torch.bfloat16)
+    yq = y.clone().requires_grad_(True)
+    ops.ln_head(yq, gamma, beta, w)[:, :f_out].backward(dlog)
+    _, ref_dy, ref_dg, ref_db, ref_dw = reference(y, gamma, beta, w, dlog)
+    assert_close(yq.grad, ref_dy, GRAD_TOL[torch.bfloat16], "ln_head large-mean dy")
+    assert_close(w.grad, ref_dw, GRAD_TOL[torch.bfloat16], "ln_head large-mean dW")
+    assert_close(gamma.grad, ref_dg, GRAD_TOL[torch.bfloat16], "ln_head large-mean dgamma")
+
+
+def test_model_tail_uses_the_fused_kernels_and_matches_the_unfused_path():
+    """The whole model with and without the fused tail (HS_FUSED_LN_HEAD): same logits and gradients to bf16 accuracy."""
+    import bench
+    from heal_swin_amd import ops
+    from heal_swin_amd.losses import seg_loss
+
+    wl = bench.WORKLOADS["T128"]
+    model, cfg, spec = bench.build_model(wl, nside=64)
+    model = model.cuda().train()
+    model.compute_dtype = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randint(0, 256, (2, 3, spec["dim_in"]), generator=g, device="cuda", dtype=torch.uint8)
+    labels = torch.randint(0, 12, (2, spec["dim_in"]), generator=g, device="cuda", dtype=torch.uint8)
+    res = {}
+    for fused in (True, False):
+        ops.FUSED_LN_HEAD = fused
+        try:
+            model.zero_grad(set_to_none=True)
+            logits = model(x.float())
+            seg_loss(logits, labels).backward()
+            res[fused] = (logits.detach().float().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            ops.FUSED_LN_HEAD = True
+    assert_close(res[True][0], res[False][0], TOL[torch.bfloat16], "fused tail: model logits vs unfused")
+    for n in ("decoder.up.norm.weight", "decoder.up.norm.bias", "decoder.output.weight", "decoder.up.expand.weight", "encoder.patch_embed.proj.weight"):
+        key = n if n in res[True][1] else [k for k in res[True][1] if k.endswith(n.split(".", 1)[1])][0]
+        assert_close(res[True][1][key], res[False][1][key], 0.05, f"fused tail: grad {key} vs unfused")
