@@ -93,6 +93,97 @@ __global__ void __launch_bounds__(256) seg_ce_bwd_kernel(CeArgs a, const float* 
     }
 }
 
+// ---- fast path: bf16 logits with the K classes of a pixel contiguous inside a 16-element (32-byte) row -- the model's own
+// output layout (the head is padded to 16 classes).  The generic kernels above issue 3 K two-byte loads per pixel and run
+// at ~1 TB/s; here a pixel is two 16-byte loads, the K logits stay in registers, and the gradient leaves as whole vectors.
+constexpr int kRow = 16;
+
+__device__ __forceinline__ void load_row16(const void* logits, int64_t base, float* z) {
+    const uint4 a = *(const uint4*)((const uint16_t*)logits + base), b = *(const uint4*)((const uint16_t*)logits + base + 8);
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        z[2 * i] = __uint_as_float(w[i] << 16);
+        z[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ float row_lse(const float* z, int K, float* zy, int64_t y) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kRow; ++c)
+        if (c < K) m = fmaxf(m, z[c]);
+    float s = 0.f, pick = 0.f;
+#pragma unroll
+    for (int c = 0; c < kRow; ++c)
+        if (c < K) {
+            s += expf(z[c] - m);
+            if (c == y) pick = z[c];
+        }
+    *zy = pick;
+    return m + logf(s);
+}
+
+__global__ void __launch_bounds__(256) seg_ce_fwd_row16_kernel(CeArgs a, float* __restrict__ partials) {
+    const int64_t total = a.batch * a.npix;
+    float num = 0.f, den = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t y = load_label(a, i);
+        if (y == a.ignore_index || (uint64_t)y >= (uint64_t)a.K) continue;
+        const int64_t b = i / a.npix, px = i - b * a.npix;
+        float z[kRow], zy;
+        load_row16(a.logits, b * a.sb + px * kRow, z);
+        const float w = a.weights ? a.weights[y] : 1.f;
+        const float lse = row_lse(z, a.K, &zy, y);
+        num = fmaf(w, lse - zy, num);
+        den += w;
+    }
+    __shared__ float red[2][4];
+    num = wave_sum(num);
+    den = wave_sum(den);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wave] = num;
+        red[1][wave] = den;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partials[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// writes columns 0 .. K-1 only (K a multiple of 4: 8-byte groups), so a destination whose rows interleave with other data
+// is left alone exactly as by the generic kernel
+__global__ void __launch_bounds__(256) seg_ce_bwd_row16_kernel(CeArgs a, const float* __restrict__ scale_p, void* __restrict__ dlogits,
+                                                               int64_t db) {
+    const int64_t total = a.batch * a.npix;
+    const float scale = scale_p[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t y = load_label(a, i);
+        const int64_t b = i / a.npix, px = i - b * a.npix;
+        float d[kRow];
+#pragma unroll
+        for (int c = 0; c < kRow; ++c) d[c] = 0.f;
+        if (!(y == a.ignore_index || (uint64_t)y >= (uint64_t)a.K)) {
+            float z[kRow], zy;
+            load_row16(a.logits, b * a.sb + px * kRow, z);
+            const float g = scale * (a.weights ? a.weights[y] : 1.f);
+            const float lse = row_lse(z, a.K, &zy, y);
+#pragma unroll
+            for (int c = 0; c < kRow; ++c)
+                if (c < a.K) d[c] = g * (expf(z[c] - lse) - (c == y ? 1.f : 0.f));
+        }
+        uint16_t* o = (uint16_t*)dlogits + b * db + px * kRow;
+#pragma unroll
+        for (int q = 0; q < kRow / 4; ++q)
+            if (4 * q < a.K) *(uint2*)(o + 4 * q) = make_uint2(pack_bf16x2(d[4 * q], d[4 * q + 1]), pack_bf16x2(d[4 * q + 2], d[4 * q + 3]));
+    }
+}
+
+bool row16_layout(const void* ptr, int64_t sb, int64_t sk, int64_t sp, int K, int dtype) {
+    return dtype == HS_BF16 && sk == 1 && sp == kRow && K <= kRow && K % 4 == 0 && sb % 8 == 0 && ((uintptr_t)ptr & 15) == 0;
+}
+
 int check_args(const CeArgs& a, int dtype) {
     HS_CHECK_ARG(a.logits && a.labels, "null pointer");
     HS_CHECK_ARG(a.batch > 0 && a.npix > 0, "bad shape");
@@ -123,7 +214,9 @@ int hs_seg_ce_fwd(const void* logits, const void* labels, const float* class_wei
     if (int st = check_args(a, dtype)) return st;
     HS_CHECK_ARG(partials, "null pointer");
     const unsigned grid = ce_grid(batch * npix);
-    if (dtype == HS_BF16) hipLaunchKernelGGL(seg_ce_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
+    if (row16_layout(logits, stride_b, stride_k, stride_p, n_classes, dtype))
+        hipLaunchKernelGGL(seg_ce_fwd_row16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
+    else if (dtype == HS_BF16) hipLaunchKernelGGL(seg_ce_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
     else hipLaunchKernelGGL(seg_ce_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
     HS_LAUNCH_CHECK("seg_ce_fwd");
     return HS_OK;
@@ -138,7 +231,10 @@ int hs_seg_ce_bwd(const void* logits, const void* labels, const float* class_wei
     if (int st = check_args(a, dtype)) return st;
     HS_CHECK_ARG(scale && dlogits, "null pointer");
     const unsigned grid = ce_grid(batch * npix);
-    if (dtype == HS_BF16)
+    if (row16_layout(logits, stride_b, stride_k, stride_p, n_classes, dtype) &&
+        row16_layout(dlogits, dstride_b, dstride_k, dstride_p, n_classes, dtype))
+        hipLaunchKernelGGL(seg_ce_bwd_row16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, scale, dlogits, dstride_b);
+    else if (dtype == HS_BF16)
         hipLaunchKernelGGL(seg_ce_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, scale, dlogits, dstride_b,
                            dstride_k, dstride_p);
     else

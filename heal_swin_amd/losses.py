@@ -42,7 +42,19 @@ class _SegCrossEntropyFn(torch.autograd.Function):
         B, K, P = logits.shape
         sb, sk, sp = logits.stride()
         dense = sorted(logits.stride(), reverse=True) == sorted(logits.contiguous().stride(), reverse=True)
-        dl = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device) if dense else torch.empty_like(logits)
+        if dense:
+            dl = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+        elif sk == 1 and sp > K and sb == P * sp:
+            # the model's padded head output ([B, Npix, sp] rows, K of sp columns used, seen as [B, K, Npix]): the gradient is
+            # written in the same layout into a zeroed padded buffer, which ops.PadSliceFn hands on whole to the head's
+            # backward (no transposing copy, no second zero fill)
+            from . import ops
+            full = torch.zeros((B, P, sp), dtype=logits.dtype, device=logits.device)
+            dl = full[:, :, :K].transpose(1, 2)
+            ops.ZERO_PADDED_GRADS.clear()
+            ops.ZERO_PADDED_GRADS[full.data_ptr()] = full
+        else:
+            dl = torch.empty_like(logits)
         scale = (grad.to(torch.float32) / tot[1]).reshape(1)
         db, dk, dp = dl.stride()
         check(lib.hs_seg_ce_bwd(ptr(logits), ptr(labels), ptr(weights), ptr(scale), ptr(dl), B, P, K, sb, sk, sp, db, dk, dp,

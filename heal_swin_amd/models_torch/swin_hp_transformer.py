@@ -547,12 +547,12 @@ class UnetDecoder(nn.Module):
             x = up.expand(self.norm_up(x))  # B, N0, p * C: row (b, n) holds the p children of token n back to back
             B, N0, _ = x.shape
             x = ops.ln_head(x.reshape(B * N0 * up.patch_size, up.dim), up.norm.weight, up.norm.bias, w)
-            return x.view(B, N0 * up.patch_size, -1)[..., :f_out].transpose(1, 2)  # B, f_out, Npix
+            return ops.pad_slice(x.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2)  # B, f_out, Npix
         x = up(self.norm_up(x))  # B, Npix, C
         if x.dtype == torch.bfloat16 and f_out % 8 and f_out > 8:
             # 12 classes: rows padded to 16 so that the input gradient (K = 12 -> 16) runs in hs_gemm_nt: 0.33 ms instead of the
             # library's 0.85 ms; the caller sees the [.., :f_out] view (the loss kernels read logits through their strides)
-            x = ops.linear(x, F.pad(w.reshape(f_out, -1), (0, 0, 0, (-f_out) % 8)))[..., :f_out]
+            x = ops.pad_slice(ops.linear(x, F.pad(w.reshape(f_out, -1), (0, 0, 0, (-f_out) % 8))), f_out)
         else:
             x = ops.linear(x, w)
         return x.transpose(1, 2)  # B, f_out, Npix

@@ -3,6 +3,7 @@
 PyTorch owns the memory (caching allocator), the stream and the autograd graph; every arithmetic step
 below runs in the HIP library.  All ops require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
 """
+import math
 import os
 
 import torch
@@ -711,6 +712,34 @@ def linear(x, weight, bias=None):
 def linear_passthrough(x, weight, bias=None):
     """(x W^T + b, alias of x): use the alias for a residual connection around the branch this Linear opens."""
     return LinearFn.apply(x, weight, bias, True)
+
+
+ZERO_PADDED_GRADS = {}  # data_ptr -> zero-padded gradient buffer written by losses.seg_loss' backward (see PadSliceFn)
+
+
+class PadSliceFn(torch.autograd.Function):
+    """x[..., :n] of the padded head output.  Backward: when the incoming gradient is the [..., :n] view of a zero-padded
+    buffer of x's shape (losses.seg_loss writes its gradient that way), that buffer IS the gradient of x; otherwise the
+    gradient is copied into a zeroed buffer, as autograd's slice backward does."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.shape, ctx.n = x.shape, n
+        return x[..., :n]
+
+    @staticmethod
+    def backward(ctx, g):
+        full = ZERO_PADDED_GRADS.pop(g.data_ptr(), None)
+        if (full is not None and full.numel() == math.prod(ctx.shape) and full.dtype == g.dtype and
+                g.shape == ctx.shape[:-1] + (ctx.n,) and g.stride() == full.view(ctx.shape)[..., :ctx.n].stride()):
+            return full.view(ctx.shape), None
+        out = g.new_zeros(ctx.shape)
+        out[..., :ctx.n] = g
+        return out, None
+
+
+def pad_slice(x, n):
+    return PadSliceFn.apply(x, n)
 
 
 FUSED_LN_HEAD = os.environ.get("HS_FUSED_LN_HEAD", "1") != "0"
