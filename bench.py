@@ -410,6 +410,9 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
         sync()
     if timing:
         ops.KERNEL_TIMINGS = []
+        # the roofline object needs the attention launches only; bracketing every GEMM as well (--kernel-table) costs ~2 % of
+        # the step in event packets
+        ops.TIMED_PREFIXES = None if args.kernel_table else ("window_attn",)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()

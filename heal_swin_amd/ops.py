@@ -15,11 +15,12 @@ from ._lib import check, lib, ptr, stream_ptr
 # Optional live kernel timing (bench.py): when KERNEL_TIMINGS is a list, the attention launches are bracketed
 # with events recorded on the stream the kernel runs on, and (tag, start, end, algorithmic_bytes, flops) is appended.
 KERNEL_TIMINGS = None
+TIMED_PREFIXES = None  # None: every tagged launch; else only tags starting with one of these (each bracket costs ~3 us of stream time)
 
 
 class _timed:
     def __init__(self, tag, device, nbytes, flops):
-        self.on = KERNEL_TIMINGS is not None
+        self.on = KERNEL_TIMINGS is not None and (TIMED_PREFIXES is None or tag.startswith(TIMED_PREFIXES))
         if self.on:
             self.tag, self.nbytes, self.flops = tag, nbytes, flops
             self.start = torch.cuda.Event(enable_timing=True)
