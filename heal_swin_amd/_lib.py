@@ -33,6 +33,7 @@ _SIGNATURES = {
     "hs_attn_mask_from_labels": [c_ptr, c_i64, c_int, c_ptr],
     "hs_rel_bias_gather": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_rel_bias_scatter_grad": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
+    "hs_rel_bias_scatter_grad_sorted": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_window_attn_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
                            c_int, c_i64, c_int, c_int, c_int, c_uint, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_window_attn_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,

@@ -30,6 +30,25 @@ __global__ void rel_bias_scatter_grad_kernel(const float* __restrict__ dbias, co
     }
 }
 
+// the same sum from the entries grouped by table row (order = stable argsort of rel_idx, offsets = its run boundaries): 16
+// lanes per (t, h), lane s adds entries s, s + 16, ... of the row's run (independent loads in flight), then a fixed
+// xor-tree over the 16 lanes -- deterministic, and T * nH * 16 threads instead of T * nH workgroups that each scan the
+// whole index (15.8 us per attention backward before)
+__global__ void __launch_bounds__(256) rel_bias_scatter_grad_sorted_kernel(const float* __restrict__ dbias, const int32_t* __restrict__ order,
+                                                                           const int32_t* __restrict__ offsets, float* __restrict__ dtable,
+                                                                           int rows, int nH, int ws2) {
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    const bool live = g < rows * nH;
+    const int t = live ? g / nH : 0, h = live ? g - t * nH : 0;
+    const int k0 = offsets[t], k1 = live ? offsets[t + 1] : k0;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int k = k0 + sub; k < k1; k += 16) acc += dbias[(int64_t)h * ws2 + order[k]];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (live && sub == 0) dtable[g] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -52,6 +71,16 @@ int hs_rel_bias_scatter_grad(const float* dbias, const int32_t* rel_idx, float* 
     hipLaunchKernelGGL(rel_bias_scatter_grad_kernel, dim3(table_rows, num_heads), dim3(nthr), 0, (hipStream_t)stream, dbias,
                        rel_idx, dtable, num_heads, ws2);
     HS_LAUNCH_CHECK("rel_bias_scatter_grad");
+    return HS_OK;
+}
+
+int hs_rel_bias_scatter_grad_sorted(const float* dbias, const int32_t* order, const int32_t* offsets, float* dtable,
+                                    int table_rows, int num_heads, int window_size, void* stream) {
+    HS_CHECK_ARG(dbias && order && offsets && dtable && table_rows > 0 && num_heads > 0 && window_size > 0, "bad arguments");
+    const int n = table_rows * num_heads * 16;
+    hipLaunchKernelGGL(rel_bias_scatter_grad_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dbias, order,
+                       offsets, dtable, table_rows, num_heads, window_size * window_size);
+    HS_LAUNCH_CHECK("rel_bias_scatter_grad_sorted");
     return HS_OK;
 }
 

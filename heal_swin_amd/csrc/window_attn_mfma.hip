@@ -120,9 +120,13 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, qq = qt * 32 + l31;
-                biasr[kt][qt][r] = p.bias ? p.bias[((int64_t)h * kWs + qq) * kWs + key] * kLog2e : 0.f;
+            for (int m = 0; m < 4; ++m) {  // registers 4m..4m+3 are 4 consecutive keys: one 16-byte load
+                const int key = kt * 32 + 8 * m + 4 * half, qq = qt * 32 + l31;
+                const float4 b4 = p.bias ? *(const float4*)(p.bias + ((int64_t)h * kWs + qq) * kWs + key) : make_float4(0.f, 0.f, 0.f, 0.f);
+                biasr[kt][qt][4 * m] = b4.x * kLog2e;
+                biasr[kt][qt][4 * m + 1] = b4.y * kLog2e;
+                biasr[kt][qt][4 * m + 2] = b4.z * kLog2e;
+                biasr[kt][qt][4 * m + 3] = b4.w * kLog2e;
             }
 
 

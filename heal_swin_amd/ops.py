@@ -81,9 +81,28 @@ class RelPosBiasFn(torch.autograd.Function):
         rows, nh, ws = ctx.shape
         dbias = dbias.to(torch.float32).contiguous()
         dtable = torch.empty((rows, nh), dtype=torch.float32, device=dbias.device)
-        check(lib.hs_rel_bias_scatter_grad(ptr(dbias), ptr(rel_idx), ptr(dtable), rows, nh, ws, stream_ptr(dbias.device)),
-              "hs_rel_bias_scatter_grad")
+        order, offsets = _rel_idx_groups(rel_idx, rows)
+        check(lib.hs_rel_bias_scatter_grad_sorted(ptr(dbias), ptr(order), ptr(offsets), ptr(dtable), rows, nh, ws,
+                                                  stream_ptr(dbias.device)), "hs_rel_bias_scatter_grad_sorted")
         return dtable.to(ctx.table_dtype), None, None
+
+
+_REL_IDX_GROUPS = {}
+
+
+def _rel_idx_groups(rel_idx, rows):
+    """(order, offsets) of `hs_rel_bias_scatter_grad_sorted` for an index buffer, built once per buffer (the index is a
+    registered buffer of the module: constant)."""
+    key = (rel_idx.data_ptr(), rel_idx.numel(), rows, rel_idx.device)
+    hit = _REL_IDX_GROUPS.get(key)
+    if hit is None:
+        flat = rel_idx.flatten().long()
+        order = torch.argsort(flat, stable=True).to(torch.int32)
+        counts = torch.bincount(flat, minlength=rows)[:rows]
+        offsets = torch.zeros(rows + 1, dtype=torch.int32, device=rel_idx.device)
+        offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        hit = _REL_IDX_GROUPS[key] = (order.contiguous(), offsets, rel_idx)  # (keeps the keyed buffer alive)
+    return hit[0], hit[1]
 
 
 # ----------------------------------------------------------------------------- fused shift + window attention
@@ -127,8 +146,11 @@ class WindowAttnCoreFn(torch.autograd.Function):
         B, N, C, nh, ws, flags, dt, roll = ctx.args
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
-        dbias = torch.zeros_like(bias_c) if bias_c is not None else None
-        dscale = torch.zeros_like(hs)
+        # dbias and dscale are accumulated into by the kernels (C ABI): one zero fill for both
+        nb = bias_c.numel() if bias_c is not None else 0
+        zeros = torch.zeros(nb + hs.numel(), dtype=torch.float32, device=qkv.device)
+        dbias = zeros[:nb].view(bias_c.shape) if bias_c is not None else None
+        dscale = zeros[nb:].view(hs.shape)
         nws = int(lib.hs_window_attn_bwd_workspace(B, N, C, nh, ws, dt))
         wsp = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws else None
         # algorithmic traffic: qkv (3C) + out (C) + dout (C) read, dqkv (3C) written; flops: 5 contractions of 2*Ws*hd

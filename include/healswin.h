@@ -96,6 +96,10 @@ int hs_rel_bias_gather(const float* table, const int32_t* rel_idx, float* bias,
 /* dtable[t, h] = sum over (i,j) with rel_idx[i,j] == t of dbias[h, i, j]   (dtable is overwritten). */
 int hs_rel_bias_scatter_grad(const float* dbias, const int32_t* rel_idx, float* dtable,
                              int table_rows, int num_heads, int window_size, void* stream);
+/* The same with the index pre-grouped by table row: order [dev] int32[Ws*Ws] = stable argsort of rel_idx, offsets [dev]
+ * int32[T + 1] = start of each row's run in `order`.  One thread per (t, h), entries added in ascending (i, j) order. */
+int hs_rel_bias_scatter_grad_sorted(const float* dbias, const int32_t* order, const int32_t* offsets, float* dtable,
+                                    int table_rows, int num_heads, int window_size, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused  shift -> window_partition -> attention core -> window_reverse -> shift_back.

@@ -605,3 +605,23 @@ def test_residual_drop_matches_the_explicit_formula(dtype):
     # same seed -> same mask; p = 0 and no DropPath -> plain add
     assert torch.equal(ops.residual_drop(x, t, rs, p, seed=77), out.detach())
     assert torch.equal(ops.residual_drop(x, t, None, 0.0), x + t)
+
+
+@pytest.mark.parametrize("ws,nh", [(64, 16), (16, 3), (256, 4)])
+def test_rel_bias_scatter_grad_sorted_matches_the_scan_kernel(ws, nh):
+    """The grouped (argsort) form of the bias-table gradient against the scanning kernel and a torch index_add."""
+    from heal_swin_amd import _lib, ops
+    from heal_swin_amd._lib import check, lib, ptr, stream_ptr
+
+    torch.manual_seed(ws + nh)
+    rel = torch.from_numpy(_lib.rel_pos_index(ws).astype("int32")).cuda().contiguous()
+    rows = int(rel.max()) + 1
+    dbias = torch.randn(nh, ws, ws, device="cuda")
+    ref = torch.zeros(rows, nh, device="cuda", dtype=torch.float64).index_add_(0, rel.flatten().long(), dbias.reshape(nh, -1).t().double())
+    a = torch.empty(rows, nh, device="cuda")
+    b = torch.empty_like(a)
+    check(lib.hs_rel_bias_scatter_grad(ptr(dbias), ptr(rel), ptr(a), rows, nh, ws, stream_ptr(a.device)), "scan")
+    order, offsets = ops._rel_idx_groups(rel, rows)
+    check(lib.hs_rel_bias_scatter_grad_sorted(ptr(dbias), ptr(order), ptr(offsets), ptr(b), rows, nh, ws, stream_ptr(a.device)), "sorted")
+    assert_close(b, ref, 1e-6, f"rel_bias scatter sorted ws={ws}")
+    assert_close(a, ref, 1e-6, f"rel_bias scatter scan ws={ws}")
