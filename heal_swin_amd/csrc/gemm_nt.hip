@@ -73,7 +73,7 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
 // NSTAGE LDS stage buffers (the DMA runs NSTAGE - 1 k-steps ahead of the MFMAs); ALIAS: the epilogue's per-wave patches lie
 // inside the stage buffer that was just consumed (one extra barrier per tile) instead of in LDS of their own
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI, bool DROP>
-__global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) {
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 * 256) ? 1 : 2) gemm_nt_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 accumulators per wave along m / n
@@ -166,12 +166,21 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     }
 
     f32x16 acc[TN][TM];
+    // (128 x 128 wave tile: the 256 accumulator registers are zeroed IN the AGPRs by an MFMA of zero operands -- as VGPR
+    // zeros on their way there they evicted every loop-invariant address)
+    const u32x4 zero_frag = {0u, 0u, 0u, 0u};
+    auto zero_acc = [&](f32x16& a) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(a) : "v"(zero_frag)); };
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (TM == 4 && TN == 4) {
+                zero_acc(acc[j][i]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+            }
+        }
 
     // ---- one k-step out of stage buffer `buf`: four 16-deep MFMA sub-steps, their fragment reads streamed ahead of them, and
     // the DMA pieces of a later k-step (into stage buffer `buf_next`, free since the barrier) issued behind each MFMA group
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         const uint32_t bo = buf * STAGE;
         // fragment reads are streamed one or two 16-deep sub-steps ahead of their MFMAs through a ring of NSET register sets
         // (two for the 128 x 64 wave tile, whose 128 accumulator registers leave no room for a third)
-        constexpr int NSET = TM == 4 ? 2 : 3;
+        constexpr int NSET = (TM == 4 && TN == 2) ? 2 : 3;  // (the 4-wave 128 x 128 wave tile has 512 registers to itself)
         u32x4 fa[NSET][TM], fb[NSET][TN];
         auto read_frags = [&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value, set = ks % NSET;
@@ -201,6 +210,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                 asm volatile("s_waitcnt lgkmcnt(%6)"
                              : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1])
                              : "n"(left));
+            else if constexpr (TM == 4 && TN == 4)
+                asm volatile("s_waitcnt lgkmcnt(%8)"
+                             : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1]),
+                               "+v"(fb[set][2]), "+v"(fb[set][3])
+                             : "n"(left));
             else
                 static_assert(TM == 2 || TM == 4, "add a wait form for this wave tile");
         };
@@ -210,9 +224,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[set][j]),
-                                                                        __builtin_bit_cast(bf16x8, fa[set][i]), acc[j][i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (TM == 4 && TN == 4) {
+                        // 256 accumulator registers: pinned to the AGPR half of the file
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(fb[set][j]), "v"(fa[set][i]));
+                    } else
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[set][j]),
+                                                                            __builtin_bit_cast(bf16x8, fa[set][i]), acc[j][i], 0, 0, 0);
+                }
             if (decltype(cnt_c)::value > 0 && prefetch) issue_pieces(kb_next, buf_next, first_c, cnt_c);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -259,11 +278,15 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.c + m0 * p.n), 0, (int)(p.c ? cbytes : 0), 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.aux + m0 * p.n), 0, (int)(p.aux ? cbytes : 0), 0x00020000);
         const ElemRng rng(p.drop_p, p.seed);
-        const bool wide = TN == 2 && (p.n & 7) == 0;  // whole-row-segment path
-        const int ncol0 = n0 + wn * (BN / WN);         // first of this wave's 64 columns
-        float4 bias4[TN][4];
+        const bool wide = (TN & 1) == 0 && (p.n & 7) == 0;  // whole-row-segment path
+        // a wave's BN / WN columns are handled 64 at a time (one patch pass per half jh: wave tiles of 64 or 128 columns)
+        constexpr int JH = TN / 2 > 0 ? TN / 2 : 1, TJ = TN < 2 ? TN : 2;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int jh = 0; jh < JH; ++jh) {
+        const int ncol0 = n0 + wn * (BN / WN) + jh * 64;  // first of the 64 columns of this pass
+        float4 bias4[TJ][4];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = ncol0 + j * 32 + 4 * half + 8 * g;
@@ -279,7 +302,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         for (int i = 0; i < TM; ++i) {
             const int ml = wm * (BM / WM) + i * 32 + l31;
             // ---- input block (h or the residual) in the own-lane view
-            u32x2 xin[TN][4];
+            u32x2 xin[TJ][4];
             if (EPI == EPI_DGELU || EPI == EPI_RESID) {
                 if (wide) {
                     u32x4 rws[4];
@@ -291,16 +314,16 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                     asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(row_addr), "v"(rws[2]) : "memory");
                     asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(row_addr), "v"(rws[3]) : "memory");
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             asm volatile("ds_read_b64 %0, %1" : "=v"(xin[j][g]) : "v"(own_addr + (((4 * j + g) ^ (l31 & 7)) << 4)));
                     asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(xin[0][0]), "+v"(xin[0][1]), "+v"(xin[0][2]), "+v"(xin[0][3]), "+v"(xin[TN - 1][0]),
-                                   "+v"(xin[TN - 1][1]), "+v"(xin[TN - 1][2]), "+v"(xin[TN - 1][3]));
+                                 : "+v"(xin[0][0]), "+v"(xin[0][1]), "+v"(xin[0][2]), "+v"(xin[0][3]), "+v"(xin[TJ - 1][0]),
+                                   "+v"(xin[TJ - 1][1]), "+v"(xin[TJ - 1][2]), "+v"(xin[TJ - 1][3]));
                 } else {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int n = ncol0 + j * 32 + 4 * half + 8 * g;
@@ -311,15 +334,27 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
             // ---- arithmetic on the accumulators, two elements at a time (packed fp32, hs_gelu.h).  Dropout (DROP) is a
             // kernel instantiation of its own: next to the branch-free p = 0 arithmetic its counter hashes cost the
             // 128 x 64 wave tile ~70 spilled registers, some of them inside the main loop
-            u32x2 o1[TN][4], o2[TN][4];  // o1 -> c ; o2 -> aux (EPI_GELU only)
+            u32x2 o1[TJ][4], o2[TJ][4];  // o1 -> c ; o2 -> aux (EPI_GELU only)
             {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int n = ncol0 + j * 32 + 4 * half + 8 * g;
-                        f32x2 v[2] = {f32x2{acc[j][i][4 * g], acc[j][i][4 * g + 1]} + f32x2{bias4[j][g].x, bias4[j][g].y},
-                                      f32x2{acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]} + f32x2{bias4[j][g].z, bias4[j][g].w}};
+                        f32x16& a16 = acc[TJ * jh + j][i];
+                        // (AGPR-resident accumulators are read element by element HERE: left to itself the compiler copies all
+                        // 256 of them into VGPRs at the top of the epilogue and spills everything else)
+                        auto rd = [&](int r) -> float {
+                            if constexpr (TM == 4 && TN == 4) {
+                                float x;
+                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a16[r]));
+                                return x;
+                            } else {
+                                return a16[r];
+                            }
+                        };
+                        f32x2 v[2] = {f32x2{rd(4 * g), rd(4 * g + 1)} + f32x2{bias4[j][g].x, bias4[j][g].y},
+                                      f32x2{rd(4 * g + 2), rd(4 * g + 3)} + f32x2{bias4[j][g].z, bias4[j][g].w}};
                         const int64_t e0 = (m0 + ml) * p.n + n;  // element index of v[0].x in the [m, n] tensor (dropout counter)
                         if (EPI == EPI_GELU) {
                             o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
@@ -344,15 +379,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                             }
                             o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
                         }
+                        if constexpr (!(TM == 4 && TN == 4)) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[j][i][4 * g + r] = 0.f;
+                            for (int r = 0; r < 4; ++r) a16[4 * g + r] = 0.f;
+                        } else if (g == 3) {
+                            zero_acc(a16);
+                        }
                     }
             }
             // ---- outputs
-            auto emit = [&](const __amdgpu_buffer_rsrc_t& rs, const u32x2 (&o)[TN][4]) {
+            auto emit = [&](const __amdgpu_buffer_rsrc_t& rs, const u32x2 (&o)[TJ][4]) {
                 if (wide) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             asm volatile("ds_write_b64 %0, %1" ::"v"(own_addr + (((4 * j + g) ^ (l31 & 7)) << 4)), "v"(o[j][g]) : "memory");
@@ -367,7 +406,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rws[t]), rs, row_voff(i, t), 0, 0);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int n = ncol0 + j * 32 + 4 * half + 8 * g;
@@ -381,6 +420,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
             } else {
                 emit(rc, o1);
             }
+            // 128 x 128 wave tile: the accumulators live in AGPRs and pass through VGPRs one row block at a time; without this
+            // fence the scheduler hoists all the copies to the front and spills the loop-invariant addresses of the main loop
+            if (TM == 4 && TN == 4) __builtin_amdgcn_sched_barrier(0);
+        }
         }
     };
 
@@ -529,6 +572,7 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     switch (variant) {
         case 2: return launch_tile<256, 128, 4, 2, 3, true>(p, epilogue, 1, st);
         case 3: return launch_tile<256, 256, 2, 4, 2, true>(p, epilogue, 1, st);
+        case 4: return launch_tile<256, 256, 2, 2, 2, true>(p, epilogue, 1, st);  // 4 waves x (128 x 128), one per SIMD, AGPR accumulators: A/B only
         default: return launch_tile<128, 128, 2, 2, 2, false>(p, epilogue, 2, st);
     }
 }

@@ -314,7 +314,8 @@ int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const
  *            HS_EPI_RESID: c = acc + bias + aux                              (aux = a residual term [read])
  *   The dropout mask is the one hs_gelu_fwd/bwd draw for the same (seed, element index m*n_cols + n).
  *   k, k2, lda, ldb multiples of 8; n a multiple of 4; dtype must be HS_BF16 (fp32 runs keep the library GEMM).
- * hs_gemm_nt_set_tile: measurement hook (0 = built-in choice, 1 = 128x128 tiles, 2 = 256x128 x 3 stages, 3 = 256x256).
+ * hs_gemm_nt_set_tile: measurement hook (0 = built-in choice, 1 = 128x128 tiles, 2 = 256x128 x 3 stages, 3 = 256x256 with
+ * 8 waves, 4 = 256x256 with 4 waves of 128x128 and the accumulators in AGPRs: never chosen by 0, kept for A/B runs).
  * ---------------------------------------------------------------------------------------------- */
 #define HS_EPI_BIAS 0
 #define HS_EPI_GELU 1
