@@ -270,7 +270,9 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
     constexpr int WK = TK / 64, NW = 2 * WK, NT = 64 * NW;  // waves along k, waves, threads: waves in 2 x WK, each (32*NB) x 64
     constexpr int YRB = TN * 2, XRB = TK * 2;    // bytes of one staged dY / X tile row
     constexpr int YB = kTok * YRB, XB = kTok * XRB;  // bytes of one staged dY / X tile
-    constexpr int STAGE = YB + XB, NSTAGE = 3;
+    // the DMA runs NSTAGE - 1 stages ahead: what bounds the main loop is the bytes in flight per CU, so the
+    // 256-wide tile (one workgroup per CU) takes a fourth 32 KB buffer: 96 instead of 64 KB in flight
+    constexpr int STAGE = YB + XB, NSTAGE = TK == 256 ? 4 : 3, AH = NSTAGE - 1;
     constexpr int YI = YB / 1024 / NW, XI = XB / 1024 / NW;  // 1-KB DMA instructions per wave and stage
     constexpr int YCH = YRB / 16, XCH = XRB / 16;           // 16-byte chunks per dY / X tile row
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
@@ -348,12 +350,16 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
     // DMA's destination buffer from the one being read: with run-time indices it orders them with an s_waitcnt vmcnt(0)
     auto stage = [&](int t, auto buf_c, auto nbuf_c) {
         constexpr int buf = decltype(buf_c)::value, nbuf = decltype(nbuf_c)::value;
-        if (t + 1 < nst)
+        // stage t has landed once only the younger stages still issued (at most AH - 1, fewer at the tail) are outstanding
+        const int younger = nst - 1 - t;
+        if (AH - 1 >= 2 && younger >= 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (YI + XI)) : "memory");
+        else if (younger >= 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YI + XI) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < nst) issue(nbuf);
+        if (t + AH < nst) issue(nbuf);
         s16x8 af[2][NB], bf[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -409,10 +415,19 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
     };
     if (nst > 0) issue(0);
     if (nst > 1) issue(1);
-    for (int t = 0; t < nst; t += NSTAGE) {
-        stage(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-        if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-        if (t + 2 < nst) stage(t + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    if (AH > 2 && nst > 2) issue(2);
+    using std::integral_constant;
+    for (int t = 0; t < nst; t += NSTAGE) {  // stage t computes buffer t % NSTAGE and refills the one stage t - 1 consumed
+        if constexpr (NSTAGE == 3) {
+            stage(t, integral_constant<int, 0>{}, integral_constant<int, 2>{});
+            if (t + 1 < nst) stage(t + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+            if (t + 2 < nst) stage(t + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+        } else {
+            stage(t, integral_constant<int, 0>{}, integral_constant<int, 3>{});
+            if (t + 1 < nst) stage(t + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+            if (t + 2 < nst) stage(t + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+            if (t + 3 < nst) stage(t + 3, integral_constant<int, 3>{}, integral_constant<int, 2>{});
+        }
     }
 
     float* dst = part_w + (int64_t)slice * ((int64_t)n_out * k_in + n_out);
@@ -479,7 +494,9 @@ __global__ void __launch_bounds__(256, 3) wgrad_dma_f32_kernel(const float* __re
     constexpr int TN = 128, TK = 128;
     constexpr int RB = TN * 4;                       // bytes of one staged tile row (both tiles are 128 floats wide)
     constexpr int YB = kTokF * RB, XB = kTokF * RB;  // 8 KB each
-    constexpr int STAGE = YB + XB, NSTAGE = 3;
+    // the DMA runs NSTAGE - 1 stages ahead: what bounds the main loop is the bytes in flight per CU, so the
+    // 256-wide tile (one workgroup per CU) takes a fourth 32 KB buffer: 96 instead of 64 KB in flight
+    constexpr int STAGE = YB + XB, NSTAGE = TK == 256 ? 4 : 3, AH = NSTAGE - 1;
     constexpr int YI = YB / 1024 / 4, XI = XB / 1024 / 4;  // 1-KB DMA instructions per wave and stage (2 + 2)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
     float* bred = (float*)smem;
@@ -540,12 +557,16 @@ __global__ void __launch_bounds__(256, 3) wgrad_dma_f32_kernel(const float* __re
 
     auto stage = [&](int t, auto buf_c, auto nbuf_c) {
         constexpr int buf = decltype(buf_c)::value, nbuf = decltype(nbuf_c)::value;
-        if (t + 1 < nst)
+        // stage t has landed once only the younger stages still issued (at most AH - 1, fewer at the tail) are outstanding
+        const int younger = nst - 1 - t;
+        if (AH - 1 >= 2 && younger >= 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (YI + XI)) : "memory");
+        else if (younger >= 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YI + XI) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < nst) issue(nbuf);
+        if (t + AH < nst) issue(nbuf);
         const uint32_t yb = ya + buf * STAGE, xb = xa + buf * STAGE;
         float fa[8][2], fb[8][2];  // [token pair][32-column block]
         static_for<8>([&](auto jc) {
@@ -587,10 +608,19 @@ __global__ void __launch_bounds__(256, 3) wgrad_dma_f32_kernel(const float* __re
     };
     if (nst > 0) issue(0);
     if (nst > 1) issue(1);
-    for (int t = 0; t < nst; t += NSTAGE) {
-        stage(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-        if (t + 1 < nst) stage(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-        if (t + 2 < nst) stage(t + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    if (AH > 2 && nst > 2) issue(2);
+    using std::integral_constant;
+    for (int t = 0; t < nst; t += NSTAGE) {  // stage t computes buffer t % NSTAGE and refills the one stage t - 1 consumed
+        if constexpr (NSTAGE == 3) {
+            stage(t, integral_constant<int, 0>{}, integral_constant<int, 2>{});
+            if (t + 1 < nst) stage(t + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+            if (t + 2 < nst) stage(t + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+        } else {
+            stage(t, integral_constant<int, 0>{}, integral_constant<int, 3>{});
+            if (t + 1 < nst) stage(t + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+            if (t + 2 < nst) stage(t + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+            if (t + 3 < nst) stage(t + 3, integral_constant<int, 3>{}, integral_constant<int, 2>{});
+        }
     }
 
     float* dst = part_w + (int64_t)slice * ((int64_t)n_out * k_in + n_out);
