@@ -625,3 +625,35 @@ def test_rel_bias_scatter_grad_sorted_matches_the_scan_kernel(ws, nh):
     check(lib.hs_rel_bias_scatter_grad_sorted(ptr(dbias), ptr(order), ptr(offsets), ptr(b), rows, nh, ws, stream_ptr(a.device)), "sorted")
     assert_close(b, ref, 1e-6, f"rel_bias scatter sorted ws={ws}")
     assert_close(a, ref, 1e-6, f"rel_bias scatter scan ws={ws}")
+
+
+@pytest.mark.parametrize("K", [12, 8, 16, 4])
+def test_seg_cross_entropy_padded_row_fast_path(K):
+    """The model's own logits layout (K classes in 16-wide bf16 rows, seen as [B, K, Npix]): `seg_ce_*_row16` must give the
+    loss and the gradient of the generic strided kernels bit for bit, leave the pad columns of the gradient buffer zero, and
+    `ops.pad_slice` must hand that buffer on whole."""
+    from heal_swin_amd import losses as L, ops
+    g = torch.Generator().manual_seed(K)
+    B, P = 2, 7001
+    z16 = torch.zeros(B, P, 16, dtype=torch.bfloat16)
+    z16[..., :K] = (torch.randn(B, P, K, generator=g) * 3).to(torch.bfloat16)
+    labels = torch.randint(0, K, (B, P), generator=g)
+    labels[1, 5:50] = -100
+    w = torch.rand(K, generator=g) + 0.5
+    # generic path: the same values in a dense pixel-major [B, P, K] tensor
+    zd = z16[..., :K].contiguous().to(DEV).requires_grad_(True)
+    loss_d = L.seg_loss(zd.transpose(1, 2), labels.to(DEV), w.to(DEV))
+    loss_d.backward()
+    # fast path through the padded rows and pad_slice
+    zp = z16.to(DEV).requires_grad_(True)
+    loss_p = L.seg_loss(ops.pad_slice(zp, K).transpose(1, 2), labels.to(DEV), w.to(DEV))
+    loss_p.backward()
+    assert float(loss_p) == float(loss_d)
+    assert torch.equal(zp.grad[..., :K], zd.grad)
+    assert not zp.grad[..., K:].any()
+    assert not ops.ZERO_PADDED_GRADS  # the buffer was consumed by pad_slice's backward
+    ref_in = z16[..., :K].float().transpose(1, 2).clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, labels, weight=w)
+    ref.backward()
+    assert abs(float(loss_p) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert float((zp.grad[..., :K].float().cpu().transpose(1, 2) - ref_in.grad).abs().max()) <= 1e-2 * float(ref_in.grad.abs().max())
