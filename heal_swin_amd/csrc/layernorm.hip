@@ -2,6 +2,7 @@
 // HBM-bound: one wavefront per row, 16-byte vector loads along the row, the row cached in registers
 // between the statistics pass and the normalise pass (each element is read once and written once).
 // Statistics and accumulations are fp32 for both fp32 and bf16 activations.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hs_device.h"
@@ -330,7 +331,10 @@ __global__ void __launch_bounds__(1024) layernorm_param_reduce_kernel(const floa
 
 // workgroups of the backward: enough to fill the chip for long inputs, few enough that the partial rows stay cheap
 int bwd_blocks(int64_t rows) {
-    int64_t want = rows / 128;
+    // rows per workgroup: 48 (was 128) keeps 8 workgroups per CU busy on the 98 304-row stage as well (89 -> 83.5 us; the
+    // partial rows of the parameter reduce grow with it: 6.7 -> 9.8 us); HS_LN_BWD_ROWS overrides for A/B runs
+    static const int div = getenv("HS_LN_BWD_ROWS") ? atoi(getenv("HS_LN_BWD_ROWS")) : 48;
+    int64_t want = rows / div;
     if (want < 64) want = 64;
     if (want > kBwdMaxBlocks) want = kBwdMaxBlocks;
     const int64_t by_rows = (rows + 15) / 16;
