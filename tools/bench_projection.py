@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fisheye -> HEALPix sampling kernels at WoodScape size (966 x 1280 frames, nside 256, 8 base pixels): frames/s and the
-algorithmic bandwidth (per output pixel: 16 B of coordinates once per launch, per plane 4 neighbour bytes + 1 byte written),
-next to the oracle (numpy) on the host.   python tools/bench_projection.py [--batch 16] [--json out.json]"""
+algorithmic bandwidth (per output pixel: 16 B of coordinates once per launch, per plane 4 neighbour bytes + 1 byte written).
+(The numpy oracle's time for the same frame is printed by tests/test_gpu_projection.py -- only tests may import the oracle.)
+python tools/bench_projection.py [--batch 16] [--json out.json]"""
 import argparse
 import json
 import os
@@ -13,7 +14,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from heal_swin_amd import projection as P  # noqa: E402
-from oracle import projection as OP  # noqa: E402
 
 CAL = dict(name="FV", intrinsic=dict(aspect_ratio=1.0, cx_offset=3.942, cy_offset=-0.472, width=1280.0, height=966.0, poly_order=4,
                                      k1=339.749, k2=-31.988, k3=48.275, k4=-7.201),
@@ -44,16 +44,8 @@ def main():
     ms = ev[0].elapsed_time(ev[1]) / iters
     n = proj.npix
     alg = 2 * 16 * n + a.batch * n * (3 * 5 + 2)  # two launches read the table; 3 image planes (4 in, 1 out) + mask (1 in, 1 out)
-    img_np, mask_np = imgs[0].cpu().numpy(), masks[0].cpu().numpy()
-    u, v = proj.u.cpu().numpy(), proj.v.cpu().numpy()
-    t0 = time.perf_counter()
-    with np.errstate(invalid="ignore"):
-        OP.sample_bilinear(img_np, v, u).astype(np.uint8)
-        OP.sample_mask(mask_np, v, u, 0)
-    cpu_s = time.perf_counter() - t0
     res = dict(nside=a.nside, base_pix=8, npix=n, batch=a.batch, frame="3x966x1280 uint8", ms_per_batch=ms, frames_per_s=a.batch / ms * 1e3,
-               algorithmic_GBps=alg / ms / 1e6, table_build_s_host_once_per_calibration=table_s,
-               oracle_numpy_s_per_frame=cpu_s, oracle_frames_per_s=1 / cpu_s)
+               algorithmic_GBps=alg / ms / 1e6, table_build_s_host_once_per_calibration=table_s)
     print(json.dumps(res, indent=1))
     if a.json:
         json.dump(res, open(a.json, "w"), indent=1)
