@@ -70,6 +70,12 @@ _SIGNATURES = {
     "hs_window_attn_module_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_i64,
                                   c_int, c_int, c_int, c_uint, c_int, c_ptr],
     "hs_layernorm_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_ptr],
+    "hs_patch_merge_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
+    "hs_patch_merge_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64,
+                           c_int, c_int, c_int, c_ptr],
+    "hs_patch_expand_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
+    "hs_patch_expand_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64,
+                            c_int, c_int, c_int, c_int, c_ptr],
 }
 _OTHER = {
     "hs_version": ([], ctypes.c_char_p),
@@ -81,6 +87,8 @@ _OTHER = {
     "hs_ln_head_partials": ([c_i64], c_i64),
     "hs_linear_wgrad_workspace": ([c_i64, c_int, c_int], c_i64),
     "hs_window_attn_bwd_workspace": ([c_int, c_i64, c_int, c_int, c_int, c_int], c_i64),
+    "hs_patch_merge_bwd_workspace": ([c_i64, c_int, c_int], c_i64),
+    "hs_patch_expand_bwd_workspace": ([c_i64, c_int, c_int, c_int], c_i64),
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_OTHER))
 

@@ -25,6 +25,8 @@
 // per-lane factor applied to the fp32 scores.
 #include "window_attn.h"
 
+#include <cstdlib>
+
 namespace hs {
 namespace {
 
@@ -114,21 +116,32 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
     // (loaded AFTER the first window's rows were requested: both latencies overlap)
     // relative-position bias of this head, in the S^T accumulator layout: tile (kt, qt), register r holds
     // query qt*32 + l31, key kt*32 + (r&3) + 8*(r>>2) + 4*half
+    // The loads are UNCONDITIONAL, eight at a time (without a bias they read this lane's bytes of the qkv tensor and the
+    // values are discarded): a per-load `p.bias ? load : 0` compiles to 16 conditional blocks, each waiting for its own
+    // load (vmcnt(0)) -- 16 serial L2 round trips in front of the first window.
     float biasr[2][2][16];
+    {
+        const bool has_bias = p.bias != nullptr;
+        const float* bsrc = has_bias ? p.bias + ((int64_t)h * kWs + l31) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt) {
+            float4 b4[2][4];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {  // registers 4m..4m+3 are 4 consecutive keys: one 16-byte load
-                const int key = kt * 32 + 8 * m + 4 * half, qq = qt * 32 + l31;
-                const float4 b4 = p.bias ? *(const float4*)(p.bias + ((int64_t)h * kWs + qq) * kWs + key) : make_float4(0.f, 0.f, 0.f, 0.f);
-                biasr[kt][qt][4 * m] = b4.x * kLog2e;
-                biasr[kt][qt][4 * m + 1] = b4.y * kLog2e;
-                biasr[kt][qt][4 * m + 2] = b4.z * kLog2e;
-                biasr[kt][qt][4 * m + 3] = b4.w * kLog2e;
-            }
-
+                for (int m = 0; m < 4; ++m)  // registers 4m..4m+3 are 4 consecutive keys: one 16-byte load
+                    b4[qt][m] = *(const float4*)(bsrc + (has_bias ? qt * 32 * kWs : 0) + kt * 32 + 8 * m);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    biasr[kt][qt][4 * m] = has_bias ? b4[qt][m].x * kLog2e : 0.f;
+                    biasr[kt][qt][4 * m + 1] = has_bias ? b4[qt][m].y * kLog2e : 0.f;
+                    biasr[kt][qt][4 * m + 2] = has_bias ? b4[qt][m].z * kLog2e : 0.f;
+                    biasr[kt][qt][4 * m + 3] = has_bias ? b4[qt][m].w * kLog2e : 0.f;
+                }
+        }
+    }
 
     for (int64_t wi = bx; wi < total_windows; wi += slots) {
         const int b = (int)(wi / nW);
@@ -549,13 +562,19 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         }
 
         // ------------------------------------------------------------ S^T = K^ Q^T and dP^T = V dO^T for this wave's 32 queries
-        float4 biasv[2][4];  // bias[h][qq][kt*32 + 8*rg + 4*half .. +3], in flight during the MFMAs below
+        // bias[h][qq][kt*32 + 8*rg + 4*half .. +3], in flight during the MFMAs below.  The eight loads are UNCONDITIONAL (without
+        // a bias they read this lane's 256 bytes of the qkv tensor and the values are discarded below): per-load
+        // `p.bias ? load : 0` ternaries compile to eight conditional blocks that each wait for their own load (vmcnt(0)) --
+        // eight serial L2 round trips per window in front of the score MFMAs -- and one branch around all of them still
+        // makes the compiler wait for them at the join.
+        float4 biasv[2][4];
+        {
+            const float* bsrc = p.bias ? p.bias + ((int64_t)h * kWs + qq) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                biasv[kt][rg] = p.bias ? *(const float4*)(p.bias + ((int64_t)h * kWs + qq) * kWs + kt * 32 + 8 * rg + 4 * half)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int rg = 0; rg < 4; ++rg) biasv[kt][rg] = *(const float4*)(bsrc + kt * 32 + 8 * rg);
+        }
         f32x16 accS[2], accP[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -582,6 +601,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ P, dS' (fp32); bias / scale gradients
         {
+            const bool has_bias = p.bias != nullptr;
             const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
             const float fqn = hscale * qinv;  // d s / d (q . k^)
             const float fq2 = fqn * kLog2e;
@@ -595,10 +615,10 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    brow[kt][4 * rg] = biasv[kt][rg].x * kLog2e;
-                    brow[kt][4 * rg + 1] = biasv[kt][rg].y * kLog2e;
-                    brow[kt][4 * rg + 2] = biasv[kt][rg].z * kLog2e;
-                    brow[kt][4 * rg + 3] = biasv[kt][rg].w * kLog2e;
+                    brow[kt][4 * rg] = has_bias ? biasv[kt][rg].x * kLog2e : 0.f;
+                    brow[kt][4 * rg + 1] = has_bias ? biasv[kt][rg].y * kLog2e : 0.f;
+                    brow[kt][4 * rg + 2] = has_bias ? biasv[kt][rg].z * kLog2e : 0.f;
+                    brow[kt][4 * rg + 3] = has_bias ? biasv[kt][rg].w * kLog2e : 0.f;
                 }
             if (mixed) {
                 const int mylab = lab_s[qq];
@@ -841,7 +861,13 @@ int persistent_slots(const AttnParams& p, int groups, int waves_per_wg) {
 int bwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / hg, 2 * hg); }  // two wavefronts per head
 int fwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / hg, hg); }
 
+// Measured (B / nside 256 / batch 8, profiles/r02_attn_head_group_ab.txt): the width of the contiguous row segment a workgroup
+// moves matters more than the number of waves behind its barriers -- backward with one head per workgroup (64-byte segments)
+// is 15-25 % slower than with pairs at every stage, four heads (256-byte segments, but eight waves per barrier and one
+// workgroup per CU) 3-8 % slower than pairs; forward with 2 / 1 heads per workgroup 3-7 % / 20 % slower than with 4.
 int pick_head_group_bwd(int nH) {
+    static const int forced = getenv("HS_ATTN_BWD_HG") ? atoi(getenv("HS_ATTN_BWD_HG")) : 0;  // A/B runs
+    if (forced == 1 || (forced == 2 && nH % 2 == 0)) return forced;
     // 37 KB of LDS per head: pairs (128-B segments) where the head count allows; a 3-head group would need 112 KB and
     // leave one workgroup per CU, so odd head counts (nH = 3 at stage 0 of the T model) run one head per workgroup and
     // let the neighbouring workgroup's half of each 128-B line come from L2
@@ -876,6 +902,8 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
 }
 
 int pick_head_group(int nH) {
+    static const int forced = getenv("HS_ATTN_FWD_HG") ? atoi(getenv("HS_ATTN_FWD_HG")) : 0;  // A/B runs
+    if (forced >= 1 && forced <= 4 && nH % forced == 0) return forced;
     if (nH % 4 == 0) return 4;
     if (nH % 3 == 0) return 3;
     if (nH % 2 == 0) return 2;

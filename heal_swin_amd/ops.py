@@ -984,6 +984,100 @@ def concat_linear(x, skip, weight, bias=None):
 
 
 # ----------------------------------------------------------------------------- standalone shift (gather rows)
+class PatchMergeFn(torch.autograd.Function):
+    """PatchMerging.forward (ref :378-395) through the one-call C-ABI operators `hs_patch_merge_fwd/bwd`: x [B, N, C] bf16 ->
+    [B, N/4, dim_out].  The operator-level binding of INTEGRATION.md; the nn.Module mirror composes the same kernels itself
+    (per-shape choice between `hs_gemm_nt` and the library GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight):
+        _require_gpu(x, gamma, beta, weight)
+        B, N, C = x.shape
+        assert N % 4 == 0, f"x size {N} is not divisible by 4 as necessary for patching."
+        x = x.contiguous()
+        rows, dim_out = B * N // 4, weight.shape[0]
+        dt = _lib.dtype_code(x.dtype)
+        w = weight.detach().to(x.dtype).contiguous()
+        g, b = _f32(gamma), _f32(beta)
+        normed = torch.empty((rows, 4 * C), dtype=x.dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        out = torch.empty((B, N // 4, dim_out), dtype=x.dtype, device=x.device)
+        check(lib.hs_patch_merge_fwd(ptr(x), ptr(g), ptr(b), ptr(w), ptr(normed), ptr(mean), ptr(rstd), ptr(out), rows, C, dim_out, dt,
+                                     stream_ptr(x.device)), "hs_patch_merge_fwd")
+        ctx.save_for_backward(x, normed, g, mean, rstd, w)
+        ctx.meta = (rows, C, dim_out, dt, gamma.dtype, beta.dtype, weight.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, normed, g, mean, rstd, w = ctx.saved_tensors
+        rows, C, dim_out, dt, gdt, bdt, wdt = ctx.meta
+        dev = x.device
+        dout = dout.contiguous()
+        w_t = w.t().contiguous()
+        dnormed = torch.empty_like(normed)
+        dx = torch.empty_like(x)
+        dw = torch.empty((dim_out, 4 * C), dtype=torch.float32, device=dev)
+        dgamma = torch.empty(4 * C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(4 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.hs_patch_merge_bwd_workspace(rows, C, dim_out)), dtype=torch.float32, device=dev)
+        check(lib.hs_patch_merge_bwd(ptr(dout), ptr(x), ptr(normed), ptr(g), ptr(mean), ptr(rstd), ptr(w_t), ptr(dnormed), ptr(dx),
+                                     ptr(dw), ptr(dgamma), ptr(dbeta), ptr(ws), 0, rows, C, dim_out, dt, stream_ptr(dev)),
+              "hs_patch_merge_bwd")
+        return dx, dgamma.to(gdt), dbeta.to(bdt), dw.to(wdt)
+
+
+def patch_merge(x, gamma, beta, weight):
+    return PatchMergeFn.apply(x, gamma, beta, weight)
+
+
+class PatchExpandFn(torch.autograd.Function):
+    """PatchExpand.forward (ref :418-430, children = 4) / FinalPatchExpand_X4.forward (:441-452, children = patch_size) through
+    `hs_patch_expand_fwd/bwd`: x [B, N, C] bf16 -> [B, N children, dim_exp / children]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, children):
+        _require_gpu(x, gamma, beta, weight)
+        B, N, C = x.shape
+        x = x.contiguous()
+        rows, dim_exp = B * N, weight.shape[0]
+        dt = _lib.dtype_code(x.dtype)
+        w = weight.detach().to(x.dtype).contiguous()
+        g, b = _f32(gamma), _f32(beta)
+        expanded = torch.empty((rows, dim_exp), dtype=x.dtype, device=x.device)
+        mean = torch.empty(rows * children, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows * children, dtype=torch.float32, device=x.device)
+        out = torch.empty((B, N * children, dim_exp // children), dtype=x.dtype, device=x.device)
+        check(lib.hs_patch_expand_fwd(ptr(x), ptr(w), ptr(g), ptr(b), ptr(expanded), ptr(mean), ptr(rstd), ptr(out), rows, C, dim_exp,
+                                      children, dt, stream_ptr(x.device)), "hs_patch_expand_fwd")
+        ctx.save_for_backward(x, expanded, g, mean, rstd, w)
+        ctx.meta = (rows, C, dim_exp, children, dt, gamma.dtype, beta.dtype, weight.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, expanded, g, mean, rstd, w = ctx.saved_tensors
+        rows, C, dim_exp, children, dt, gdt, bdt, wdt = ctx.meta
+        dev = x.device
+        dout = dout.contiguous()
+        w_t = w.t().contiguous()
+        dexp = torch.empty_like(expanded)
+        dx = torch.empty_like(x)
+        dw = torch.empty((dim_exp, C), dtype=torch.float32, device=dev)
+        dgamma = torch.empty(dim_exp // children, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(dim_exp // children, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.hs_patch_expand_bwd_workspace(rows, C, dim_exp, children)), dtype=torch.float32, device=dev)
+        check(lib.hs_patch_expand_bwd(ptr(dout), ptr(x), ptr(expanded), ptr(g), ptr(mean), ptr(rstd), ptr(w_t), ptr(dexp), ptr(dx),
+                                      ptr(dw), ptr(dgamma), ptr(dbeta), ptr(ws), 0, rows, C, dim_exp, children, dt, stream_ptr(dev)),
+              "hs_patch_expand_bwd")
+        return dx, dw.to(wdt), dgamma.to(gdt), dbeta.to(bdt), None
+
+
+def patch_expand(x, weight, gamma, beta, children=4):
+    return PatchExpandFn.apply(x, weight, gamma, beta, children)
+
+
 class GatherRowsFn(torch.autograd.Function):
     """out[:, j] = x[:, idx[j]]  (or roll); backward gathers with the inverse table."""
 

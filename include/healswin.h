@@ -365,6 +365,41 @@ int hs_ln_head_fwd(const void* y, const void* wfold, const float* bvec, void* lo
 int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const void* dlogits, const void* afold, void* dy,
                    void* dprime, float* partials, int64_t rows, int width, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * PatchMerging / PatchExpand / FinalPatchExpand_X4 as one operator call per module and direction (SURVEY 8b's proposed
+ * hs_patch_merge_* / hs_patch_expand_*).  In nested HEALPix order the reference's data movement is a free view -- the four
+ * strided slices + cat of PatchMerging (models_torch/swin_hp_transformer.py:385-390) are [B, N, C] -> [B, N/4, 4C], PatchExpand's
+ * 'b n (p c) -> b (n p) c' (:427, :449) is [B, N, p c] -> [B, N p, c] -- so each module is a row LayerNorm and a bias-free
+ * Linear.  These entry points chain the library's own kernels (hs_layernorm_*, hs_gemm_nt, hs_linear_wgrad) on the caller's
+ * stream; bf16 only (HS_ERR_UNSUPPORTED otherwise: fp32 runs compose hs_layernorm_* with a library GEMM).
+ *
+ * hs_patch_merge_fwd   replaces PatchMerging.forward (:378-395):  out = LN_{4 dim}(x) W^T
+ *   x [dev] bf16[rows, 4 dim] = the stage output [B, N, dim] viewed as [B N/4, 4 dim]; gamma, beta [dev] f32[4 dim];
+ *   w [dev] bf16[dim_out, 4 dim] (nn.Linear layout; the reference has dim_out = 2 dim); normed [dev] bf16[rows, 4 dim],
+ *   mean, rstd [dev] f32[rows]: saved for the backward; out [dev] bf16[rows, dim_out].
+ * hs_patch_merge_bwd   its autograd: dx [dev] bf16[rows, 4 dim]; dw f32[dim_out, 4 dim], dgamma, dbeta f32[4 dim] overwritten
+ *   (accumulate == 0) or added to (the callers' .grad buffers); w_t [dev] bf16[4 dim, dim_out] = the transposed weight;
+ *   dnormed [dev] bf16[rows, 4 dim] scratch; workspace [dev] f32[hs_patch_merge_bwd_workspace(...)].
+ * hs_patch_expand_fwd  replaces PatchExpand.forward (:418-430; children = 4, dim_exp = 2 dim) and FinalPatchExpand_X4.forward
+ *   (:441-452; children = patch_size, dim_exp = patch_size dim):  out = LN_{dim_exp / children}( view(x W^T) )
+ *   x [dev] bf16[rows, dim]; w [dev] bf16[dim_exp, dim]; gamma, beta f32[dim_exp / children]; expanded [dev] bf16[rows, dim_exp],
+ *   mean, rstd [dev] f32[rows children]: saved; out [dev] bf16[rows children, dim_exp / children].
+ * hs_patch_expand_bwd  its autograd: w_t [dev] bf16[dim, dim_exp]; dexpanded [dev] bf16[rows, dim_exp] scratch; dx [dev]
+ *   bf16[rows, dim]; dw f32[dim_exp, dim]; dgamma, dbeta f32[dim_exp / children]; workspace as sized by the _workspace call.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_patch_merge_fwd(const void* x, const float* gamma, const float* beta, const void* w, void* normed, float* mean, float* rstd,
+                       void* out, int64_t rows, int dim, int dim_out, int dtype, void* stream);
+int64_t hs_patch_merge_bwd_workspace(int64_t rows, int dim, int dim_out);
+int hs_patch_merge_bwd(const void* dout, const void* x, const void* normed, const float* gamma, const float* mean, const float* rstd,
+                       const void* w_t, void* dnormed, void* dx, float* dw, float* dgamma, float* dbeta, float* workspace,
+                       int accumulate, int64_t rows, int dim, int dim_out, int dtype, void* stream);
+int hs_patch_expand_fwd(const void* x, const void* w, const float* gamma, const float* beta, void* expanded, float* mean, float* rstd,
+                        void* out, int64_t rows, int dim, int dim_exp, int children, int dtype, void* stream);
+int64_t hs_patch_expand_bwd_workspace(int64_t rows, int dim, int dim_exp, int children);
+int hs_patch_expand_bwd(const void* dout, const void* x, const void* expanded, const float* gamma, const float* mean, const float* rstd,
+                        const void* w_t, void* dexpanded, void* dx, float* dw, float* dgamma, float* dbeta, float* workspace,
+                        int accumulate, int64_t rows, int dim, int dim_exp, int children, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
