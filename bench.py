@@ -75,10 +75,10 @@ def build_model(wl, nside=None):
 
 
 def pmc_traffic_per_launch(attn_agg):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_attn_pmc_hbm_traffic.json: rocprofv3 --pmc
+    """HBM bytes per launch from the committed PMC passes (profiles/r02_attn_pmc_hbm_traffic.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, KiB units, FETCH x2 gfx950 correction), averaged over this run's launch
     mix by matching each launch's algorithmic byte count; None if a launch shape was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_attn_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_attn_pmc_hbm_traffic.json")
     if not os.path.exists(path):
         return None
     table = {}
@@ -329,7 +329,7 @@ def roofline_of(timings, elapsed, detail=False):
         "kernel": " + ".join(sorted(attn)) + " (fused shift / window partition / attention / reverse)",
         "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
         "traffic": traffic,
-        "traffic_source": "profiles/r01_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same "
+        "traffic_source": "profiles/r02_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same "
                           "kernels and shapes; looked up, not measured in this run)" if traffic is not None else None,
         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": tot_b / launches},

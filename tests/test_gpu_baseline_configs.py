@@ -127,3 +127,45 @@ def test_baseline_architecture_fwd_bwd_vs_oracle(name, dtype):
     assert_close(xg.grad, ref_dx, GRAD_TOL[dtype], tag + " dx")
     conftest.NOTES.append(f"{tag}: {len(ref_grads)} parameter gradients, worst max|a-b|/max|b| {worst[1]:.2e} ({worst[0]}), "
                           f"median rms {sorted(rms)[len(rms) // 2]:.2e}; input gradient {edx['scale_err']:.2e}")
+
+
+# ----------------------------------------------------------------------------- configs[2] at its FULL size (forward)
+_FULL = {}
+
+
+def _full_size_oracle():
+    """HEAL-SWIN-B, nside 256, 12 base pixels (786 432 pixels, 46 blocks), one image: oracle logits and loss, forward only under
+    no_grad (the oracle's autograd graph of this size holds every [windows, heads, 64, 64] score tensor: tens of GB)."""
+    if not _FULL:
+        from oracle import model as OM
+        CASES["_full"] = (B_CFG, 256, 12, 1, dict(shift_strategy="nest_roll", shift_size=32))
+        model, cfg, spec, x, y = _setup("_full")
+        del CASES["_full"]
+        sd = {k: v.detach() for k, v in model.state_dict().items() if not k.endswith("attn_mask")}
+        torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+        with torch.no_grad():
+            logits = OM.forward(sd, types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec), x)
+            loss = float(OM.seg_loss(logits, y))
+        _FULL.update(model=model, x=x, y=y, logits=logits, loss=loss)
+    return _FULL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_headline_config_full_size_logits_vs_oracle(dtype):
+    """BASELINE configs[2] exactly as bench.py runs it (HEAL-SWIN-B, nside 256, 12 base pixels, window 64, nest_roll 32), default
+    initialisation + N(0, 0.02) bias tables: logits within north_star's 1e-3 (fp32) / 1e-2 (bf16) of the oracle, CE loss equal."""
+    from heal_swin_amd.losses import seg_loss
+    f = _full_size_oracle()
+    model = f["model"].to(DEV).eval()
+    model.compute_dtype = dtype
+    for grad_mode in (True, False):  # the training kernels and the no-grad path (stage 0 through the one-launch module kernel)
+        with torch.set_grad_enabled(grad_mode):
+            logits = model(f["x"].to(DEV))
+            loss = float(seg_loss(logits, f["y"].to(DEV)))
+        tag = f"configs2_B_nside256_bp12_FULL[{'bf16' if dtype == torch.bfloat16 else 'fp32'}{'' if grad_mode else ', no_grad'}]"
+        e = errors(logits, f["logits"])
+        conftest.NOTES.append(f"{tag}: logits max|a-b|/max|b| {e['scale_err']:.2e} (scale {e['scale']:.2f}), rms {e['rms_err']:.2e}; "
+                              f"loss {loss:.6f} vs oracle {f['loss']:.6f}")
+        assert_close(logits, f["logits"], LOGIT_TOL[dtype], tag + " logits")
+        assert abs(loss - f["loss"]) <= (1e-4 if dtype == torch.float32 else 2e-3) * max(1.0, abs(f["loss"]))
+    f["model"].cpu()
