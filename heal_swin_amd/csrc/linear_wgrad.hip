@@ -49,7 +49,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int tok0, i
 }
 
 struct Geometry {
-    int tile_n, tile_k, tiles_n, tiles_k, tiles, slices, chunks, per_xcd, dma;
+    int tile_n, tile_k, tiles_n, tiles_k, tiles, slices, chunks, per_xcd, dma, reads_first;
     int64_t rows_per_slice;
 };
 
@@ -73,6 +73,10 @@ inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int 
     g.per_xcd = (g.slices * g.tiles + 7) / 8;
     // the LDS-DMA kernels address a slice through 32-bit buffer offsets
     g.dma = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * elt < ((int64_t)1 << 31);
+    static const int reads_first = getenv("HS_WGRAD_READS_FIRST") ? atoi(getenv("HS_WGRAD_READS_FIRST")) : 3;
+    // stage schedule of the LDS-DMA kernels (A/B hook): 0 = next stage's DMA issued before the fragment reads, 1 = behind them,
+    // 2 = behind the first MFMA group, 3 (default) = 1 + the second wave group half a stage out of phase (8-wave tile)
+    g.reads_first = reads_first;
     return g;
 }
 
@@ -348,8 +352,65 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
 
     // one stage; the buffer indices are compile-time constants (loop unrolled by NSTAGE) so that the compiler can tell the
     // DMA's destination buffer from the one being read: with run-time indices it orders them with an s_waitcnt vmcnt(0)
+    s16x8 af[2][NB], bf[2][2];  // the stage's MFMA operands (the second wave group keeps them across the barrier, see below)
+    auto read_frags = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[ks][j] = tr_frag_asm<XRB>(lds0 + buf * STAGE + xoff[j], ks);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) af[ks][i] = tr_frag_asm<YRB>(lds0 + buf * STAGE + yoff[i], ks);
+        }
+    };
+    auto wait_half = [&](int ks) {  // ks = 0: first half landed once at most the second half's 2 * (NB + 2) reads are outstanding
+        if constexpr (NB == 4) {
+            if (ks == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]));
+        } else {
+            if (ks == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(af[0][0]), "+v"(af[0][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(af[1][0]), "+v"(af[1][1]));
+        }
+    };
+    auto mma_half = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks][i]), __builtin_bit_cast(bf16x8, bf[ks][j]), acc[i][j], 0, 0, 0);
+    };
+    auto bias_sums = [&](auto buf_c) {  // column sums of the staged dY tile (also asm reads: a plain LDS load would drain the DMA queue)
+        constexpr int buf = decltype(buf_c)::value;
+        constexpr int PS = kTok / (NT / YCH);
+        u32x4 v[PS];
+        const uint32_t ba = lds0 + buf * STAGE + boff;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(ba));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[1]) : "v"(ba), "n"((NT / YCH) * YRB));
+        if constexpr (PS == 4) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[2]) : "v"(ba), "n"(2 * (NT / YCH) * YRB));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[3]) : "v"(ba), "n"(3 * (NT / YCH) * YRB));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
+        }
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bsum[2 * i] += __uint_as_float(v[ps][i] << 16);
+                bsum[2 * i + 1] += __uint_as_float(v[ps][i] & 0xffff0000u);
+            }
+        }
+    };
+    // ALTERNATING WAVE GROUPS (8-wave tile): the workgroup barrier of every stage phase-locks the two waves of a SIMD -- both
+    // read their fragments, both wait for the LDS, both then want the matrix pipe, both idle at the next barrier -- so the pipe
+    // sits idle for a whole barrier + DMA issue + LDS round trip per stage (measured: MFMA busy 49 %, ~2070 cycles per stage
+    // for 1024 cycles of MFMA work per SIMD).  Waves 4..7 (the second wave of each SIMD) therefore run HALF A STAGE OUT OF PHASE:
+    // behind barrier t they first multiply the fragments of stage t - 1, which they fetched before the barrier, and only then
+    // fetch stage t's; waves 0..3 fetch first and multiply second.  One group always has MFMAs to issue while the other waits.
+    const bool late_group = NW == 8 && g.reads_first == 3 && wave >= NW / 2;
     auto stage = [&](int t, auto buf_c, auto nbuf_c) {
-        constexpr int buf = decltype(buf_c)::value, nbuf = decltype(nbuf_c)::value;
+        constexpr int nbuf = decltype(nbuf_c)::value;
         // stage t has landed once only the younger stages still issued (at most AH - 1, fewer at the tail) are outstanding
         const int younger = nst - 1 - t;
         if (AH - 1 >= 2 && younger >= 2)
@@ -359,59 +420,31 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + AH < nst) issue(nbuf);
-        s16x8 af[2][NB], bf[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[ks][j] = tr_frag_asm<XRB>(lds0 + buf * STAGE + xoff[j], ks);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) af[ks][i] = tr_frag_asm<YRB>(lds0 + buf * STAGE + yoff[i], ks);
+        if (late_group) {
+            if (t > 0) {
+                mma_half(0);
+                mma_half(1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + AH < nst) issue(nbuf);
+            read_frags(buf_c);
+            if (do_bias) bias_sums(buf_c);
+            wait_half(0);
+            wait_half(1);  // complete before this wave arrives at the next barrier (which releases the buffer for a refill)
+            return;
         }
-        // first half landed once at most the second half's 2 * (NB + 2) reads are outstanding
-        if constexpr (NB == 4) {
-            asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]));
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(af[0][0]), "+v"(af[0][1]));
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[0][i]), __builtin_bit_cast(bf16x8, bf[0][j]), acc[i][j], 0, 0, 0);
+        if (g.reads_first == 0 && t + AH < nst) issue(nbuf);
+        read_frags(buf_c);
+        // the next stage's DMA issued BEHIND this stage's fragment reads: its ~100 issue cycles per piece then cover the LDS
+        // latency of the reads instead of standing in front of them (1.5-2 % over issuing it first)
+        if (g.reads_first != 0 && g.reads_first != 2 && t + AH < nst) issue(nbuf);
+        wait_half(0);
+        mma_half(0);
         __builtin_amdgcn_sched_barrier(0);  // keep the first half's MFMAs ahead of the second wait
-        if constexpr (NB == 4) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]));
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(af[1][0]), "+v"(af[1][1]));
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[1][i]), __builtin_bit_cast(bf16x8, bf[1][j]), acc[i][j], 0, 0, 0);
-        if (do_bias) {  // column sums of the staged dY tile (also asm reads: a plain LDS load would drain the DMA queue)
-            constexpr int PS = kTok / (NT / YCH);
-            u32x4 v[PS];
-            const uint32_t ba = lds0 + buf * STAGE + boff;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(ba));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[1]) : "v"(ba), "n"((NT / YCH) * YRB));
-            if constexpr (PS == 4) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[2]) : "v"(ba), "n"(2 * (NT / YCH) * YRB));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[3]) : "v"(ba), "n"(3 * (NT / YCH) * YRB));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
-            }
-#pragma unroll
-            for (int ps = 0; ps < PS; ++ps) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bsum[2 * i] += __uint_as_float(v[ps][i] << 16);
-                    bsum[2 * i + 1] += __uint_as_float(v[ps][i] & 0xffff0000u);
-                }
-            }
-        }
+        if (g.reads_first == 2 && t + AH < nst) issue(nbuf);  // (A/B) in the shadow of the first half's MFMAs
+        wait_half(1);
+        mma_half(1);
+        if (do_bias) bias_sums(buf_c);
     };
     if (nst > 0) issue(0);
     if (nst > 1) issue(1);
@@ -428,6 +461,11 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
             if (t + 2 < nst) stage(t + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
             if (t + 3 < nst) stage(t + 3, integral_constant<int, 3>{}, integral_constant<int, 2>{});
         }
+    }
+
+    if (late_group && nst > 0) {  // the last stage's fragments are still to be multiplied
+        mma_half(0);
+        mma_half(1);
     }
 
     float* dst = part_w + (int64_t)slice * ((int64_t)n_out * k_in + n_out);
