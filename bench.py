@@ -332,7 +332,10 @@ def roofline_of(timings, elapsed, detail=False):
         "traffic_source": "profiles/r02_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same "
                           "kernels and shapes; looked up, not measured in this run)" if traffic is not None else None,
         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": tot_b / launches},
+                "algorithmic_bytes_per_launch": tot_b / launches,
+                # what a pure read stream reaches on this chip (tools/microbench/fill_rate.hip, 1 GB working set, every CU
+                # streaming: profiles/r02_microbench_fill_rate.txt) -- the vendor figure above is the contract's denominator
+                "measured_read_ceiling_GBs": 6300.0, "frac_of_measured_ceiling": gbs / 6300.0},
         "algorithmic_flops_per_launch": tot_f / launches,
         "avg_launch_us": 1e6 * tot_t / launches, "launches": launches, "share_of_step": tot_t / elapsed,
         "per_kernel": {tag: {"launches": a[3], "avg_us": 1e6 * a[0] / a[3], "GB/s": a[1] / a[0] / 1e9,
