@@ -35,6 +35,7 @@ class GradBucketAllReduce:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # a one-rank group normally skips the collectives; exchange_single_rank keeps them (exercises the RCCL path on one GPU)
         self._exchange = self.world > 1 or (exchange_single_rank and dist.is_initialized())
+        self._avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.buckets = []       # flat fp32 tensors
         self._counts = []       # parameters per bucket
         self._where = {}        # param -> bucket id
@@ -201,8 +202,11 @@ class GradBucketAllReduce:
         flat = self.buckets[b]
         if self.async_wgrad is not None:
             self.async_wgrad.sync()  # gradients deposited from the side stream must have landed before the exchange
-        flat.mul_(1.0 / self.world)  # average, as DDP does (gloo has no AVG op)
-        self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._avg_in_collective:  # RCCL averages inside the all-reduce: no extra pass over the bucket
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:
+            flat.mul_(1.0 / self.world)  # average, as DDP does (gloo has no AVG op)
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._launched[b] = True
         self._reduced = True
 
