@@ -30,21 +30,21 @@ WORKLOADS = {
     # BASELINE.json configs[2]: HEAL-SWIN-B, nside 256, 12 base pixels (full sphere), window 64 (nest_roll: the only
     # shift valid for 12 base pixels), 12 classes
     "B256": dict(name="HEAL-SWIN-B nside=256 base_pix=12 window=64 nest_roll(shift 32) seg 12 classes",
-                 nside=256, base_pix=12, f_out=12,
+                 nside=256, base_pix=12, f_out=12, fwd_gflop_per_image=3799.23,
                  cfg=dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=64, shift_size=32,
                           shift_strategy="nest_roll", rel_pos_bias="flat")),
     # the paper's run config (run_configs/segmentation/swin_hp_synwoodscape_large_plus_AD_train_run_config.py:35-96)
     "T256": dict(name="HEAL-SWIN-T (paper) nside=256 base_pix=8 window=64 ring_shift(4) cos-attn v2-norm seg 12 classes",
-                 nside=256, base_pix=8, f_out=12,
+                 nside=256, base_pix=8, f_out=12, fwd_gflop_per_image=722.26,
                  cfg=dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=64, shift_size=4,
                           shift_strategy="ring_shift", rel_pos_bias="flat", use_cos_attn=True, use_v2_norm_placement=True)),
     # BASELINE.json configs[1]
     "T128": dict(name="HEAL-SWIN-T nside=128 base_pix=8 window=64 nest_roll(shift 32) seg 12 classes",
-                 nside=128, base_pix=8, f_out=12,
+                 nside=128, base_pix=8, f_out=12, fwd_gflop_per_image=180.56,
                  cfg=dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=64, shift_size=32,
                           shift_strategy="nest_roll", rel_pos_bias="flat")),
     # BASELINE.json configs[0] shape (plumbing)
-    "tiny": dict(name="HEAL-SWIN-tiny nside=32 base_pix=4 window=16", nside=32, base_pix=4, f_out=12,
+    "tiny": dict(name="HEAL-SWIN-tiny nside=32 base_pix=4 window=16", nside=32, base_pix=4, f_out=12, fwd_gflop_per_image=0.67,
                  cfg=dict(embed_dim=48, depths=[2, 2, 2], num_heads=[3, 6, 12], window_size=16, shift_size=8,
                           shift_strategy="nest_roll", rel_pos_bias="flat")),
 }
@@ -280,6 +280,11 @@ def main():
                        "params_M": res.params_m, "final_loss": res.loss,
                        "library_gemm_selection": "TunableOp tuning run" if args.tune_gemm else ("TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic")},
         }
+        # whole-step model FLOPs (analytic forward count == FlopCounterMode; backward = 2x) against the dense bf16 peak
+        if wl.get("fwd_gflop_per_image"):
+            tf = 3 * wl["fwd_gflop_per_image"] * images / elapsed / 1e3
+            out["model_flops"] = {"fwd_GFLOP_per_image": wl["fwd_gflop_per_image"], "achieved_TFLOPs": tf,
+                                  "frac_of_dense_bf16_peak": tf / (MFMA_PEAK_TFLOPS * world) if args.dtype == "bf16" else None}
         if world > 1:
             out["rccl"] = res.rccl
         if res.timings:
