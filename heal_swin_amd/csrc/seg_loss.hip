@@ -180,8 +180,11 @@ __global__ void __launch_bounds__(256) seg_ce_bwd_row16_kernel(CeArgs a, const f
     }
 }
 
+// The fast path reads the WHOLE 32-byte row of a pixel (two 16-byte loads): only for K > 8 (the second load then overlaps the
+// K used columns) and a pointer at the start of a 32-byte row -- a caller view such as buf[..., 8:16] (sp = 16, K = 8) would
+// otherwise read 16 bytes past the storage on its last pixel.
 bool row16_layout(const void* ptr, int64_t sb, int64_t sk, int64_t sp, int K, int dtype) {
-    return dtype == HS_BF16 && sk == 1 && sp == kRow && K <= kRow && K % 4 == 0 && sb % 8 == 0 && ((uintptr_t)ptr & 15) == 0;
+    return dtype == HS_BF16 && sk == 1 && sp == kRow && K > 8 && K <= kRow && K % 4 == 0 && sb % kRow == 0 && ((uintptr_t)ptr & 31) == 0;
 }
 
 int check_args(const CeArgs& a, int dtype) {

@@ -339,7 +339,11 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
 // ================================================================================================ backward
 // Per (window, head), on one wave, 40 MFMAs (the minimum: S, dP, dV, dK, dQ):
 //   S^T  = K^ Q^T , dP^T = V dO^T                       (lane = query, registers = keys)
-//   P^T  = exp2(S^T*f + bias - lse) ;  dS^T = P^T o (dP^T - D) ,  D[q] = dO[q].O[q]
+//   P^T  = exp2(S^T*f + bias - lse) ;  dS^T = P^T o (dP^T - D) ,  D[q] = sum_k P[q][k] dP[q][k]  (= dO[q].O[q], but formed
+//                                     from the fp32 P and dP of this very pass: a query's 64 keys sit in one lane pair, so D is
+//                                     32 FMAs + one lane^32 exchange, sum_k dS[q][k] = 0 holds to fp32 rounding instead of to the
+//                                     bf16 rounding of the stored O, and the O rows are not read at all: 7 instead of 8 row
+//                                     streams per token and head)
 //   dS' = dS * f_q   (f_q = head scale [* 1/|q| for cosine])  ->  ONE bf16 matrix feeds both dK and dQ
 //   dV = P^T dO ,  dK^ = dS'^T Q      A operands = P / dS' TRANSPOSED: stored row-major [q][key] in an LDS scratch and
 //                                     read back with ds_read_b64_tr_b16 (hardware 4x16 transpose); B operands (dO, Q:
@@ -358,15 +362,14 @@ constexpr int kPsBytes = kWs * kPsLd;         // 8704
 struct LdsLayoutBwd {
     // per head: Q | K | V | dO tiles (4096 each) | P/dS' scratch [64][64] bf16 (padded) | dq, dk, dv staging (4096 each);
     // then per-row scalars
-    int head, scratch_off, stage_off, qinv, kinv, dsum, lab, total;
+    int head, scratch_off, stage_off, qinv, kinv, lab, total;
     __host__ __device__ explicit LdsLayoutBwd(int hg) {
         scratch_off = 4 * kTileBytes;
         stage_off = scratch_off + kPsBytes;
         head = stage_off + 3 * kTileBytes;  // 37376 bytes per head
         qinv = hg * head;
         kinv = qinv + hg * kWs * 4;
-        dsum = kinv + hg * kWs * 4;
-        lab = dsum + hg * kWs * 4;
+        lab = kinv + hg * kWs * 4;
         total = lab + kWs + 16;
     }
 };
@@ -418,7 +421,6 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     constexpr bool cosine = COS;  // compile-time: the plain variant carries none of the norm / scale-gradient arithmetic
     const float hscale = p.head_scale[h];
     const uint16_t* qkv = (const uint16_t*)p.qkv;
-    const uint16_t* fo = (const uint16_t*)p.out;
     const uint16_t* dout = (const uint16_t*)p.dout;
     uint16_t* dqkv = (uint16_t*)p.dqkv;
 
@@ -431,7 +433,6 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     unsigned char* stg = my + L.stage_off;  // [dq | dk | dv] row-major [64][32] bf16
     float* qinv_s = (float*)(smem + L.qinv);
     float* kinv_s = (float*)(smem + L.kinv);
-    float* dsum_s = (float*)(smem + L.dsum);
     unsigned char* lab_s = smem + L.lab;
     const int qq = qt * 32 + l31;  // this lane's query
 
@@ -445,13 +446,13 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
     float dscale_acc = 0.f;
 
-    // Software pipeline (non-cosine variants; the cosine ones are at the register limit): the q, k, v, dO, O rows of window
+    // Software pipeline (non-cosine variants; the cosine ones are at the register limit): the q, k, v, dO rows of window
     // i+1 are requested into registers right after window i's MFMA phases, when the accumulators are dead, and land while
     // window i's partial sums are exchanged and its results stored.  The workgroup barriers of that tail are RAW s_barrier
     // instructions behind an explicit lgkmcnt(0): __syncthreads() would also wait for the loads in flight (vmcnt(0)) and
     // undo the overlap -- PMC had the waves parked 62 % of their cycles (SQ_WAIT_ANY).
-    constexpr bool PREFETCH = !COS;
-    uint4 ldq[2], ldk[2], ldv[2], lddo[2], ldo[2];
+    constexpr bool PREFETCH = !(COS && DROP);
+    uint4 ldq[2], ldk[2], ldv[2], lddo[2];
     int64_t tok_next[2];
     float lse_next = 0.f;
     auto issue_loads = [&](int64_t wi_l) {
@@ -468,7 +469,6 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             ldk[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + C + col_l);
             ldv[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + 2 * (int64_t)C + col_l);
             lddo[rb] = *(const uint4*)(dout + tok_next[rb] * C + col_l);
-            ldo[rb] = *(const uint4*)(fo + tok_next[rb] * C + col_l);
         }
         // this lane's query row of the saved log-sum-exp (needed first thing in the P / dS' phase)
         lse_next = p.lse[((int64_t)b_l * p.nH + h) * N + j_l + qt * 32 + (lane & 31)];
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         const int qq = qt * 32 + l31;
         const int lane = lane_o;
 
-        // ------------------------------------------------------------ stage q, k^, v, dO; D = dO.O; norms
+        // ------------------------------------------------------------ stage q, k^, v, dO; norms
         int64_t tok[2];
         if constexpr (!PREFETCH) issue_loads(wi);
 #pragma unroll
@@ -516,21 +516,15 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             uint4 vk = ldk[rb];
             const uint4 vv = ldv[rb];
             const uint4 vdo = lddo[rb];
-            const uint4 vo = ldo[rb];
-            const uint32_t wq[4] = {vq.x, vq.y, vq.z, vq.w}, wdo[4] = {vdo.x, vdo.y, vdo.z, vdo.w}, wo[4] = {vo.x, vo.y, vo.z, vo.w};
-            uint32_t wk[4] = {vk.x, vk.y, vk.z, vk.w};
-            float ds = 0.f, sq = 0.f, sk = 0.f;
+            if (cosine) {
+                const uint32_t wq[4] = {vq.x, vq.y, vq.z, vq.w};
+                uint32_t wk[4] = {vk.x, vk.y, vk.z, vk.w};
+                float sq = 0.f, sk = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ds += bf_lo(wdo[i]) * bf_lo(wo[i]) + bf_hi(wdo[i]) * bf_hi(wo[i]);
-                if constexpr (COS) {
+                for (int i = 0; i < 4; ++i) {
                     sq += bf_lo(wq[i]) * bf_lo(wq[i]) + bf_hi(wq[i]) * bf_hi(wq[i]);
                     sk += bf_lo(wk[i]) * bf_lo(wk[i]) + bf_hi(wk[i]) * bf_hi(wk[i]);
                 }
-            }
-            ds += __shfl_xor(ds, 1, 64);
-            ds += __shfl_xor(ds, 2, 64);
-            if (cosine) {
                 sq += __shfl_xor(sq, 1, 64);
                 sq += __shfl_xor(sq, 2, 64);
                 sk += __shfl_xor(sk, 1, 64);
@@ -544,7 +538,6 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                     kinv_s[sg * kWs + row] = kinv;
                 }
             }
-            if (scc == 0) dsum_s[sg * kWs + row] = ds;
             const int off = swz(row, scc);
             *(uint4*)(st + off) = vq;
             *(uint4*)(st + kTileBytes + off) = vk;
@@ -606,10 +599,9 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             const float fqn = hscale * qinv;  // d s / d (q . k^)
             const float fq2 = fqn * kLog2e;
             const float lse2 = lse_cur * kLog2e;
-            const float dsum = dsum_s[g * kWs + qq];
             const DropRng rng(p, ((int64_t)b * p.nH + h) * N + j0 + qq);
             // bias (log2 domain) and, in the rare windows cut by the shift boundary, the mask: folded into one additive term
-            // under a single wave-uniform branch so that the element loop below is branch-free
+            // under a single wave-uniform branch so that the element loops below are branch-free
             float brow[2][16];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -628,6 +620,9 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                     for (int r = 0; r < 16; ++r)
                         if (lab_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != mylab) brow[kt][r] += kMaskLog2;
             }
+            // pass 1: P and the (dropout-masked) dP in place; D = sum_k P dP over this lane's 32 keys.  Cosine attention also
+            // needs sum_k dS S_raw = sum_k P dP S_raw - D sum_k P S_raw for the logit-scale gradient: two more running sums
+            float dsum = 0.f, s_pds = 0.f, s_ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -635,16 +630,36 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                     const float sraw = accS[kt][r];
                     const float t = fmaf(sraw, fq2, brow[kt][r]);
                     const float pr = __builtin_amdgcn_exp2f(t - lse2);
-                    float dpv = accP[kt][r], prd = pr;
-                    if constexpr (DROP) {  // the forward multiplied V by P o mask/(1-p): regenerate the same mask
-                        const float mlt = rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-                        dpv *= mlt;
-                        prd *= mlt;
+                    float dpv = accP[kt][r];
+                    if constexpr (DROP)  // the forward multiplied V by P o mask/(1-p): regenerate the same mask
+                        dpv *= rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                    dsum = fmaf(pr, dpv, dsum);
+                    if constexpr (COS) {
+                        const float ps = pr * sraw;
+                        s_ps += ps;
+                        s_pds = fmaf(ps, dpv, s_pds);
                     }
-                    const float dsv = pr * (dpv - dsum);
+                    accS[kt][r] = pr;
+                    accP[kt][r] = dpv;
+                    // (cosine: S_raw is needed again after the exp2; unfenced, the scheduler issues all 32 exp2 first and keeps
+                    // 32 extra values alive, which spills at the 256-VGPR limit of two waves per SIMD)
+                    if constexpr (COS)
+                        if ((r & 7) == 7) asm volatile("" : "+v"(dsum), "+v"(s_ps), "+v"(s_pds));
+                }
+            dsum += __shfl_xor(dsum, 32, 64);  // the other 32 keys of this query
+            if constexpr (COS) dscale_acc = fmaf(qinv, s_pds - dsum * s_ps, dscale_acc);  // this lane's share of sum_k dS S_raw / |q|
+            // pass 2: dS = P o (dP - D); bias gradient; the operands of the three products
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = accS[kt][r];
+                    const float dsv = pr * (accP[kt][r] - dsum);
                     dbacc[kt][r] += dsv;
-                    if constexpr (COS) dscale_acc = fmaf(dsv * qinv, sraw, dscale_acc);
-                    accP[kt][r] = prd;        // (dropped) P, the operand of dV
+                    if constexpr (DROP)
+                        accP[kt][r] = pr * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);  // dropped P, the operand of dV
+                    else
+                        accP[kt][r] = pr;
                     accS[kt][r] = dsv * fqn;  // dS'
                 }
         }

@@ -30,6 +30,7 @@
 //     whole 2C-byte token rows to out[token] (the scatter half of the shift).
 // All LDS traffic of the main phases is inline asm: a compiler-visible LDS access beside the DMA queue would be preceded by
 // s_waitcnt vmcnt(0) and serialise the next window's loads behind every phase.
+#include <algorithm>
 #include <type_traits>
 
 #include "window_attn.h"
@@ -564,15 +565,25 @@ int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const
     if (!hs_window_attn_module_supported(channels, num_heads, window_size, dtype))
         return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_fwd: bf16, window 64, head_dim 32 and C = 96 or 128 only (got C = %d, "
                     "heads %d, window %d): the qkv weights must fit the LDS", channels, num_heads, window_size);
-    if ((int64_t)batch * n_tokens * channels * 2 > 0x7FFFFE00ll)
-        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_fwd: activation tensor beyond the 2 GiB buffer-offset range");
-    ModParams p{};
-    p.x = (const uint16_t*)x; p.out = (uint16_t*)out; p.qkv_w = (const uint16_t*)qkv_w; p.qkv_b = qkv_b;
-    p.proj_w = (const uint16_t*)proj_w; p.proj_b = proj_b; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.bias = bias;
-    p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = batch; p.N = n_tokens;
-    p.flags = flags;
+    // The x tiles are addressed through a buffer descriptor (32-bit byte offsets, < 2 GiB): larger activation tensors are
+    // processed in batch chunks of whole images, one launch each (images are independent).
+    const int64_t image_bytes = n_tokens * channels * 2;
+    if (image_bytes > 0x7FFFFE00ll)
+        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_fwd: one image beyond the 2 GiB buffer-offset range");
+    const int chunk = (int)std::min<int64_t>(batch, 0x7FFFFE00ll / image_bytes);
     const bool cosine = (flags & HS_ATTN_COSINE) != 0;
-    return num_heads == 4 ? launch_module<4>(p, cosine, (hipStream_t)stream) : launch_module<3>(p, cosine, (hipStream_t)stream);
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        ModParams p{};
+        p.x = (const uint16_t*)x + (int64_t)b0 * n_tokens * channels;
+        p.out = (uint16_t*)out + (int64_t)b0 * n_tokens * channels;
+        p.qkv_w = (const uint16_t*)qkv_w; p.qkv_b = qkv_b;
+        p.proj_w = (const uint16_t*)proj_w; p.proj_b = proj_b; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.bias = bias;
+        p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = std::min(chunk, batch - b0);
+        p.N = n_tokens; p.flags = flags;
+        const int rc = num_heads == 4 ? launch_module<4>(p, cosine, (hipStream_t)stream) : launch_module<3>(p, cosine, (hipStream_t)stream);
+        if (rc != HS_OK) return rc;
+    }
+    return HS_OK;
 }
 
 }  // extern "C"

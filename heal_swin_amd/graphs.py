@@ -73,4 +73,10 @@ class GraphedTrainStep:
         self.inputs.copy_(inputs, non_blocking=True)
         self.targets.copy_(targets, non_blocking=True)
         self.graph.replay()
+        # The replay updated the parameters on the device without touching their Python-side version counters, which is what
+        # ops.ParamCastCache keys its bf16 copies on: an EAGER forward after this replay (validation, the no-grad fused path)
+        # must re-make them.  (The replayed step itself refreshes its copies inside the graph.)  Host-only, no launch.
+        invalidate = getattr(self.model, "invalidate_param_casts", None)
+        if invalidate is not None:
+            invalidate()
         return self.loss

@@ -51,8 +51,7 @@ class _SegCrossEntropyFn(torch.autograd.Function):
             from . import ops
             full = torch.zeros((B, P, sp), dtype=logits.dtype, device=logits.device)
             dl = full[:, :, :K].transpose(1, 2)
-            ops.ZERO_PADDED_GRADS.clear()
-            ops.ZERO_PADDED_GRADS[full.data_ptr()] = full
+            ops.ZERO_PADDED_GRADS[full.data_ptr()] = full  # weak: the entry lives exactly as long as the gradient does
         else:
             dl = torch.empty_like(logits)
         scale = (grad.to(torch.float32) / tot[1]).reshape(1)
@@ -89,36 +88,45 @@ def depth_unstandardize(d):
 
 
 def _finite(target):
-    return ~torch.isinf(target).detach()
+    """(keep mask, target with the infinite entries replaced by 0, number of finite entries as an fp32 device scalar).
+    The reference selects the finite pixels by boolean-mask indexing (`preds[~isinf(target)]`), which on a device costs a
+    `nonzero` and a device-to-host synchronisation per call and cannot be captured in a HIP graph; the same mean is formed
+    here as masked sum / count, all on the device."""
+    keep = ~torch.isinf(target).detach()
+    return keep, torch.where(keep, target, torch.zeros((), dtype=target.dtype, device=target.device)), keep.sum().to(torch.float32)
+
+
+def _masked_mean(values, keep, count):
+    return torch.where(keep, values, torch.zeros((), dtype=values.dtype, device=values.device)).sum() / count
 
 
 def depth_l1_loss(pred, target, mask_background=False):
     """mean |pred[:,0] - target| over non-inf targets (heal_swin/training/loss_depth_regression.py:41-53)."""
-    keep = _finite(target)
-    return (pred[:, 0].float()[keep] - target[keep]).abs().mean()
+    keep, tgt, n = _finite(target)
+    return _masked_mean((pred[:, 0].float() - tgt).abs(), keep, n)
 
 
 def depth_l2_loss(pred, target, mask_background=False):
     """`mse`: mean (pred[:,0] - target)^2 / 2 over non-inf targets (loss_depth_regression.py:9-21)."""
-    keep = _finite(target)
-    return ((pred[:, 0].float()[keep] - target[keep]) ** 2 / 2).mean()
+    keep, tgt, n = _finite(target)
+    return _masked_mean((pred[:, 0].float() - tgt) ** 2 / 2, keep, n)
 
 
 def depth_huber_loss(pred, target, mask_background=False, delta=1.0):
     """SmoothL1Loss(beta=delta, reduction='mean') over non-inf targets (loss_depth_regression.py:56-68); like the reference
     (which indexes all channels of `preds` with the [B,1,Npix] mask) it is defined for one-channel predictions."""
     assert pred.shape[1] == 1, "huber_loss needs a one-channel prediction (reference loss_depth_regression.py:66)"
-    keep = _finite(target)
-    d = (pred[:, 0].float()[keep] - target[keep]).abs()
-    return torch.where(d < delta, 0.5 * d * d / delta, d - 0.5 * delta).mean()
+    keep, tgt, n = _finite(target)
+    d = (pred[:, 0].float() - tgt).abs()
+    return _masked_mean(torch.where(d < delta, 0.5 * d * d / delta, d - 0.5 * delta), keep, n)
 
 
 def depth_mean_log_var_loss(pred, target, mask_background=False):
     """mean of log_var/2 + (mean - target)^2 exp(-log_var)/2 over non-inf targets, channel 0 = mean, channel 1 = log variance
     (loss_depth_regression.py:23-38)."""
-    keep = _finite(target)
-    means, log_var = pred[:, 0].float()[keep], pred[:, 1].float()[keep]
-    return (0.5 * log_var + (means - target[keep]) ** 2 * (0.5 * torch.exp(-log_var))).mean()
+    keep, tgt, n = _finite(target)
+    means, log_var = pred[:, 0].float(), pred[:, 1].float()
+    return _masked_mean(0.5 * log_var + (means - tgt) ** 2 * (0.5 * torch.exp(-log_var)), keep, n)
 
 
 def get_depth_loss(common_depth_config):

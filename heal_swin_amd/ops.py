@@ -5,6 +5,7 @@ below runs in the HIP library.  All ops require CUDA(HIP) tensors and raise othe
 """
 import math
 import os
+import weakref
 
 import torch
 
@@ -153,8 +154,10 @@ class WindowAttnCoreFn(torch.autograd.Function):
         dscale = zeros[nb:].view(hs.shape)
         nws = int(lib.hs_window_attn_bwd_workspace(B, N, C, nh, ws, dt))
         wsp = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws else None
-        # algorithmic traffic: qkv (3C) + out (C) + dout (C) read, dqkv (3C) written; flops: 5 contractions of 2*Ws*hd
-        with _timed("window_attn_bwd", qkv.device, 8 * B * N * C * qkv.element_size(), 10 * B * N * C * ws):
+        # algorithmic traffic: qkv (3C) + dout (C) read, dqkv (3C) written -- plus out (C) in the fp32 / VALU kernels; the bf16
+        # MFMA kernel forms D = rowsum(P o dP) from its own registers and never reads `out`; flops: 5 contractions of 2*Ws*hd
+        streams = 7 if (qkv.dtype == torch.bfloat16 and ws == 64 and C == 32 * nh and not (flags & _lib.HS_ATTN_FORCE_VALU)) else 8
+        with _timed("window_attn_bwd", qkv.device, streams * B * N * C * qkv.element_size(), 10 * B * N * C * ws):
             check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale), ptr(wsp),
                                          ptr(bias_c), ptr(hs), ptr(idx), roll, ptr(labels),
                                          B, N, C, nh, ws, flags, ctx.drop[0], ctx.drop[1], dt, stream_ptr(qkv.device)),
@@ -737,7 +740,10 @@ def linear_passthrough(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias, True)
 
 
-ZERO_PADDED_GRADS = {}  # data_ptr -> zero-padded gradient buffer written by losses.seg_loss' backward (see PadSliceFn)
+# data_ptr -> zero-padded gradient buffer written by losses.seg_loss' backward (see PadSliceFn).  WEAK values: an entry exists only
+# while the buffer itself is alive (i.e. while autograd still holds the gradient view into it), so nothing is retained when no
+# PadSliceFn consumes it, and a recycled address cannot resurrect a dead buffer.
+ZERO_PADDED_GRADS = weakref.WeakValueDictionary()
 
 
 class PadSliceFn(torch.autograd.Function):
@@ -753,7 +759,7 @@ class PadSliceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         full = ZERO_PADDED_GRADS.pop(g.data_ptr(), None)
-        if (full is not None and full.numel() == math.prod(ctx.shape) and full.dtype == g.dtype and
+        if (full is not None and g._base is full and full.numel() == math.prod(ctx.shape) and full.dtype == g.dtype and
                 g.shape == ctx.shape[:-1] + (ctx.n,) and g.stride() == full.view(ctx.shape)[..., :ctx.n].stride()):
             return full.view(ctx.shape), None
         out = g.new_zeros(ctx.shape)

@@ -175,12 +175,18 @@ def _stage(x, sd, pre, depth, num_heads, cfg, base_pix, rel_index):
     return x
 
 
-def forward(sd, cfg, spec, x):
+def forward(sd, cfg, spec, x, taps=None):
     """reference SwinHPTransformerSys.forward :948-955 (+ forward_features :930-946, UnetDecoder.forward
     :765-791).  `sd`: reference-layout state dict of fp32 tensors; `cfg`: anything with the
     SwinHPTransformerConfig fields (:794-818); `spec`: anything with dim_in, f_in, f_out, base_pix.
     x: [B, f_in, dim_in] -> [B, f_out, dim_in].  All drop rates are treated as 0.
+    `taps` (a dict, optional) receives the intermediate activations a parity test wants to localise an error with:
+    "patch_embed", "layers.{i}" (output of encoder stage i incl. its PatchMerging), "norm", "decoder.layers_up.{k}".
     """
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.detach()
+
     sd = {k: v for k, v in sd.items()}
     L = len(cfg.depths)
     B, f_in, npix = x.shape
@@ -196,6 +202,7 @@ def forward(sd, cfg, spec, x):
     x = xp @ w.reshape(w.shape[0], -1).t() + sd["patch_embed.proj.bias"]
     if cfg.ape:
         x = x + sd["absolute_pos_embed"]
+    tap("patch_embed", x)
 
     skips = []
     for i in range(L):  # :939-943
@@ -203,12 +210,15 @@ def forward(sd, cfg, spec, x):
         x = _stage(x, sd, f"layers.{i}.", cfg.depths[i], cfg.num_heads[i], cfg, spec.base_pix, rel_index)
         if i < L - 1:
             x = patch_merging(x, sd, f"layers.{i}.downsample.")
+        tap(f"layers.{i}", x)
     x = layer_norm(x, sd["norm.weight"], sd["norm.bias"])  # :945
+    tap("norm", x)
 
     for inx in range(L):  # :766-778
         pre = f"decoder.layers_up.{inx}."
         if inx == 0:
             x = patch_expand(x, sd, pre)
+            tap(f"decoder.layers_up.{inx}", x)
             continue
         down = L - 1 - inx
         x = torch.cat([x, skips[down]], dim=-1)
@@ -216,6 +226,7 @@ def forward(sd, cfg, spec, x):
         x = _stage(x, sd, pre, cfg.depths[down], cfg.num_heads[down], cfg, spec.base_pix, rel_index)
         if down > 0:
             x = patch_expand(x, sd, pre + "upsample.")
+        tap(f"decoder.layers_up.{inx}", x)
     x = layer_norm(x, sd["decoder.norm_up.weight"], sd["decoder.norm_up.bias"])  # :781
     x = patch_expand(x, sd, "decoder.up.", p=cfg.patch_size)  # :782
     wo = sd["decoder.output.weight"]  # [f_out, C, 1], 1x1 conv without bias :756-761

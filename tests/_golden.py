@@ -72,5 +72,24 @@ def model_cfg_spec(name):
     return cfg, spec
 
 
+# The reference-scale set (refinit.npz, make_golden.py:make_refinit): production kernel shapes, the reference's own init scale
+REFINIT_MODEL_CASES = {
+    "bp12_roll_v1_scaled": (12, 16, dict(shift_strategy="nest_roll", shift_size=32, use_cos_attn=False, use_v2_norm_placement=False)),
+    "bp8_ring_v2_cos": (8, 16, dict(shift_strategy="ring_shift", shift_size=4, use_cos_attn=True, use_v2_norm_placement=True)),
+}
+REFINIT_WA_CASES = ["scaled_nomask", "scaled_rollmask", "cos_nomask", "cos_ringmask"]
+REFINIT_BLOCK_CASES = [(False, "roll", "nest_roll", 32), (True, "ring", "ring_shift", 4)]
+
+
+def refinit_cfg_spec(name):
+    bp, nside, kw = REFINIT_MODEL_CASES[name]
+    cfg = dict(patch_size=4, window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", embed_dim=32,
+               depths=[2, 2], num_heads=[1, 2], mlp_ratio=4.0, qkv_bias=True, qk_scale=None, use_cos_attn=False,
+               drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, use_v2_norm_placement=False, ape=False)
+    cfg.update(kw)
+    spec = dict(dim_in=bp * nside * nside, f_in=3, f_out=12, base_pix=bp, class_names=[])
+    return cfg, spec
+
+
 def ns(d):
     return types.SimpleNamespace(**d)

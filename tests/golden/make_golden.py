@@ -292,6 +292,96 @@ def make_losses():
     print("losses.npz", len(out), "arrays")
 
 
+
+# ------------------------------------------------------------------ reference-scale initialisation (round 3)
+def refinit_(module, gen):
+    """The reference's OWN initialisation scale (swin_hp_transformer.py:912-919, :84-87, :92-96): Linear weights trunc-normal
+    sigma 0.02 with zero biases, LayerNorm 1 / 0, logit_scale = ln 10, relative-position table N(0, 0.02) (the reference starts
+    it at zero, which would leave the bias path without signal).  Conv1d layers keep the torch default init, as in the
+    reference.  Drawn from `gen` so that the fixture is reproducible."""
+    import math
+
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.Linear):
+                w = torch.randn(m.weight.shape, generator=gen).clamp_(-2.0, 2.0) * 0.02  # trunc-normal(0.02), cut at 2 sigma
+                m.weight.copy_(w)
+                if m.bias is not None:
+                    m.bias.zero_()
+            elif isinstance(m, torch.nn.LayerNorm):
+                m.weight.fill_(1.0)
+                m.bias.zero_()
+            elif isinstance(m, torch.nn.Conv1d):
+                bound = 1.0 / math.sqrt(m.weight.shape[1] * m.weight.shape[2])
+                m.weight.copy_((torch.rand(m.weight.shape, generator=gen) * 2 - 1) * bound)
+                if m.bias is not None:
+                    m.bias.copy_((torch.rand(m.bias.shape, generator=gen) * 2 - 1) * bound)
+        for name, p in module.named_parameters():
+            if name.endswith("logit_scale"):
+                p.fill_(math.log(10.0))
+            elif name.endswith("relative_position_bias_table"):
+                p.copy_(0.02 * torch.randn(p.shape, generator=gen))
+            elif name.endswith("absolute_pos_embed"):
+                p.copy_(0.02 * torch.randn(p.shape, generator=gen).clamp_(-2.0, 2.0))
+
+
+REFINIT_MODEL_CASES = {
+    # production kernel shapes (window 64, head_dim 32) at the reference's own weight scale
+    "bp12_roll_v1_scaled": (12, 16, dict(shift_strategy="nest_roll", shift_size=32, use_cos_attn=False, use_v2_norm_placement=False)),
+    "bp8_ring_v2_cos": (8, 16, dict(shift_strategy="ring_shift", shift_size=4, use_cos_attn=True, use_v2_norm_placement=True)),
+}
+
+
+def refinit_model_config(kw):
+    base = dict(patch_size=4, window_size=64, shift_size=32, rel_pos_bias="flat", embed_dim=32, depths=[2, 2], num_heads=[1, 2],
+                drop_path_rate=0.0)
+    base.update(kw)
+    return M.SwinHPTransformerConfig(**base)
+
+
+def make_refinit():
+    """Second golden set: the same reference modules at the reference's OWN initialisation scale, on
+    the production kernel shapes (window 64, head_dim 32), so that north_star's 1e-3 (fp32) / 1e-2 (bf16) can be asserted
+    directly on reference-produced tensors without a stress multiplier."""
+    gen = torch.Generator().manual_seed(20260930)
+    out = {}
+    C, nH, Ws, nW, B = 128, 4, 64, 2, 2
+    roll_mask = S.NestRollShift(32, nW * Ws, Ws).get_mask()
+    ring16 = S.RingShift(16, 8, Ws, 4).get_mask()
+    cnt = (ring16 != 0).reshape(ring16.shape[0], -1).sum(1)
+    ring_mask = ring16[torch.argsort(cnt, descending=True)[:nW]].contiguous()
+    for cos in (False, True):
+        for mname, mask in (("nomask", None), ("rollmask", roll_mask), ("ringmask", ring_mask)):
+            if (cos, mname) in ((False, "ringmask"), (True, "rollmask")):
+                continue  # (fixture size: each mask kind once per attention kind is enough)
+            wa = M.WindowAttention(C, Ws, nH, rel_pos_bias="flat", use_cos_attn=cos)
+            refinit_(wa, gen)
+            # LayerNorm-scale activations, as the block feeds the module (norm1 output / block input)
+            x = torch.randn((B if mask is not None else 1) * nW, Ws, C, generator=gen)
+            key = f"window_attention/{'cos' if cos else 'scaled'}_{mname}"
+            run_case(wa, x, lambda t: wa(t, mask=mask), gen, out, key)
+            if mask is not None:
+                out[key + "/mask"] = npy(mask).astype(np.int8)
+    # one v1 (pre-norm, scaled attention, nest_roll) and one v2 (post-norm, cosine attention, ring_shift) block:
+    # 8 faces x nside 8 = 512 tokens = 8 windows of 64, C = 64, 2 heads of 32
+    for v2, sname, strat, shift in ((False, "roll", "nest_roll", 32), (True, "ring", "ring_shift", 4)):
+        blk = M.SwinTransformerBlock(64, 512, 8, 2, window_size=64, shift_size=shift, shift_strategy=strat,
+                                     rel_pos_bias="flat", use_v2_norm_placement=v2, use_cos_attn=v2)
+        refinit_(blk, gen)
+        run_case(blk, torch.randn(1, 512, 64, generator=gen), blk, gen, out, f"block/{'v2' if v2 else 'v1'}_{sname}")
+    for name, (bp, nside, kw) in REFINIT_MODEL_CASES.items():
+        cfg = refinit_model_config(kw)
+        spec = DataSpec(dim_in=bp * nside * nside, f_in=3, f_out=12, base_pix=bp, class_names=[])
+        model = M.SwinHPTransformerSys(cfg, spec)
+        refinit_(model, gen)
+        model.train()
+        x = torch.randint(0, 256, (2, 3, spec.dim_in), generator=gen).float()
+        run_case(model, x, model, gen, out, f"model/{name}")
+        print(name, "state entries", len(model.state_dict()), "params", sum(p.numel() for p in model.parameters()))
+    np.savez_compressed(os.path.join(HERE, "refinit.npz"), **out)
+    print("refinit.npz", len(out), "arrays")
+
+
 # ------------------------------------------------------------------ fisheye -> HEALPix projection (SURVEY 8f N4)
 PROJ_CALS = {
     # WoodScape-like calibrations (polynomial fisheye model, quaternion scalar last); the small ones scale the optics to small
@@ -372,7 +462,7 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     only = [a for a in sys.argv[1:] if not a.startswith("-")]  # e.g. `make_golden.py losses` regenerates one file
     for name, fn in (("tables", make_tables), ("modules", make_modules), ("models", make_models), ("losses", make_losses),
-                     ("projection", make_projection)):
+                     ("projection", make_projection), ("refinit", make_refinit)):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(HERE)):

@@ -112,3 +112,27 @@ def test_model_no_grad_uses_the_fused_module_and_matches(cfgkw):
     assert n_fused == 4 and len(calls) == 4  # the 2 + 2 stage-0 blocks (encoder, decoder), only in no-grad mode
     assert_close(y_fused, y_ref, 1e-2, "fused logits vs oracle")
     assert_close(y_fused, y_plain, 1e-2, "fused vs three-kernel logits")
+
+
+def test_module_kernel_batches_beyond_the_2gib_descriptor_range():
+    """B * N * C * 2 bytes > 2 GiB (batch >= 43 at stage 0 of HEAL-SWIN-B / nside 256) used to raise
+    HS_ERR_UNSUPPORTED on the default no-grad path.  The entry point now runs such calls in chunks of whole images; the result
+    equals the per-image calls bit for bit."""
+    import torch
+    from heal_swin_amd import ops
+    B, N, C, nH = 44, 196608, 128, 4
+    assert B * N * C * 2 > 0x7FFFFE00
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, N, C, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    qkv_w = (torch.randn(3 * C, C, generator=g, device="cuda") * 0.05)
+    proj_w = (torch.randn(C, C, generator=g, device="cuda") * 0.05)
+    qkv_b = torch.randn(3 * C, generator=g, device="cuda") * 0.1
+    proj_b = torch.randn(C, generator=g, device="cuda") * 0.1
+    bias = torch.randn(nH, 64, 64, generator=g, device="cuda") * 0.2
+    hs = torch.full((nH,), 32 ** -0.5, device="cuda")
+    with torch.no_grad():
+        assert ops.window_attn_module_ok(x, nH, 64)
+        y = ops.window_attn_module(x, qkv_w, qkv_b, proj_w, proj_b, bias, hs, None, 32, None, nH, 64, False)
+        for b in (0, 41, 42, 43):  # images on both sides of the chunk boundary (42 images fit the descriptor)
+            yb = ops.window_attn_module(x[b:b + 1], qkv_w, qkv_b, proj_w, proj_b, bias, hs, None, 32, None, nH, 64, False)
+            assert torch.equal(y[b:b + 1], yb), b

@@ -70,6 +70,50 @@ def test_graphed_step_equals_eager_step(sink):
         assert torch.equal(v, finals["graph"][k]), k
 
 
+def test_eager_forward_between_replays_sees_the_current_weights():
+    """replay -> eval -> replay -> eval: every eager (no-grad) forward between graph replays must use the parameters as the
+    last replay left them.  The bf16 weight copies are keyed on the parameters' Python-side version counters, which a replay
+    does not bump: GraphedTrainStep invalidates them after each replay."""
+    from heal_swin_amd.graphs import GraphedTrainStep
+    from heal_swin_amd.losses import seg_loss
+
+    evals = {}
+    for mode in ("eager", "graph"):
+        model, spec = _build()
+        data = _batches(spec, 5)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True, capturable=True)
+        xe = data[0][0].float()
+        out = []
+
+        def evaluate():
+            model.eval()
+            with torch.no_grad():
+                y = model(xe).float().clone()
+            model.train()
+            return y
+
+        if mode == "graph":
+            step = GraphedTrainStep(model, seg_loss, opt, data[0][0], data[0][1], warmup=2, pre_forward=lambda x: x.float())
+            for x, y in data[1:]:
+                step(x, y)
+                out.append(evaluate())
+        else:
+            def eager(x, y):
+                opt.zero_grad(set_to_none=False)
+                loss = seg_loss(model(x.float()), y)
+                loss.backward()
+                opt.step()
+            for _ in range(2):
+                eager(*data[0])
+            for x, y in data[1:]:
+                eager(x, y)
+                out.append(evaluate())
+        evals[mode] = out
+    for i, (a, b) in enumerate(zip(evals["eager"], evals["graph"])):
+        assert torch.equal(a, b), f"eval after replay {i}: max diff {float((a - b).abs().max())}"
+    assert not torch.equal(evals["graph"][0], evals["graph"][-1])  # the weights did move between the evaluations
+
+
 def test_graphed_step_refuses_what_it_cannot_capture():
     from heal_swin_amd.graphs import GraphedTrainStep
     from heal_swin_amd.losses import seg_loss

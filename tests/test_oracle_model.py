@@ -7,7 +7,8 @@ import torch
 
 from oracle import model as OM
 from oracle import tables as T
-from _golden import case, load, state_dict, model_cfg_spec, ns, MODEL_CASES
+from _golden import (case, load, state_dict, model_cfg_spec, ns, MODEL_CASES, REFINIT_MODEL_CASES, REFINIT_WA_CASES,
+                     REFINIT_BLOCK_CASES, refinit_cfg_spec)
 
 
 def close(a, b, tol=2e-5, what=""):
@@ -84,6 +85,53 @@ def test_whole_model(name):
     # in fp32 (the two fp32 evaluations differ by summation order only), hence the looser bound there.
     tol = 2e-3 if name == "ref_test_config" else 5e-5
     run_and_check(c, lambda sd, x: OM.forward(sd, ns(cfg), ns(spec), x), tol=tol)
+
+
+# ----------------------------------------------------------------------------- reference-scale goldens (refinit.npz)
+def close_own_scale(a, b, tol, what=""):
+    """max|a-b| / max|b| with NO floor at 1: at the reference's init scale (sigma 0.02) gradients are 1e-3 .. 1e-6 in size."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = float(np.abs(b).max())
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale + 1e-12, f"{what}: err {err:.3e} vs scale {scale:.3e} (ratio {err / max(scale, 1e-300):.3e} > {tol})"
+
+
+def run_and_check_own_scale(c, fwd, tol):
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in state_dict(c).items()}
+    x = torch.from_numpy(c["x"]).requires_grad_(True)
+    y = fwd(sd, x)
+    close_own_scale(y.detach().numpy(), c["y"], tol, "y")
+    y.backward(torch.from_numpy(c["dy"]))
+    close_own_scale(x.grad.numpy(), c["dx"], tol, "dx")
+    for k, g in c["grad"].items():
+        got = sd[k].grad
+        got = np.zeros_like(g) if got is None else got.numpy()
+        close_own_scale(got, g, tol, "grad " + k)
+
+
+@pytest.mark.parametrize("name", REFINIT_WA_CASES)
+def test_refinit_window_attention(name):
+    c = case("refinit", "window_attention/" + name)
+    mask = torch.from_numpy(c["mask"].astype(np.float32)) if "mask" in c else None
+    rel = torch.from_numpy(T.rel_pos_index(64))
+    run_and_check_own_scale(c, lambda sd, x: OM.window_attention(x, sd, "", 4, rel, mask, name.startswith("cos")), 5e-5)
+
+
+@pytest.mark.parametrize("v2,sname,strat,shift", REFINIT_BLOCK_CASES)
+def test_refinit_block(v2, sname, strat, shift):
+    c = case("refinit", f"block/{'v2' if v2 else 'v1'}_{sname}")
+    sh = OM.Shifter(strat, 512, 8, 64, shift)
+    rel = torch.from_numpy(T.rel_pos_index(64))
+    run_and_check_own_scale(c, lambda sd, x: OM.swin_block(x, sd, "", 2, 64, sh, rel, v2, v2), 5e-5)
+
+
+@pytest.mark.parametrize("name", list(REFINIT_MODEL_CASES))
+def test_refinit_whole_model(name):
+    c = case("refinit", "model/" + name)
+    cfg, spec = refinit_cfg_spec(name)
+    run_and_check_own_scale(c, lambda sd, x: OM.forward(sd, ns(cfg), ns(spec), x), 2e-4)
 
 
 def test_seg_loss():
