@@ -43,6 +43,11 @@ WORKLOADS = {
                  nside=128, base_pix=8, f_out=12, fwd_gflop_per_image=180.56,
                  cfg=dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=64, shift_size=32,
                           shift_strategy="nest_roll", rel_pos_bias="flat")),
+    # BASELINE.json configs[4]: depth-estimation head (f_out = 1, masked L1 loss), fp32 -- the `depth_fp32` companion of the line
+    "D256": dict(name="HEAL-SWIN-T depth head nside=256 base_pix=8 window=64 nest_roll(shift 32) f_out=1, L1 over finite targets",
+                 nside=256, base_pix=8, f_out=1, fwd_gflop_per_image=721.15, task="depth",
+                 cfg=dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=64, shift_size=32,
+                          shift_strategy="nest_roll", rel_pos_bias="flat")),
     # BASELINE.json configs[0] shape (plumbing)
     "tiny": dict(name="HEAL-SWIN-tiny nside=32 base_pix=4 window=16", nside=32, base_pix=4, f_out=12, fwd_gflop_per_image=0.67,
                  cfg=dict(embed_dim=48, depths=[2, 2, 2], num_heads=[3, 6, 12], window_size=16, shift_size=8,
@@ -75,10 +80,12 @@ def build_model(wl, nside=None):
 
 
 def pmc_traffic_per_launch(attn_agg):
-    """HBM bytes per launch from the committed PMC passes (profiles/r02_attn_pmc_hbm_traffic.json: rocprofv3 --pmc
+    """HBM bytes per launch from the committed PMC passes (profiles/r03_attn_pmc_hbm_traffic.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, KiB units, FETCH x2 gfx950 correction), averaged over this run's launch
     mix by matching each launch's algorithmic byte count; None if a launch shape was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r02_attn_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_attn_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r02_attn_pmc_hbm_traffic.json")
     if not os.path.exists(path):
         return None
     table = {}
@@ -143,33 +150,90 @@ def _oracle_timing(wl, nside, batch, warmup, iters):
     return times
 
 
-def cpu_baseline(wl, budget_s=25.0):
+def host_memory_gb():
+    """Memory this process may use: MemAvailable capped by the cgroup limit (GiB)."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            lim_free = (int(lim) - cur) / 2 ** 30
+            avail = lim_free if avail is None else min(avail, lim_free)
+    except (OSError, ValueError):
+        pass
+    return avail if avail is not None else 16.0
+
+
+def _peak_rss_gb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20
+
+
+def cpu_baseline(wl, budget_s=30.0):
     """Times the CPU oracle (forward + CE loss + backward over all parameters; a port of the reference's forward, fp32) on
-    this host's usable cores.  Headline workload: a BOUNDED sample of the same model -- ONE image at a reduced nside chosen
-    by calibration so that 1 warm-up + 3 timed iterations cost about 10-30 s; images/s is rescaled by the pixel ratio (cost
-    is linear in the pixel count for windowed attention).  BASELINE configs[0] (tiny) and configs[1] (T, nside 128) are timed
-    at their full size alongside (1 warm-up + 3 timed iterations)."""
+    this host's usable cores (SURVEY 8d protocol).  Headline workload: ONE image, at the workload's own nside when one
+    iteration fits the time budget (about 10-30 s of CPU work) AND the oracle's autograd graph fits the host memory (it holds
+    every [windows, heads, 64, 64] score tensor: both are calibrated at a small nside and extrapolated x4 per doubling),
+    otherwise at the largest nside that does, rescaled by the pixel ratio (cost is linear in the pixel count for windowed
+    attention) -- `sample` says which.  BASELINE configs[0] (tiny) and configs[1] (T, nside 128) are timed at full size
+    (2 warm-up + 3 timed iterations) and the paper config (T, nside 256, 8 base pixels, ring_shift + cosine + v2) with ONE timed
+    iteration, as 8d prescribes."""
     cores = usable_cores()
     torch.set_num_threads(cores)
-    L = len(wl["cfg"]["depths"])
-    nside = min(wl["nside"], 16 * 2 ** (L - 1))  # >= one 64-token window per base-pixel quartet at the last stage
-    t = min(_oracle_timing(wl, nside, 1, 0, 1))  # calibration
-    while nside * 2 <= wl["nside"] and t * 4 * 4 * 1.2 < budget_s:
-        nside *= 2
-        t *= 4
-    times = _oracle_timing(wl, nside, 1, 1, 3)
+    mem_gb = host_memory_gb()
+
+    def fit(w, budget):
+        """Largest nside <= the workload's whose single iteration fits `budget` seconds and 60 % of the host memory:
+        (nside, estimated seconds, estimated GiB)."""
+        L = len(w["cfg"]["depths"])
+        nside = min(w["nside"], 16 * 2 ** (L - 1))  # >= one 64-token window per base-pixel quartet at the last stage
+        rss0 = _peak_rss_gb()
+        t = min(_oracle_timing(w, nside, 1, 1, 1))  # calibration (after one warm-up: thread pool, allocator)
+        gb = max(_peak_rss_gb() - rss0, 0.05)
+        while nside * 2 <= w["nside"] and t * 4 * 1.2 < budget and gb * 4 * 1.3 < 0.6 * mem_gb:
+            nside, t, gb = nside * 2, t * 4, gb * 4
+        return nside, t, gb
+
+    # headline: full nside with a single timed iteration if it fits, else 1 warm-up + 3 timed at the reduced nside
+    nside, t_est, gb_est = fit(wl, budget_s)
+    gb_full = gb_est * (wl["nside"] / nside) ** 2
+    if nside == wl["nside"]:
+        times = _oracle_timing(wl, nside, 1, 0, 1) if t_est * 4 > budget_s else _oracle_timing(wl, nside, 1, 1, 3)
+    else:
+        n2, t2 = nside, t_est
+        while n2 > 16 and t2 * 4 * 1.2 > budget_s:  # 1 warm-up + 3 timed iterations inside the budget
+            n2, t2 = n2 // 2, t2 / 4
+        nside = n2
+        times = _oracle_timing(wl, nside, 1, 1, 3)
     t = sum(times) / len(times)
     scale = (wl["nside"] / nside) ** 2
+    how = (f"at the workload's own nside={nside} (no rescaling)" if scale == 1 else
+           f"at nside={nside}, rescaled x{1 / scale:.4g} to nside={wl['nside']} by pixel count (a full-size iteration: "
+           f"estimated {t * scale:.0f} s and {gb_full:.0f} GiB of autograd state)")
     out = {"value": 1.0 / (t * scale), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
-           "sample": f"oracle (CPU restatement of the reference forward) fwd+CE+bwd, fp32, 1 image at nside={nside}, 1 warm-up + "
-                     f"{len(times)} timed iterations (mean {t:.2f}s, min {min(times):.2f}s on {cores} threads), rescaled "
-                     f"x{1 / scale:.4g} to nside={wl['nside']} by pixel count"}
+           "host_memory_GiB_available": round(mem_gb, 1),
+           "sample": f"oracle (CPU restatement of the reference forward) fwd+CE+bwd, fp32, 1 image {how}; "
+                     f"{len(times)} timed iteration(s) (mean {t:.2f}s, min {min(times):.2f}s on {cores} threads)"}
     other = {}
     for key, batch in (("tiny", 1), ("T128", 1)):  # BASELINE configs[0] and configs[1] at full size
         w = WORKLOADS[key]
         ts = _oracle_timing(w, w["nside"], batch, 2, 3)
         other[key] = {"workload": w["name"], "images_per_s": batch * len(ts) / sum(ts), "s_per_iter": [round(v, 3) for v in ts],
                       "batch": batch, "iters": "2 warm-up + 3 timed"}
+    # the paper config: ONE timed iteration at its own size (SURVEY 8d), memory permitting
+    w = WORKLOADS["T256"]
+    n_p, t_p, gb_p = fit(w, 60.0)
+    ts = _oracle_timing(w, n_p, 1, 0, 1)
+    sc = (w["nside"] / n_p) ** 2
+    other["T256_paper"] = {"workload": w["name"], "images_per_s": 1.0 / (ts[0] * sc), "s_per_iter": [round(ts[0], 3)], "batch": 1,
+                           "nside_timed": n_p, "rescaled": sc != 1,
+                           "iters": "1 timed iteration, no warm-up (SURVEY 8d: reference anchor 67 s on 8 cores of the survey container)"}
     out["other_configs"] = other
     return out
 
@@ -203,6 +267,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-shape table of the event-timed launches to stderr")
     ap.add_argument("--no-fp32-companion", action="store_true", help="skip the fp32 run of the same workload (N = 1 only)")
+    ap.add_argument("--no-graph-companion", action="store_true", help="skip the HIP-graph replay of the same workload (N = 1 only)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd + loss + bwd + Adam) in one HIP graph and replay it (single GPU, no "
                          "dropout); removes host launch latency, which dominates the small workloads")
@@ -234,10 +299,18 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
+        if rank == 0 and not shared_gpu:
+            os.environ.setdefault("NCCL_DEBUG", "VERSION")  # one line with the RCCL version on stderr of rank 0
+        t_init = time.perf_counter()
         if shared_gpu:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+        # diagnosability of the first real multi-GPU run: what every rank sees, on stderr (the JSON line stays alone on stdout)
+        env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "MASTER_"))}
+        print(f"[bench rank {rank}/{world}] device {dev_index}: {torch.cuda.get_device_name(dev_index)}, backend "
+              f"{dist.get_backend()}, init {time.perf_counter() - t_init:.2f}s, env {env}", file=sys.stderr, flush=True)
 
     # Library GEMMs (forward / input-gradient of the Linear layers): load the per-shape hipBLASLt/rocBLAS solution choices
     # tuned once on an MI355X with PyTorch TunableOp (tuning itself stays OFF here; a validator mismatch -- other ROCm,
@@ -302,6 +375,26 @@ def main():
         out["fp32"] = {"value": args.batch * k / r32.elapsed, "unit": "images/s", "ms_per_step": 1e3 * r32.elapsed / k, "steps": k,
                        "warmup": 1, "batch_per_gpu": args.batch, "workload": wl["name"], "final_loss": r32.loss,
                        "note": "fp32 activations and MFMA-f32 kernels; library GEMMs with the default heuristic"}
+    # BASELINE configs[4] at its stated size next to it: HEAL-SWIN-T, nside 256, 8 base pixels, depth head (f_out = 1), fp32, masked
+    # L1 loss; batch 2 per GPU as in the reference's run configs (run_configs/*/..._train_run_config.py: batch_size 2)
+    if world == 1 and args.dtype == "bf16" and args.workload == "B256" and not args.no_fp32_companion and not args.graph and not args.tune_gemm:
+        dctx = types.SimpleNamespace(**{**vars(ctx), "wl": WORKLOADS["D256"], "batch": 2})
+        kd = 5
+        rd = run_workload(dctx, "fp32", kd, 2, timing=False)
+        out["depth_fp32"] = {"value": 2 * kd / rd.elapsed, "unit": "images/s", "ms_per_step": 1e3 * rd.elapsed / kd, "steps": kd, "warmup": 2,
+                             "batch_per_gpu": 2, "workload": WORKLOADS["D256"]["name"], "final_loss": rd.loss,
+                             "model_TFLOPs": 3 * WORKLOADS["D256"]["fwd_gflop_per_image"] * 2 * kd / rd.elapsed / 1e3,
+                             "note": "BASELINE configs[4]: fp32 activations (the reference's precision), MFMA-f32 attention / weight-gradient "
+                                     "kernels, fp32 library GEMMs; parity at this size: tests/test_gpu_model.py::test_depth_head_fp32_*[256]"}
+    # the same step replayed from ONE HIP graph (heal_swin_amd.graphs): what host launch latency costs the eager line above
+    if world == 1 and args.dtype == "bf16" and not args.graph and not args.no_graph_companion and not args.paper_drop_rates and not args.tune_gemm:
+        gctx = types.SimpleNamespace(**{**vars(ctx), "args": argparse.Namespace(**{**vars(args), "graph": True})})
+        kg = max(2, min(args.steps, 8))
+        rg = run_workload(gctx, "bf16", kg, 2, timing=False)
+        out["graph_replay"] = {"value": args.batch * kg / rg.elapsed, "unit": "images/s", "ms_per_step": 1e3 * rg.elapsed / kg, "steps": kg,
+                               "eager_over_graph": (elapsed / args.steps) / (rg.elapsed / kg),
+                               "note": "whole step (zero_grad, fwd, CE, bwd, Adam) captured once and replayed; the headline `value` stays the "
+                                       "eager step because the roofline brackets need per-launch HIP events"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
@@ -329,18 +422,28 @@ def roofline_of(timings, elapsed, detail=False):
     launches = sum(a[3] for a in attn.values())
     tf = tot_f / tot_t / 1e12
     gbs = tot_b / tot_t / 1e9
+    # SURVEY 8d counts the attention-core flops of fwd + bwd as 3 x forward (backward = 2 x for contractions); the kernels'
+    # own count (tot_f) includes the backward's recomputed score tile (forward 4, backward 10 units of B N C Ws)
+    fwd_f = sum(a[2] for t, a in attn.items() if t.endswith("_fwd"))
+    fwd_n = sum(a[3] for t, a in attn.items() if t.endswith("_fwd"))
+    bwd_n = sum(a[3] for t, a in attn.items() if t.endswith("_bwd"))
+    tf_8d = (fwd_f + 2.0 * fwd_f * (bwd_n / fwd_n if fwd_n else 0.0)) / tot_t / 1e12
     traffic = pmc_traffic_per_launch({t: a for t, a in attn.items() if t in ("window_attn_fwd", "window_attn_bwd")})
     return {
         "kernel": " + ".join(sorted(attn)) + " (fused shift / window partition / attention / reverse)",
-        "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+        # a core-only attention kernel is 32 flop/B: HBM is the bound that applies; the MFMA fraction is the
+        # north_star's target metric and is carried beside it
+        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
         "traffic": traffic,
-        "traffic_source": "profiles/r02_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same "
+        "traffic_source": "profiles/r03_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same "
                           "kernels and shapes; looked up, not measured in this run)" if traffic is not None else None,
-        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": tot_b / launches,
-                # what a pure read stream reaches on this chip (tools/microbench/fill_rate.hip, 1 GB working set, every CU
-                # streaming: profiles/r02_microbench_fill_rate.txt) -- the vendor figure above is the contract's denominator
-                "measured_read_ceiling_GBs": 6300.0, "frac_of_measured_ceiling": gbs / 6300.0},
+        "algorithmic_bytes_per_launch": tot_b / launches,
+        # what a pure read stream reaches on this chip (tools/microbench/fill_rate.hip, 1 GB working set, every CU
+        # streaming: profiles/r02_microbench_fill_rate.txt) -- the vendor figure above is the contract's denominator
+        "measured_read_ceiling_GBs": 6300.0, "frac_of_measured_ceiling": gbs / 6300.0,
+        "mfma": {"achieved": tf_8d, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_8d / MFMA_PEAK_TFLOPS,
+                 "flop_count": "SURVEY 8d: attention-core flops, fwd + bwd = 3 x forward",
+                 "achieved_counting_recompute": tf, "frac_counting_recompute": tf / MFMA_PEAK_TFLOPS},
         "algorithmic_flops_per_launch": tot_f / launches,
         "avg_launch_us": 1e6 * tot_t / launches, "launches": launches, "share_of_step": tot_t / elapsed,
         "per_kernel": {tag: {"launches": a[3], "avg_us": 1e6 * a[0] / a[3], "GB/s": a[1] / a[0] / 1e9,
@@ -369,10 +472,11 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
 
     import torch.distributed as dist
     from heal_swin_amd import ops
-    from heal_swin_amd.losses import seg_loss
+    from heal_swin_amd.losses import depth_l1_loss, seg_loss
     from heal_swin_amd.parallel import GradBucketAllReduce
 
     args, wl, dev, world, rank = ctx.args, ctx.wl, ctx.dev, ctx.world, ctx.rank
+    batch = getattr(ctx, "batch", None) or args.batch
     model, cfg, spec = build_model(wl)
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
@@ -380,13 +484,20 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=args.graph)  # ref: training/optimizer.py:57-66
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    imgs = torch.randint(0, 256, (args.batch, 3, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
-    labels = torch.randint(0, spec["f_out"], (args.batch, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
+    imgs = torch.randint(0, 256, (batch, 3, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
+    if wl.get("task") == "depth":
+        # positive depths with ~4 % infinite (background) targets, as in the data set
+        labels = torch.randn((batch, spec["dim_in"]), generator=g, device=dev).abs() * 10
+        labels[torch.rand((batch, spec["dim_in"]), generator=g, device=dev) < 0.04] = float("inf")
+        loss_fn = depth_l1_loss  # training/loss_depth_regression.py:41-53
+    else:
+        labels = torch.randint(0, spec["f_out"], (batch, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
+        loss_fn = seg_loss
 
     def step():
         dp.zero_grad()
         logits = model(imgs.float())  # the caller's `.float()` (model_lightning_swin_hp.py:61)
-        loss = seg_loss(logits, labels)
+        loss = loss_fn(logits, labels)
         loss.backward()
         dp.finish()
         opt.step()
@@ -431,6 +542,9 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
     if world > 1:
         assert dist.get_world_size() == world == args.gpus
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        own = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(own, t)
+        step_ms_per_rank = [round(1e3 * float(v.item()) / steps, 3) for v in own]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the exchange on its own: every gradient bucket all-reduced back to back, timed per rank with events
@@ -450,7 +564,12 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
         dist.all_gather(per_rank, mine)
         nbytes = sum(f.numel() * 4 for f in dp.buckets)
         ms = [float(v.item()) for v in per_rank]
-        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "buckets": len(dp.buckets),
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl_version = None
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl_version,
+                "step_ms_per_rank": step_ms_per_rank, "buckets": len(dp.buckets),
                 "allreduce_bytes_per_step": nbytes, "allreduce_ms_per_step_standalone_per_rank": [round(v, 3) for v in ms],
                 "allreduce_bus_GBps": 2 * (world - 1) / world * nbytes / (max(ms) * 1e-3) / 1e9,
                 "exchange": "fp32 flat buckets, async all-reduce launched from gradient hooks during backward"}

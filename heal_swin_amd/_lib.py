@@ -41,8 +41,8 @@ _SIGNATURES = {
     "hs_gather_rows": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr],
     "hs_pix2ang_nest": [c_int, c_i64, c_i64, c_ptr, c_ptr],
     "hs_ln_head_supported": [c_int, c_int, c_int],
-    "hs_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
-    "hs_ln_head_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
+    "hs_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
+    "hs_ln_head_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_sample_bilinear_u8": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "hs_sample_mask_u8": [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr],
     "hs_gelu_fwd": [c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
@@ -58,6 +58,8 @@ _SIGNATURES = {
                               ctypes.c_uint64, c_i64, c_int, c_int, c_ptr],
     "hs_add_layernorm_drop_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float,
                                   ctypes.c_uint64, c_i64, c_int, c_int, c_ptr],
+    "hs_layernorm_fwd_ex": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float,
+                            ctypes.c_uint64, c_i64, c_int, c_int, c_ptr],
     "hs_add_layernorm_drop_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64,
                                   ctypes.c_float, ctypes.c_uint64, c_i64, c_int, c_int, c_ptr],
     "hs_seg_ce_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_ptr],

@@ -73,10 +73,17 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                                                             float* __restrict__ rstd_out, int64_t rows, int width,
                                                             const void* __restrict__ add_in, void* __restrict__ sum_out,
                                                             const float* __restrict__ row_scale, int64_t rows_per_sample,
-                                                            float drop_p, uint64_t seed) {
+                                                            float drop_p, uint64_t seed, const void* __restrict__ lo_in,
+                                                            void* __restrict__ lo_out) {
     // Stochastic extras (train mode).  With add_in (v1):  s = x + rs * drop(add_in),  y = LN(s).
     // Without (v2 / plain):                               y = [residual +] rs * LN(drop(x)).
     // rs = row_scale[row / rows_per_sample] is the per-sample DropPath factor, drop() the counter-based dropout mask.
+    // Compensated residual stream (lo_in / lo_out, optional, activation dtype): the residual stream of a stage is the sum of
+    // up to 36 branch outputs; stored in bf16 every add rounds it (2^-9 relative), which is a third of the bf16 logit error of
+    // HEAL-SWIN-B (tests/experiments/bf16_error_budget.py).  With lo_out the stream operand is hi + lo: the new sum is
+    // formed in fp32, `hi` = its rounding goes to sum_out / y as before and `lo` = the rounding remainder to lo_out; the
+    // next add reads both, so the stream carries 16 mantissa bits at 4 bytes per element while every other consumer (GEMMs,
+    // the backward) keeps reading the plain bf16 `hi` tensor.
     const bool dropping = drop_p > 0.f;
     const ElemRng rng(drop_p, seed);
     constexpr int RPW = 64 / LPR;  // rows per wave
@@ -98,15 +105,22 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
             if (live && c < nchunk) {
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, v[it]);
                 if (add_in) {  // s = x + rs*drop(add_in), rounded to the activation dtype exactly as a separate add would store it
-                    float a2[VEC];
+                    float a2[VEC], l2[VEC], hi[VEC];
                     vec_io<T, VEC>::load(add_in, base + (int64_t)c * VEC, a2);
+                    if (lo_in) vec_io<T, VEC>::load(lo_in, base + (int64_t)c * VEC, l2);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         float add = a2[k] * rs;
                         if (dropping) add *= rng.mult(base + (int64_t)c * VEC + k);
-                        v[it][k] = round_to<T>(v[it][k] + add);
+                        const float full = v[it][k] + (lo_in ? l2[k] : 0.f) + add;
+                        hi[k] = round_to<T>(full);  // the stream as every other consumer sees it
+                        l2[k] = full - hi[k];
+                        // without compensation LN sees the stored (rounded) sum, exactly as after a separate add; with it, the
+                        // un-rounded one (the backward re-normalises the stored tensor: a 2^-9 relative difference in xhat)
+                        v[it][k] = lo_out ? full : hi[k];
                     }
-                    vec_io<T, VEC>::store(sum_out, base + (int64_t)c * VEC, v[it]);
+                    vec_io<T, VEC>::store(sum_out, base + (int64_t)c * VEC, hi);
+                    if (lo_out) vec_io<T, VEC>::store(lo_out, base + (int64_t)c * VEC, l2);
                 } else if (dropping) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) v[it][k] *= rng.mult(base + (int64_t)c * VEC + k);
@@ -141,11 +155,27 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                     vec_io<float, 4>::load(beta, (int64_t)c * VEC + 4, b + 4);
                 }
                 if (residual) vec_io<T, VEC>::load(residual, base + (int64_t)c * VEC, r);
+                if (residual && lo_in && !add_in) {  // v2 placement: the residual operand is the compensated stream
+                    float rl[VEC];
+                    vec_io<T, VEC>::load(lo_in, base + (int64_t)c * VEC, rl);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) r[k] += rl[k];
+                }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     o[k] = fmaf((v[it][k] - mean) * rstd, g[k], b[k]);
                     if (!add_in) o[k] *= rs;  // v2: DropPath scales the normalised branch
                     if (residual) o[k] += r[k];
+                }
+                if (residual && lo_out && !add_in) {  // v2: y = hi, remainder to lo_out
+                    float ol[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float hi = round_to<T>(o[k]);
+                        ol[k] = o[k] - hi;
+                        o[k] = hi;
+                    }
+                    vec_io<T, VEC>::store(lo_out, base + (int64_t)c * VEC, ol);
                 }
                 vec_io<T, VEC>::store(y, base + (int64_t)c * VEC, o);
             }
@@ -342,11 +372,13 @@ int bwd_blocks(int64_t rows) {
     return (int)(want < 1 ? 1 : want);
 }
 
-struct LnExtra {  // stochastic extras, all optional
+struct LnExtra {  // stochastic extras and the compensated-stream operands, all optional
     const float* row_scale = nullptr;
     int64_t rows_per_sample = 1;
     float drop_p = 0.f;
     uint64_t seed = 0;
+    const void* lo_in = nullptr;
+    void* lo_out = nullptr;
 };
 
 template <typename T, int VEC, int LPR, int ITERS>
@@ -356,7 +388,8 @@ int run_fwd(const void* x, const void* res, const float* g, const float* b, void
     int64_t blocks = (rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, VEC, LPR, ITERS>), dim3((unsigned)blocks), dim3(256), 0, s, x, res, g, b, y,
-                       mean, rstd, rows, width, add_in, sum_out, ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed);
+                       mean, rstd, rows, width, add_in, sum_out, ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed, ex.lo_in,
+                       ex.lo_out);
     HS_LAUNCH_CHECK("layernorm_fwd");
     return HS_OK;
 }
@@ -487,6 +520,20 @@ int hs_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, cons
                          int width, int dtype, void* stream) {
     return ln_bwd_impl(dy, sum, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, dtype, stream, dsum, nullptr,
                        hs::LnExtra{}, 1, accumulate);
+}
+
+/* the general forward: every optional operand of the kernels above in one entry point.  Exactly one of `residual` (v2 placement:
+ * y = residual + rs LN(drop(x))) and `add_in` (v1: sum_out = x + rs drop(add_in), y = LN(sum_out)) may be given; lo_in / lo_out are the
+ * compensated-stream remainders of the stream operand (x for v1, residual for v2) and of the new stream (sum_out for v1, y for v2). */
+int hs_layernorm_fwd_ex(const void* x, const void* residual, const void* add_in, const void* lo_in, const float* gamma, const float* beta,
+                        void* y, void* sum_out, void* lo_out, float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample,
+                        float drop_p, uint64_t seed, int64_t rows, int width, int dtype, void* stream) {
+    HS_CHECK_ARG(!(residual && add_in), "hs_layernorm_fwd_ex: residual and add_in are exclusive");
+    HS_CHECK_ARG(!(lo_in || lo_out) || residual || add_in, "hs_layernorm_fwd_ex: lo_in / lo_out need a stream operand (residual or add_in)");
+    hs::LnExtra ex = make_extra(row_scale, rows_per_sample, drop_p, seed);
+    ex.lo_in = lo_in;
+    ex.lo_out = lo_out;
+    return ln_fwd_impl(x, residual, gamma, beta, y, mean, rstd, rows, width, dtype, stream, add_in, sum_out, ex);
 }
 
 /* train-mode variants: dropout (drop_p, seed) and per-sample DropPath scale (row_scale[rows / rows_per_sample]) fused in */

@@ -42,9 +42,14 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 }
 
 // wfold [32][C] bf16: row k = gamma * W[k, :] (rows >= f_out zero); bvec [32] f32: sum_c beta_c W[k, c]
-template <int NB>
+// F32OUT: the logits leave as fp32 rows of 16 (64 B) instead of bf16 (32 B).  The decoder tail is where bf16 rounding is NOT
+// averaged away by anything downstream: the four roundings norm_up -> expand -> xhat -> logits account for 6.4e-3 of the 7.7e-3
+// logit error of HEAL-SWIN-B (tests/experiments/bf16_error_budget.py), the whole rest of the network for 2.9e-3.  So here
+// the logits keep their fp32 accumulator value and xhat enters the head product as hi + lo (two MFMAs per k-step instead of
+// one: the kernel is HBM-bound, the second MFMA is free).
+template <int NB, bool F32OUT>
 __global__ void __launch_bounds__(256) ln_head_fwd_kernel(const uint16_t* __restrict__ y, const uint16_t* __restrict__ wfold,
-                                                          const float* __restrict__ bvec, uint16_t* __restrict__ logits,
+                                                          const float* __restrict__ bvec, void* __restrict__ logits_v,
                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows) {
     constexpr int C = NB * 32, NS = NB * 2;
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
@@ -89,13 +94,27 @@ __global__ void __launch_bounds__(256) ln_head_fwd_kernel(const uint16_t* __rest
             for (int j = 0; j < 8; ++j) x[s][j] *= rstd;
             const uint4 xb = pack8(x[s]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+            if constexpr (F32OUT) {  // the rounding remainder of xhat as a second operand
+                float hi[8], lo[8];
+                unpack8(xb, hi);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lo[j] = x[s][j] - hi[j];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], __builtin_bit_cast(bf16x8, pack8(lo)), acc, 0, 0, 0);
+            }
         }
         if (live) {
             // accumulator register r = class 4 half + (r & 3) + 8 (r >> 2) of this lane's row: classes 0..15 are r = 0..7
-            uint2 o0 = make_uint2(pack_bf16x2(acc[0] + bk[0], acc[1] + bk[1]), pack_bf16x2(acc[2] + bk[2], acc[3] + bk[3]));
-            uint2 o1 = make_uint2(pack_bf16x2(acc[4] + bk[4], acc[5] + bk[5]), pack_bf16x2(acc[6] + bk[6], acc[7] + bk[7]));
-            *(uint2*)(logits + row * kKP + 4 * half) = o0;
-            *(uint2*)(logits + row * kKP + 8 + 4 * half) = o1;
+            if constexpr (F32OUT) {
+                float* logits = (float*)logits_v;
+                *(float4*)(logits + row * kKP + 4 * half) = make_float4(acc[0] + bk[0], acc[1] + bk[1], acc[2] + bk[2], acc[3] + bk[3]);
+                *(float4*)(logits + row * kKP + 8 + 4 * half) = make_float4(acc[4] + bk[4], acc[5] + bk[5], acc[6] + bk[6], acc[7] + bk[7]);
+            } else {
+                uint16_t* logits = (uint16_t*)logits_v;
+                uint2 o0 = make_uint2(pack_bf16x2(acc[0] + bk[0], acc[1] + bk[1]), pack_bf16x2(acc[2] + bk[2], acc[3] + bk[3]));
+                uint2 o1 = make_uint2(pack_bf16x2(acc[4] + bk[4], acc[5] + bk[5]), pack_bf16x2(acc[6] + bk[6], acc[7] + bk[7]));
+                *(uint2*)(logits + row * kKP + 4 * half) = o0;
+                *(uint2*)(logits + row * kKP + 8 + 4 * half) = o1;
+            }
             if (half == 0) {
                 mean_out[row] = mean;
                 rstd_out[row] = rstd;
@@ -105,9 +124,9 @@ __global__ void __launch_bounds__(256) ln_head_fwd_kernel(const uint16_t* __rest
 }
 
 // afold [C][16] bf16: afold[c][k] = gamma_c W[k, c] (columns >= f_out zero); part [nwaves][32] f32: u[0..15], t[0..15]
-template <int NB>
+template <int NB, bool F32IN>
 __global__ void __launch_bounds__(256) ln_head_bwd_kernel(const uint16_t* __restrict__ y, const float* __restrict__ mean_in,
-                                                          const float* __restrict__ rstd_in, const uint16_t* __restrict__ dlog,
+                                                          const float* __restrict__ rstd_in, const void* __restrict__ dlog_v,
                                                           const uint16_t* __restrict__ afold, uint16_t* __restrict__ dy,
                                                           uint16_t* __restrict__ dprime, float* __restrict__ part, int64_t rows) {
     constexpr int C = NB * 32, NS = NB * 2;
@@ -130,7 +149,19 @@ __global__ void __launch_bounds__(256) ln_head_bwd_kernel(const uint16_t* __rest
         const int64_t row = row0 + l31;
         const bool live = row < rows;
         const float mean = live ? mean_in[row] : 0.f, rstd = live ? rstd_in[row] : 0.f;
-        const uint4 dl = live ? *(const uint4*)(dlog + row * kKP + 8 * half) : make_uint4(0, 0, 0, 0);
+        uint4 dl = make_uint4(0, 0, 0, 0);
+        float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's 8 classes of the row's dlogits, un-rounded
+        if (live) {
+            if constexpr (F32IN) {
+                const float4 a = *(const float4*)((const float*)dlog_v + row * kKP + 8 * half);
+                const float4 b = *(const float4*)((const float*)dlog_v + row * kKP + 8 * half + 4);
+                d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+                dl = pack8(d);
+            } else {
+                dl = *(const uint4*)((const uint16_t*)dlog_v + row * kKP + 8 * half);
+                unpack8(dl, d);
+            }
+        }
         uint4 v[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) v[s] = live ? *(const uint4*)(y + row * C + 16 * s + 8 * half) : make_uint4(0, 0, 0, 0);
@@ -143,8 +174,7 @@ __global__ void __launch_bounds__(256) ln_head_bwd_kernel(const uint16_t* __rest
         }
         // D' = dlogits * rstd (bf16) and the two class sums, on this lane's 8 classes
         {
-            float d[8], dp[8];
-            unpack8(dl, d);
+            float dp[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) dp[j] = d[j] * rstd;
             const uint4 pk = pack8(dp);
@@ -217,15 +247,21 @@ int hs_ln_head_supported(int width, int n_classes, int dtype) {
 int64_t hs_ln_head_partials(int64_t rows) { return rows > 0 ? (int64_t)hs::grid_for(rows) * 4 : 0; }
 
 int hs_ln_head_fwd(const void* y, const void* wfold, const float* bvec, void* logits, float* mean, float* rstd, int64_t rows,
-                   int width, int dtype, void* stream) {
+                   int width, int dtype, int logits_dtype, void* stream) {
     using namespace hs;
     HS_CHECK_ARG(y && wfold && bvec && logits && mean && rstd, "null pointer");
     HS_CHECK_ARG(rows > 0, "bad shape");
+    HS_CHECK_ARG(logits_dtype == HS_BF16 || logits_dtype == HS_F32, "logits_dtype must be HS_BF16 or HS_F32");
     if (!hs_ln_head_supported(width, 1, dtype)) return fail(HS_ERR_UNSUPPORTED, "hs_ln_head: bf16 rows of 64..256 (multiple of 32) columns only");
     const dim3 grid(grid_for(rows)), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define HS_LNH_FWD(NB) \
-    case NB: hipLaunchKernelGGL(ln_head_fwd_kernel<NB>, grid, block, 0, s, (const uint16_t*)y, (const uint16_t*)wfold, bvec, (uint16_t*)logits, mean, rstd, rows); break;
+#define HS_LNH_FWD(NB)                                                                                                                   \
+    case NB:                                                                                                                             \
+        if (logits_dtype == HS_F32)                                                                                                      \
+            hipLaunchKernelGGL((ln_head_fwd_kernel<NB, true>), grid, block, 0, s, (const uint16_t*)y, (const uint16_t*)wfold, bvec, logits, mean, rstd, rows); \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((ln_head_fwd_kernel<NB, false>), grid, block, 0, s, (const uint16_t*)y, (const uint16_t*)wfold, bvec, logits, mean, rstd, rows); \
+        break;
     switch (width / 32) {
         HS_LNH_FWD(2) HS_LNH_FWD(3) HS_LNH_FWD(4) HS_LNH_FWD(5) HS_LNH_FWD(6) HS_LNH_FWD(7) HS_LNH_FWD(8)
     }
@@ -235,15 +271,21 @@ int hs_ln_head_fwd(const void* y, const void* wfold, const float* bvec, void* lo
 }
 
 int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const void* dlogits, const void* afold, void* dy,
-                   void* dprime, float* partials, int64_t rows, int width, int dtype, void* stream) {
+                   void* dprime, float* partials, int64_t rows, int width, int dtype, int logits_dtype, void* stream) {
     using namespace hs;
     HS_CHECK_ARG(y && mean && rstd && dlogits && afold && dy && dprime && partials, "null pointer");
     HS_CHECK_ARG(rows > 0, "bad shape");
+    HS_CHECK_ARG(logits_dtype == HS_BF16 || logits_dtype == HS_F32, "logits_dtype must be HS_BF16 or HS_F32");
     if (!hs_ln_head_supported(width, 1, dtype)) return fail(HS_ERR_UNSUPPORTED, "hs_ln_head: bf16 rows of 64..256 (multiple of 32) columns only");
     const dim3 grid(grid_for(rows)), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define HS_LNH_BWD(NB) \
-    case NB: hipLaunchKernelGGL(ln_head_bwd_kernel<NB>, grid, block, 0, s, (const uint16_t*)y, mean, rstd, (const uint16_t*)dlogits, (const uint16_t*)afold, (uint16_t*)dy, (uint16_t*)dprime, partials, rows); break;
+#define HS_LNH_BWD(NB)                                                                                                                   \
+    case NB:                                                                                                                             \
+        if (logits_dtype == HS_F32)                                                                                                      \
+            hipLaunchKernelGGL((ln_head_bwd_kernel<NB, true>), grid, block, 0, s, (const uint16_t*)y, mean, rstd, dlogits, (const uint16_t*)afold, (uint16_t*)dy, (uint16_t*)dprime, partials, rows); \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((ln_head_bwd_kernel<NB, false>), grid, block, 0, s, (const uint16_t*)y, mean, rstd, dlogits, (const uint16_t*)afold, (uint16_t*)dy, (uint16_t*)dprime, partials, rows); \
+        break;
     switch (width / 32) {
         HS_LNH_BWD(2) HS_LNH_BWD(3) HS_LNH_BWD(4) HS_LNH_BWD(5) HS_LNH_BWD(6) HS_LNH_BWD(7) HS_LNH_BWD(8)
     }

@@ -7,6 +7,8 @@
 // no transposed / fp32 copy of the logits is made (the torch composition costs five full passes over them).  HBM-bound:
 // forward reads the logits once, backward reads them once (softmax recomputed) and writes the gradient once.
 // Deterministic: per-workgroup partial sums in a fixed grid, summed by the caller.
+#include <type_traits>
+
 #include "hs_device.h"
 
 namespace hs {
@@ -98,13 +100,24 @@ __global__ void __launch_bounds__(256) seg_ce_bwd_kernel(CeArgs a, const float* 
 // at ~1 TB/s; here a pixel is two 16-byte loads, the K logits stay in registers, and the gradient leaves as whole vectors.
 constexpr int kRow = 16;
 
-__device__ __forceinline__ void load_row16(const void* logits, int64_t base, float* z) {
+template <typename T>
+__device__ __forceinline__ void load_row16(const void* logits, int64_t base, float* z);
+template <>
+__device__ __forceinline__ void load_row16<bf16_t>(const void* logits, int64_t base, float* z) {
     const uint4 a = *(const uint4*)((const uint16_t*)logits + base), b = *(const uint4*)((const uint16_t*)logits + base + 8);
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         z[2 * i] = __uint_as_float(w[i] << 16);
         z[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <>
+__device__ __forceinline__ void load_row16<float>(const void* logits, int64_t base, float* z) {  // fp32 logits rows of 16 (64 B)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *(const float4*)((const float*)logits + base + 4 * q);
+        z[4 * q] = v.x; z[4 * q + 1] = v.y; z[4 * q + 2] = v.z; z[4 * q + 3] = v.w;
     }
 }
 __device__ __forceinline__ float row_lse(const float* z, int K, float* zy, int64_t y) {
@@ -123,6 +136,7 @@ __device__ __forceinline__ float row_lse(const float* z, int K, float* zy, int64
     return m + logf(s);
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) seg_ce_fwd_row16_kernel(CeArgs a, float* __restrict__ partials) {
     const int64_t total = a.batch * a.npix;
     float num = 0.f, den = 0.f;
@@ -131,7 +145,7 @@ __global__ void __launch_bounds__(256) seg_ce_fwd_row16_kernel(CeArgs a, float* 
         if (y == a.ignore_index || (uint64_t)y >= (uint64_t)a.K) continue;
         const int64_t b = i / a.npix, px = i - b * a.npix;
         float z[kRow], zy;
-        load_row16(a.logits, b * a.sb + px * kRow, z);
+        load_row16<T>(a.logits, b * a.sb + px * kRow, z);
         const float w = a.weights ? a.weights[y] : 1.f;
         const float lse = row_lse(z, a.K, &zy, y);
         num = fmaf(w, lse - zy, num);
@@ -154,6 +168,7 @@ __global__ void __launch_bounds__(256) seg_ce_fwd_row16_kernel(CeArgs a, float* 
 
 // writes columns 0 .. K-1 only (K a multiple of 4: 8-byte groups), so a destination whose rows interleave with other data
 // is left alone exactly as by the generic kernel
+template <typename T>
 __global__ void __launch_bounds__(256) seg_ce_bwd_row16_kernel(CeArgs a, const float* __restrict__ scale_p, void* __restrict__ dlogits,
                                                                int64_t db) {
     const int64_t total = a.batch * a.npix;
@@ -166,17 +181,24 @@ __global__ void __launch_bounds__(256) seg_ce_bwd_row16_kernel(CeArgs a, const f
         for (int c = 0; c < kRow; ++c) d[c] = 0.f;
         if (!(y == a.ignore_index || (uint64_t)y >= (uint64_t)a.K)) {
             float z[kRow], zy;
-            load_row16(a.logits, b * a.sb + px * kRow, z);
+            load_row16<T>(a.logits, b * a.sb + px * kRow, z);
             const float g = scale * (a.weights ? a.weights[y] : 1.f);
             const float lse = row_lse(z, a.K, &zy, y);
 #pragma unroll
             for (int c = 0; c < kRow; ++c)
                 if (c < a.K) d[c] = g * (expf(z[c] - lse) - (c == y ? 1.f : 0.f));
         }
-        uint16_t* o = (uint16_t*)dlogits + b * db + px * kRow;
+        if constexpr (std::is_same<T, float>::value) {
+            float* o = (float*)dlogits + b * db + px * kRow;
 #pragma unroll
-        for (int q = 0; q < kRow / 4; ++q)
-            if (4 * q < a.K) *(uint2*)(o + 4 * q) = make_uint2(pack_bf16x2(d[4 * q], d[4 * q + 1]), pack_bf16x2(d[4 * q + 2], d[4 * q + 3]));
+            for (int q = 0; q < kRow / 4; ++q)
+                if (4 * q < a.K) *(float4*)(o + 4 * q) = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+        } else {
+            uint16_t* o = (uint16_t*)dlogits + b * db + px * kRow;
+#pragma unroll
+            for (int q = 0; q < kRow / 4; ++q)
+                if (4 * q < a.K) *(uint2*)(o + 4 * q) = make_uint2(pack_bf16x2(d[4 * q], d[4 * q + 1]), pack_bf16x2(d[4 * q + 2], d[4 * q + 3]));
+        }
     }
 }
 
@@ -184,7 +206,8 @@ __global__ void __launch_bounds__(256) seg_ce_bwd_row16_kernel(CeArgs a, const f
 // K used columns) and a pointer at the start of a 32-byte row -- a caller view such as buf[..., 8:16] (sp = 16, K = 8) would
 // otherwise read 16 bytes past the storage on its last pixel.
 bool row16_layout(const void* ptr, int64_t sb, int64_t sk, int64_t sp, int K, int dtype) {
-    return dtype == HS_BF16 && sk == 1 && sp == kRow && K > 8 && K <= kRow && K % 4 == 0 && sb % kRow == 0 && ((uintptr_t)ptr & 31) == 0;
+    const uintptr_t row_bytes = dtype == HS_BF16 ? 32 : 64;
+    return sk == 1 && sp == kRow && K > 8 && K <= kRow && K % 4 == 0 && sb % kRow == 0 && ((uintptr_t)ptr & (row_bytes - 1)) == 0;
 }
 
 int check_args(const CeArgs& a, int dtype) {
@@ -217,9 +240,10 @@ int hs_seg_ce_fwd(const void* logits, const void* labels, const float* class_wei
     if (int st = check_args(a, dtype)) return st;
     HS_CHECK_ARG(partials, "null pointer");
     const unsigned grid = ce_grid(batch * npix);
-    if (row16_layout(logits, stride_b, stride_k, stride_p, n_classes, dtype))
-        hipLaunchKernelGGL(seg_ce_fwd_row16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
-    else if (dtype == HS_BF16) hipLaunchKernelGGL(seg_ce_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
+    if (row16_layout(logits, stride_b, stride_k, stride_p, n_classes, dtype)) {
+        if (dtype == HS_BF16) hipLaunchKernelGGL(seg_ce_fwd_row16_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
+        else hipLaunchKernelGGL(seg_ce_fwd_row16_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
+    } else if (dtype == HS_BF16) hipLaunchKernelGGL(seg_ce_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
     else hipLaunchKernelGGL(seg_ce_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, partials);
     HS_LAUNCH_CHECK("seg_ce_fwd");
     return HS_OK;
@@ -235,9 +259,12 @@ int hs_seg_ce_bwd(const void* logits, const void* labels, const float* class_wei
     HS_CHECK_ARG(scale && dlogits, "null pointer");
     const unsigned grid = ce_grid(batch * npix);
     if (row16_layout(logits, stride_b, stride_k, stride_p, n_classes, dtype) &&
-        row16_layout(dlogits, dstride_b, dstride_k, dstride_p, n_classes, dtype))
-        hipLaunchKernelGGL(seg_ce_bwd_row16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, scale, dlogits, dstride_b);
-    else if (dtype == HS_BF16)
+        row16_layout(dlogits, dstride_b, dstride_k, dstride_p, n_classes, dtype)) {
+        if (dtype == HS_BF16)
+            hipLaunchKernelGGL(seg_ce_bwd_row16_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, scale, dlogits, dstride_b);
+        else
+            hipLaunchKernelGGL(seg_ce_bwd_row16_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, scale, dlogits, dstride_b);
+    } else if (dtype == HS_BF16)
         hipLaunchKernelGGL(seg_ce_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, scale, dlogits, dstride_b,
                            dstride_k, dstride_p);
     else

@@ -293,10 +293,12 @@ class SwinTransformerBlock(nn.Module):
             return None, self.shift_size % x.shape[1], labels
         return idx, 0, labels
 
-    def forward_deferred(self, x, pending):
-        """v1 block on the input `x + rs*drop(p)` for pending = (p, rs, drop_p) (or None); returns (x1, pending') with the
-        block output = x1 + rs'*drop(m) (ref :337-338 and :316 of the next block)."""
+    def forward_deferred(self, x, pending, x_lo=None):
+        """v1 block on the input `x (+ x_lo) + rs*drop(p)` for pending = (p, rs, drop_p) (or None); returns (x1, pending', x1_lo)
+        with the block output = x1 (+ x1_lo) + rs'*drop(m) (ref :337-338 and :316 of the next block).  x_lo / x1_lo are the
+        rounding remainders of the compensated residual stream (bf16 runs; None when off or not yet started)."""
         train = self.training
+        comp = ops.COMP_RESIDUAL and x.dtype == torch.bfloat16
         if self.attn.fusable(x, self.window_size) and not (train and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0):
             # no-grad forward: x1 = xs + proj(attn(qkv(norm1(xs)))) is ONE launch (norm1 as the kernel's prologue, the
             # residual add as its epilogue), xs = x + previous block's MLP branch
@@ -304,17 +306,39 @@ class SwinTransformerBlock(nn.Module):
             idx, roll, labels = self._shift_args(xs)
             x1 = self.attn.fused_module(xs, self.window_size, idx, roll, labels, norm=self.norm1, residual=True)
             m = self.mlp(self.norm2(x1), apply_out_drop=False)
-            return x1, (m, None, 0.0)
+            return x1, (m, None, 0.0), None
         if pending is None:  # x feeds norm1 AND the residual add below: the alias keeps the two gradients in one kernel
             n1, x = ops.layer_norm_passthrough(x, self.norm1.weight, self.norm1.bias)
+        elif comp:
+            t, rs, dp = pending
+            x, n1, x_lo = ops.add_layer_norm_stream(x, x_lo, t, self.norm1.weight, self.norm1.bias, row_scale=rs, drop_p=dp)
         else:
             t, rs, dp = pending
             x, n1 = ops.add_layer_norm(x, t, self.norm1.weight, self.norm1.bias, row_scale=rs, drop_p=dp)
         a = self._attention_branch(n1, apply_proj_drop=False)
-        x1, n2 = ops.add_layer_norm(x, a, self.norm2.weight, self.norm2.bias, row_scale=self._path_scale(x),
-                                    drop_p=self.attn.proj_drop.p if train else 0.0)
+        if comp:
+            x1, n2, x1_lo = ops.add_layer_norm_stream(x, x_lo, a, self.norm2.weight, self.norm2.bias, row_scale=self._path_scale(x),
+                                                      drop_p=self.attn.proj_drop.p if train else 0.0)
+        else:
+            x1_lo = None
+            x1, n2 = ops.add_layer_norm(x, a, self.norm2.weight, self.norm2.bias, row_scale=self._path_scale(x),
+                                        drop_p=self.attn.proj_drop.p if train else 0.0)
         m = self.mlp(n2, apply_out_drop=False)
-        return x1, (m, self._path_scale(x), self.mlp.drop.p if train else 0.0)
+        return x1, (m, self._path_scale(x), self.mlp.drop.p if train else 0.0), x1_lo
+
+    def can_stream_v2(self):
+        """v2 placement with the HIP norms: the block's two `x + norm(branch)` results are the residual stream itself."""
+        return self.use_v2_norm_placement and self._hs_norms()
+
+    def forward_stream_v2(self, x, x_lo=None):
+        """v2 block (ref :334-335) on the compensated stream x (+ x_lo); returns (x', x'_lo)."""
+        train = self.training
+        a, xr = self._attention_branch(x, apply_proj_drop=False, residual_alias=True)
+        x, x_lo = ops.layer_norm_stream(a, self.norm1.weight, self.norm1.bias, xr, res_lo=x_lo, row_scale=self._path_scale(x),
+                                        drop_p=self.attn.proj_drop.p if train else 0.0)
+        m, xr = self.mlp(x, apply_out_drop=False, residual_alias=True)
+        return ops.layer_norm_stream(m, self.norm2.weight, self.norm2.bias, xr, res_lo=x_lo, row_scale=self._path_scale(x),
+                                     drop_p=self.mlp.drop.p if train else 0.0)
 
     @staticmethod
     def resolve_pending(x, pending):
@@ -335,7 +359,7 @@ class SwinTransformerBlock(nn.Module):
         B, N, C = x.shape
         assert N == self.input_resolution, f"expected {self.input_resolution} tokens, got {N}"
         if self.can_defer():
-            return self.resolve_pending(*self.forward_deferred(x, None))
+            return self.resolve_pending(*self.forward_deferred(x, None)[:2])
         train = self.training
         if self.use_v2_norm_placement and self._hs_norms():  # ref :334-335: x + drop_path(norm(branch)), fused per branch
             # the residual operand is the alias handed back by the branch's first Linear: its gradient is then added inside
@@ -416,12 +440,19 @@ def _build_blocks(dim, input_resolution, depth, num_heads, window_size, base_pix
 class _Stage(nn.Module):
     def _run_blocks(self, x):
         pending = None  # second residual branch of the previous block, added inside the next block's first LayerNorm
+        x_lo = None     # rounding remainder of the residual stream (compensated bf16 stream, ops.COMP_RESIDUAL); dropped at the
+        #                 end of the stage (one ordinary rounding): every tensor that leaves a stage is a plain activation
         for blk in self.blocks:
-            if self.use_checkpoint or not blk.can_defer():
-                x, pending = SwinTransformerBlock.resolve_pending(x, pending), None
-                x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
+            if self.use_checkpoint:
+                x, pending, x_lo = SwinTransformerBlock.resolve_pending(x, pending), None, None
+                x = checkpoint.checkpoint(blk, x, use_reentrant=False)
+            elif blk.can_defer():
+                x, pending, x_lo = blk.forward_deferred(x, pending, x_lo)
+            elif blk.can_stream_v2() and ops.COMP_RESIDUAL and x.dtype == torch.bfloat16 and x.is_cuda:
+                x, x_lo = blk.forward_stream_v2(x, x_lo)
             else:
-                x, pending = blk.forward_deferred(x, pending)
+                x, pending, x_lo = SwinTransformerBlock.resolve_pending(x, pending), None, None
+                x = blk(x)
         return SwinTransformerBlock.resolve_pending(x, pending)
 
     def extra_repr(self):
@@ -547,7 +578,7 @@ class UnetDecoder(nn.Module):
             x = up.expand(self.norm_up(x))  # B, N0, p * C: row (b, n) holds the p children of token n back to back
             B, N0, _ = x.shape
             x = ops.ln_head(x.reshape(B * N0 * up.patch_size, up.dim), up.norm.weight, up.norm.bias, w)
-            return ops.pad_slice(x.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2)  # B, f_out, Npix
+            return ops.pad_slice(x.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2)  # B, f_out, Npix (fp32)
         x = up(self.norm_up(x))  # B, Npix, C
         if x.dtype == torch.bfloat16 and f_out % 8 and f_out > 8:
             # 12 classes: rows padded to 16 so that the input gradient (K = 12 -> 16) runs in hs_gemm_nt: 0.33 ms instead of the
@@ -555,7 +586,7 @@ class UnetDecoder(nn.Module):
             x = ops.pad_slice(ops.linear(x, F.pad(w.reshape(f_out, -1), (0, 0, 0, (-f_out) % 8))), f_out)
         else:
             x = ops.linear(x, w)
-        return x.transpose(1, 2)  # B, f_out, Npix
+        return x.float().transpose(1, 2)  # B, f_out, Npix; logits leave the model in fp32 whatever the compute dtype (see ops.LnHeadFn)
 
 
 @dataclass
@@ -687,7 +718,7 @@ class SwinHPTransformerSys(nn.Module):
                 or any(sh.device != p.device for sh, p in zip(cache.shadows[:1], params[:1]))):
             cache = ops.ParamCastCache(params, dt)
             self.__dict__["_cast_cache"] = cache  # not a module attribute: stays out of state_dict / .to()
-        cache.refresh()
+        cache.refresh(force=torch.is_grad_enabled())  # (fused optimizers do not bump parameter versions: see ops.ParamCastCache)
         return cache
 
     def invalidate_param_casts(self):

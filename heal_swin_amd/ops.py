@@ -177,6 +177,13 @@ def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window
                                   float(attn_drop), int(seed or 0))
 
 
+# Compensated residual stream (bf16 runs): the two residual adds of every block keep their rounding remainder in a second bf16
+# tensor that only the next add reads (csrc/layernorm.hip).  Opt-in (HS_COMP_RESIDUAL=1): measured on HEAL-SWIN-B / nside 256 it
+# halves the error of the stage outputs (enc.2: 2.6e-2 -> 1.3e-2 of scale) but moves the LOGIT error by only 0-12 % (the decoder
+# tail's roundings dominate it, tests/experiments/bf16_error_budget.py) and costs 2.4 % of the step (158.7 -> 162.6 ms).
+COMP_RESIDUAL = os.environ.get("HS_COMP_RESIDUAL", "0") == "1"
+
+
 FUSED_ATTN_MODULE = os.environ.get("HS_FUSED_ATTN_MODULE", "1") != "0"  # A/B switch of the no-grad fused module path
 
 
@@ -255,7 +262,9 @@ class LayerNormFn(torch.autograd.Function):
     optional per-sample DropPath factor and dropout mask (train mode), absent in eval."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, extras, passthrough=False):
+    def forward(ctx, x, weight, bias, residual, extras, passthrough=False, res_lo=None, want_lo=False):
+        """res_lo / want_lo: compensated residual stream of the v2 placement (y = residual + LN(x) IS the stream): the stream
+        operand is residual + res_lo, and with want_lo the call returns (y, y_lo) with y_lo the rounding remainder of y."""
         _require_gpu(x, weight, bias, residual)
         x = x.contiguous()
         width = x.shape[-1]
@@ -269,7 +278,15 @@ class LayerNormFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:3])
         mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
-        if extras is None:
+        y_lo = None
+        if want_lo or res_lo is not None:
+            assert res is not None and not passthrough
+            y_lo = torch.empty_like(x) if want_lo else None
+            rs, rps, p, seed = extras if extras is not None else (None, 1, 0.0, 0)
+            check(lib.hs_layernorm_fwd_ex(ptr(x), ptr(res), None, ptr(None if res_lo is None else res_lo.contiguous()), ptr(g), ptr(b),
+                                          ptr(y), None, ptr(y_lo), ptr(mean), ptr(rstd), ptr(rs), rps, p, seed, rows, width, dt,
+                                          stream_ptr(x.device)), "hs_layernorm_fwd_ex")
+        elif extras is None:
             check(lib.hs_layernorm_fwd(ptr(x), ptr(res), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, width, dt,
                                        stream_ptr(x.device)), "hs_layernorm_fwd")
         else:
@@ -282,6 +299,9 @@ class LayerNormFn(torch.autograd.Function):
         # passthrough (plain norm only): also hand x back as an alias for a second use (the block's residual connection); its
         # gradient then arrives here with dy and is added inside the backward kernel instead of by a separate elementwise add
         assert not passthrough or (extras is None and residual is None)
+        if want_lo:
+            ctx.mark_non_differentiable(y_lo)
+            return y, y_lo
         return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
@@ -290,7 +310,7 @@ class LayerNormFn(torch.autograd.Function):
         rows, width, dt, has_res, extras = ctx.meta
         weight, bias = ctx.params
         if dy is None:  # only the alias was used downstream
-            return dx_alias, None, None, None, None, None
+            return dx_alias, None, None, None, None, None, None, None
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma, dbeta, direct = _norm_param_grads(weight, bias, width, x.device, ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
@@ -308,11 +328,17 @@ class LayerNormFn(torch.autograd.Function):
                                             ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
                   "hs_layernorm_drop_bwd")
         dw, db = _norm_param_result(weight, bias, dgamma, dbeta, direct)
-        return dx, dw, db, (dy if has_res else None), None, None
+        return dx, dw, db, (dy if has_res else None), None, None, None, None
 
 
 def layer_norm(x, weight, bias, residual=None, row_scale=None, drop_p=0.0, seed=None):
     return LayerNormFn.apply(x, weight, bias, residual, _extras(x, row_scale, drop_p, seed))
+
+
+def layer_norm_stream(x, weight, bias, residual, res_lo=None, row_scale=None, drop_p=0.0, seed=None):
+    """(y, y_lo) with y + y_lo = residual + res_lo + rs * LN(drop(x)) to 16 mantissa bits: the v2-placement residual stream kept
+    compensated (see csrc/layernorm.hip).  y is the plain activation tensor; y_lo is not differentiable."""
+    return LayerNormFn.apply(x, weight, bias, residual, _extras(x, row_scale, drop_p, seed), False, res_lo, True)
 
 
 def layer_norm_passthrough(x, weight, bias):
@@ -325,7 +351,9 @@ class AddLayerNormFn(torch.autograd.Function):
     and routes the gradient of b through the same DropPath factor / dropout mask."""
 
     @staticmethod
-    def forward(ctx, a, b, weight, bias, extras):
+    def forward(ctx, a, b, weight, bias, extras, a_lo=None, want_lo=False):
+        """a_lo / want_lo: compensated residual stream (csrc/layernorm.hip): the stream operand is a + a_lo, and with want_lo the
+        call returns (s, y, s_lo) with s_lo the rounding remainder of the new stream s (not differentiable)."""
         _require_gpu(a, b, weight, bias)
         a, b = a.contiguous(), b.contiguous()
         assert a.shape == b.shape and a.dtype == b.dtype
@@ -337,7 +365,14 @@ class AddLayerNormFn(torch.autograd.Function):
         y = torch.empty_like(a)
         mean = torch.empty(rows, dtype=torch.float32, device=a.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
-        if extras is None:
+        s_lo = None
+        if want_lo or a_lo is not None:
+            s_lo = torch.empty_like(a) if want_lo else None
+            rs, rps, p, seed = extras if extras is not None else (None, 1, 0.0, 0)
+            check(lib.hs_layernorm_fwd_ex(ptr(a), None, ptr(b), ptr(None if a_lo is None else a_lo.contiguous()), ptr(g), ptr(be), ptr(y),
+                                          ptr(s), ptr(s_lo), ptr(mean), ptr(rstd), ptr(rs), rps, p, seed, rows, width, dt,
+                                          stream_ptr(a.device)), "hs_layernorm_fwd_ex")
+        elif extras is None:
             check(lib.hs_add_layernorm_fwd(ptr(a), ptr(b), ptr(g), ptr(be), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, width,
                                            dt, stream_ptr(a.device)), "hs_add_layernorm_fwd")
         else:
@@ -347,16 +382,19 @@ class AddLayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(s, g, mean, rstd, None if extras is None else extras[0])
         ctx.meta = (rows, width, dt, extras)
         ctx.params = (weight, bias)
+        if want_lo:
+            ctx.mark_non_differentiable(s_lo)
+            return s, y, s_lo
         return s, y
 
     @staticmethod
-    def backward(ctx, ds, dy):
+    def backward(ctx, ds, dy, ds_lo=None):
         s, g, mean, rstd, rs = ctx.saved_tensors
         rows, width, dt, extras = ctx.meta
         weight, bias = ctx.params
         if dy is None:  # only the sum was used downstream
             if extras is None:
-                return ds, ds, None, None, None
+                return ds, ds, None, None, None, None, None
             dy = torch.zeros_like(s)
         dy = dy.contiguous()
         ds_c = None if ds is None else ds.contiguous()
@@ -375,12 +413,18 @@ class AddLayerNormFn(torch.autograd.Function):
                                                 ptr(dgamma), ptr(dbeta), ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width,
                                                 dt, stream_ptr(s.device)), "hs_add_layernorm_drop_bwd")
         dw, dbias = _norm_param_result(weight, bias, dgamma, dbeta, direct)
-        return da, db, dw, dbias, None
+        return da, db, dw, dbias, None, None, None
 
 
 def add_layer_norm(a, b, weight, bias, row_scale=None, drop_p=0.0, seed=None):
     """returns (a + rs*drop(b), LayerNorm(a + rs*drop(b)))"""
     return AddLayerNormFn.apply(a, b, weight, bias, _extras(a, row_scale, drop_p, seed))
+
+
+def add_layer_norm_stream(a, a_lo, b, weight, bias, row_scale=None, drop_p=0.0, seed=None):
+    """(s, y, s_lo): s + s_lo = a + a_lo + rs*drop(b) to 16 mantissa bits (a_lo may be None), y = LayerNorm of that sum: the
+    v1-placement residual stream kept compensated.  s is the plain activation tensor; s_lo is not differentiable."""
+    return AddLayerNormFn.apply(a, b, weight, bias, _extras(a, row_scale, drop_p, seed), a_lo, True)
 
 
 # ----------------------------------------------------------------------------- GELU (+ dropout)
@@ -474,12 +518,17 @@ GRAD_SINK = None
 
 
 class ParamCastCache:
-    """Activation-dtype copies of the fp32 master parameters of the Linear layers.  Refreshed for ALL registered parameters
-    by one multi-tensor copy when any of them changed since the last refresh, instead of one cast kernel per parameter and
-    forward.  A change is detected through (data_ptr, _version) of each parameter: optimizer steps, load_state_dict,
-    `param.data = ...` are seen; in-place writes through `param.data` (some EMA / SWA utilities, manual weight surgery) bump
-    neither -- call `invalidate()` (or `model.invalidate_param_casts()`) after those, or set `always_refresh = True` to pay
-    the one multi-tensor copy every forward."""
+    """Activation-dtype copies of the fp32 master parameters of the Linear layers, refreshed for ALL registered parameters by
+    one multi-tensor copy instead of one cast kernel per parameter and forward.  When:
+      * every GRAD-ENABLED forward (`force`): a training forward is followed by an optimizer step, and the FUSED optimizers
+        (`torch.optim.Adam(fused=True)`, what bench.py and the Lightning trainer use) update the parameters WITHOUT bumping their
+        `_version` counters (verified: 0 -> 0 across `step()`), so a version check alone left the forward on the bf16 weights of
+        step 0 for a whole run (found in round 3 by tests/test_gpu_graphs.py::test_eager_forward_between_replays_...);
+      * a no-grad forward after a grad-enabled one (`dirty`), or whenever (data_ptr, _version) of a parameter changed
+        (load_state_dict, `param.data = ...`, non-fused optimizers);
+      * after `invalidate()` (`model.invalidate_param_casts()`): HIP-graph replays and in-place writes through `param.data`
+        (EMA / SWA utilities, manual weight surgery) are invisible to both rules.
+    Cost: one read of the fp32 masters and one bf16 write per training step (0.9 GB for HEAL-SWIN-B: ~0.2 ms of a 155 ms step)."""
 
     always_refresh = False
 
@@ -489,17 +538,19 @@ class ParamCastCache:
         self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.versions = None
+        self.dirty = False    # a grad-enabled forward has run since the last refresh: the parameters are about to change
         self.transposed = {}  # index -> (transposed shadow, the `versions` list object it was made from)
 
     def invalidate(self):
         self.versions = None
 
-    def refresh(self):
+    def refresh(self, force=False):
         versions = [(p.data_ptr(), p._version) for p in self.params]
-        if self.always_refresh or versions != self.versions:
+        if force or self.dirty or self.always_refresh or versions != self.versions:
             with torch.no_grad():
                 torch._foreach_copy_(self.shadows, self.params)
             self.versions = versions
+        self.dirty = bool(force)
 
     def get(self, p, dtype):
         i = self.index.get(id(p)) if dtype == self.dtype else None
@@ -783,7 +834,7 @@ def ln_head_ok(x, width, n_classes):
 class LnHeadFn(torch.autograd.Function):
     """LayerNorm(C) + bias-free 1x1 head as one pass over the rows, forward and backward (reference: the `norm` of
     FinalPatchExpand_X4, swin_hp_transformer.py:448-452, followed by `self.output`, :785-788): the normalised [rows, C] tensor is
-    neither written nor saved.  Returns the padded logits [rows, 16] (columns >= f_out are zero); backward takes their gradient.
+    neither written nor saved.  Returns the padded logits [rows, 16] in FP32 (columns >= f_out are zero); backward takes their gradient.
     Parameter gradients come from ONE weight-gradient product over the raw rows (see csrc/ln_head.hip):
         X[k, c] = sum_rows dlogits[row, k] xhat[row, c] = hs_linear_wgrad(dlogits * rstd, y)[k, c] - sum_rows dlogits rstd mean
         dW = gamma X + beta u,   dgamma_c = sum_k W X,   dbeta_c = sum_k W u,   u[k] = sum_rows dlogits[row, k]."""
@@ -801,12 +852,14 @@ class LnHeadFn(torch.autograd.Function):
         wfold[:f_out] = (w * g32).to(torch.bfloat16)
         bvec = torch.zeros(32, dtype=torch.float32, device=y2.device)
         bvec[:f_out] = w @ b32
-        logits = torch.empty((rows, LnHeadFn.KP), dtype=torch.bfloat16, device=y2.device)
+        # fp32 logits: the tail's roundings (norm_up -> expand -> xhat -> logits) dominate the bf16 logit error of the whole
+        # model (csrc/ln_head.hip); the logits therefore keep their accumulator value and xhat enters the head as hi + lo
+        logits = torch.empty((rows, LnHeadFn.KP), dtype=torch.float32, device=y2.device)
         mean = torch.empty(rows, dtype=torch.float32, device=y2.device)
         rstd = torch.empty_like(mean)
-        with _timed("ln_head_fwd", y2.device, 2 * rows * (C + LnHeadFn.KP) + 8 * rows, 2 * rows * C * 32):
+        with _timed("ln_head_fwd", y2.device, rows * (2 * C + 4 * LnHeadFn.KP) + 8 * rows, 2 * rows * C * 32):
             check(lib.hs_ln_head_fwd(ptr(y2), ptr(wfold), ptr(bvec), ptr(logits), ptr(mean), ptr(rstd), rows, C, _lib.HS_BF16,
-                                     stream_ptr(y2.device)), "hs_ln_head_fwd")
+                                     _lib.HS_F32, stream_ptr(y2.device)), "hs_ln_head_fwd")
         ctx.save_for_backward(y2, mean, rstd, gamma, beta, weight)
         return logits
 
@@ -820,13 +873,13 @@ class LnHeadFn(torch.autograd.Function):
         g32, b32 = gamma.detach().float(), beta.detach().float()
         afold = torch.zeros((C, KP), dtype=torch.bfloat16, device=dev)
         afold[:, :f_out] = (w * g32).t().to(torch.bfloat16)
-        dlogits = dlogits.to(torch.bfloat16).contiguous()
+        dlogits = dlogits.to(torch.float32).contiguous()
         dy = torch.empty_like(y2)
-        dprime = torch.empty_like(dlogits)
+        dprime = torch.empty((rows, KP), dtype=torch.bfloat16, device=dev)
         part = torch.empty((int(lib.hs_ln_head_partials(rows)), 32), dtype=torch.float32, device=dev)
-        with _timed("ln_head_bwd", dev, 2 * rows * (2 * C + 2 * KP) + 8 * rows, 2 * rows * C * KP):
+        with _timed("ln_head_bwd", dev, rows * (4 * C + 6 * KP) + 8 * rows, 2 * rows * C * KP):
             check(lib.hs_ln_head_bwd(ptr(y2), ptr(mean), ptr(rstd), ptr(dlogits), ptr(afold), ptr(dy), ptr(dprime), ptr(part), rows, C,
-                                     _lib.HS_BF16, stream_ptr(dev)), "hs_ln_head_bwd")
+                                     _lib.HS_BF16, _lib.HS_F32, stream_ptr(dev)), "hs_ln_head_bwd")
         ut = part.sum(0)
         u, t = ut[:f_out], ut[KP:KP + f_out]
         dgamma = dbeta = dw = None

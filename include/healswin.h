@@ -215,6 +215,16 @@ int hs_layernorm_drop_bwd(const void* dy, const void* x, const float* gamma, con
 int hs_add_layernorm_drop_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* sum_out, void* y,
                               float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample, float drop_p,
                               uint64_t seed, int64_t rows, int width, int dtype, void* stream);
+/* General forward with every optional operand, incl. the COMPENSATED RESIDUAL STREAM (replaces the reference's two plain adds per
+ * block, swin_hp_transformer.py:316 / :338 (v1) and :334-335 (v2), whose results it keeps to 16 instead of 8 mantissa bits in bf16):
+ * exactly one of `residual` (v2: y = residual + rs LN(drop(x))) and `add_in` (v1: sum_out = x + rs drop(add_in), y = LN(sum_out)).
+ * lo_in (optional) is the rounding remainder of the stream operand (x for v1, residual for v2) left by the previous call, lo_out
+ * (optional) receives the remainder of the new stream (sum_out for v1, y for v2): stream = hi + lo with hi the plain activation
+ * tensor every other kernel reads.  Backward: the plain hs_*layernorm*_bwd entry points on the hi tensors. */
+int hs_layernorm_fwd_ex(const void* x, const void* residual, const void* add_in, const void* lo_in, const float* gamma,
+                        const float* beta, void* y, void* sum_out, void* lo_out, float* mean, float* rstd,
+                        const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed, int64_t rows, int width,
+                        int dtype, void* stream);
 int hs_add_layernorm_drop_bwd(const void* dy, const void* dsum, const void* sum, const float* gamma, const float* mean,
                               const float* rstd, void* da, void* db, float* dgamma, float* dbeta, float* workspace, int accumulate,
                               const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed,
@@ -357,13 +367,16 @@ int hs_sample_mask_u8(const void* mask, int batch, int height, int width, const 
  *             partials [dev] f32[hs_ln_head_partials(rows), 32]: per-wave sums u[k] = sum dlogits (0..15) and
  *             t[k] = sum dprime * mean (16..31).  With X = hs_linear_wgrad(dprime, y) - t:  dW = gamma X + beta u,
  *             dgamma_c = sum_k W X, dbeta_c = sum_k W u   (heal_swin_amd/ops.py:LnHeadFn).
+ *   logits_dtype: HS_BF16 (32-byte rows) or HS_F32 (64-byte rows: the logits keep their fp32 accumulator value and xhat enters the
+ *             head product as hi + lo; dlogits is then read as fp32 too) -- the decoder tail's roundings are not averaged by
+ *             anything downstream and dominate the bf16 logit error, see csrc/ln_head.hip.
  * ---------------------------------------------------------------------------------------------- */
 int hs_ln_head_supported(int width, int n_classes, int dtype);
 int64_t hs_ln_head_partials(int64_t rows);
 int hs_ln_head_fwd(const void* y, const void* wfold, const float* bvec, void* logits, float* mean, float* rstd, int64_t rows,
-                   int width, int dtype, void* stream);
+                   int width, int dtype, int logits_dtype, void* stream);
 int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const void* dlogits, const void* afold, void* dy,
-                   void* dprime, float* partials, int64_t rows, int width, int dtype, void* stream);
+                   void* dprime, float* partials, int64_t rows, int width, int dtype, int logits_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PatchMerging / PatchExpand / FinalPatchExpand_X4 as one operator call per module and direction (SURVEY 8b's proposed

@@ -93,7 +93,9 @@ def test_window_attention_reference_scale_golden(name, dtype):
     for k, g in c["grad"].items():
         got = params[k].grad
         got = torch.zeros_like(params[k]) if got is None else got
-        assert_close(got, g, GRAD_TOL[dtype], "refinit grad " + k, floor=_zero_floor(c, k))
+        # d logit_scale: one scalar per head summed over every (window, query, key): 5e-2 of its value in bf16
+        tol = 5e-2 if (k.endswith("logit_scale") and dtype == torch.bfloat16) else GRAD_TOL[dtype]
+        assert_close(got, g, tol, "refinit grad " + k, floor=_zero_floor(c, k))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -219,6 +221,64 @@ def test_layernorm_vs_oracle(rows, width, residual, dtype):
     assert_close(bd.grad, br.grad, GRAD_TOL[dtype], "dbeta")
     if residual:
         assert_close(rd.grad, rr.grad, GRAD_TOL[dtype], "dres")
+
+
+# ----------------------------------------------------------------------------- compensated residual stream
+@pytest.mark.parametrize("placement", ["v1", "v2"])
+def test_compensated_stream_tracks_the_fp32_sum(placement):
+    """36 residual adds in a row (the depth of HEAL-SWIN-B's stage 2) in bf16: the plain stream rounds after every add, the
+    compensated one (hi + lo, `hs_layernorm_fwd_ex`) follows the fp32 sum to 2^-16; the normalised output is LN of the
+    un-rounded sum; the gradients are those of the plain kernels."""
+    ops, _, _ = _mods()
+    from oracle import model as OM
+    g = torch.Generator().manual_seed(3)
+    rows, width, depth = 1000, 512, 36
+    x0 = torch.randn(rows, width, generator=g).to(torch.bfloat16)
+    w = 1 + 0.3 * torch.randn(width, generator=g)
+    b = 0.2 * torch.randn(width, generator=g)
+    branches = [(0.3 * torch.randn(rows, width, generator=g)).to(torch.bfloat16) for _ in range(depth)]
+    wd, bd = w.to(DEV), b.to(DEV)
+    ref = x0.float()
+    plain, comp, lo = x0.to(DEV), x0.to(DEV), None
+    for t in branches:
+        td = t.to(DEV)
+        if placement == "v1":   # s = a + t, y = LN(s)
+            ref = ref + t.float()
+            y_ref = OM.layer_norm(ref, w, b)
+            plain, _ = ops.add_layer_norm(plain, td, wd, bd)
+            comp, y, lo = ops.add_layer_norm_stream(comp, lo, td, wd, bd)
+        else:                   # y = res + LN(t): the output is the stream
+            ref = ref + OM.layer_norm(t.float(), w, b)
+            plain = ops.layer_norm(td, wd, bd, plain)
+            comp, lo = ops.layer_norm_stream(td, wd, bd, comp, res_lo=lo)
+    scale = float(ref.abs().max())
+    err_plain = float((plain.float().cpu() - ref).abs().max()) / scale
+    err_hi = float((comp.float().cpu() - ref).abs().max()) / scale
+    err_comp = float((comp.float().cpu() + lo.float().cpu() - ref).abs().max()) / scale
+    import conftest
+    conftest.NOTES.append(f"residual stream after {depth} bf16 adds ({placement}): plain {err_plain:.2e}, compensated hi {err_hi:.2e}, "
+                          f"hi + lo {err_comp:.2e} of the fp32 sum's scale")
+    assert err_comp < 3e-5 and err_comp < err_plain / 50 and err_hi <= 2.0 ** -8
+    if placement == "v1":
+        assert_close(y, y_ref, 6e-3, "LN of the compensated sum")  # (bf16 output rounding only)
+    # gradients: identical to the plain kernels' (the remainder is not differentiable)
+    a = x0.to(DEV).requires_grad_(True)
+    t = branches[0].to(DEV).requires_grad_(True)
+    wg, bg = wd.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+    dy = torch.randn(rows, width, generator=g).to(torch.bfloat16).to(DEV)
+    got = {}
+    for mode in ("plain", "comp"):
+        for v in (a, t, wg, bg):
+            v.grad = None
+        if placement == "v1":
+            out = ops.add_layer_norm(a, t, wg, bg) if mode == "plain" else ops.add_layer_norm_stream(a, None, t, wg, bg)[:2]
+            (out[0].float() * 0.5 + out[1].float() * dy.float()).sum().backward()
+        else:
+            out = ops.layer_norm(t, wg, bg, a) if mode == "plain" else ops.layer_norm_stream(t, wg, bg, a)[0]
+            (out.float() * dy.float()).sum().backward()
+        got[mode] = [v.grad.clone() for v in (a, t, wg, bg)]
+    for p_, c_ in zip(got["plain"], got["comp"]):
+        assert_close(c_, p_, 2e-2 if placement == "v1" else 1e-6, "gradient of the compensated call")
 
 
 # ----------------------------------------------------------------------------- shifters (standalone gather) bit-exact

@@ -33,7 +33,7 @@ def test_ln_head_matches_the_composition(rows, C, f_out):
     yq = y.clone().requires_grad_(True)
     out = ops.ln_head(yq, gamma, beta, w)
     assert out.shape == (rows, 16) and not out[:, f_out:].any()
-    out[:, :f_out].backward(dlog)
+    out[:, :f_out].backward(dlog.float())  # (the logits are fp32)
     ref_out, ref_dy, ref_dg, ref_db, ref_dw = reference(y, gamma, beta, w.reshape(f_out, C), dlog)
     tag = f"ln_head[{rows}x{C}->{f_out}]"
     assert_close(out[:, :f_out], ref_out, TOL[torch.bfloat16], tag + " logits")
@@ -56,7 +56,7 @@ def test_ln_head_with_a_large_row_mean():
     w = (torch.randn(f_out, C, device="cuda") * C ** -0.5).requires_grad_(True)
     dlog = torch.randn(rows, f_out, device="cuda").to(torch.bfloat16)
     yq = y.clone().requires_grad_(True)
-    ops.ln_head(yq, gamma, beta, w)[:, :f_out].backward(dlog)
+    ops.ln_head(yq, gamma, beta, w)[:, :f_out].backward(dlog.float())
     _, ref_dy, ref_dg, ref_db, ref_dw = reference(y, gamma, beta, w, dlog)
     assert_close(yq.grad, ref_dy, GRAD_TOL[torch.bfloat16], "ln_head large-mean dy")
     assert_close(w.grad, ref_dw, GRAD_TOL[torch.bfloat16], "ln_head large-mean dW")

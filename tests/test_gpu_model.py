@@ -96,7 +96,7 @@ def test_whole_model_golden(name, dtype):
     model.compute_dtype = dtype
     x = torch.from_numpy(c["x"]).to(DEV).requires_grad_(True)  # raw 0..255 fp32 input, cast inside the model
     y = model(x)
-    assert y.dtype == dtype and y.shape == tuple(c["y"].shape)
+    assert y.dtype == torch.float32 and y.shape == tuple(c["y"].shape)  # logits leave the model in fp32 whatever the compute dtype
     # bf16 tolerance: north_star's 1e-2 holds on default-initialised models (tests/test_gpu_baseline_configs.py asserts it on
     # BASELINE's own architectures).  THESE goldens are a STRESS case: all weights N(0, 0.3..1) instead of 0.02 and, in the
     # cosine cases, one head's logit_scale pinned at the x100 clamp (ref :144-146), which amplifies bf16's 2^-9 input rounding
@@ -105,7 +105,7 @@ def test_whole_model_golden(name, dtype):
     if dtype == torch.bfloat16:
         stress = 8.0 if cfg["use_cos_attn"] else 3.0
     assert_close(y, c["y"], TOL[dtype] * stress, "logits" + (" [bf16 stress golden]" if stress > 1 else ""))
-    y.backward(torch.from_numpy(c["dy"]).to(DEV).to(dtype))
+    y.backward(torch.from_numpy(c["dy"]).to(DEV))
     gt = GRAD_TOL[dtype] * (stress * 2.0 if (dtype == torch.bfloat16 and cfg["use_cos_attn"]) else stress)
     assert_close(x.grad, c["dx"], gt, "dx")
     params = dict(model.named_parameters())
@@ -131,7 +131,9 @@ def _check_grads_own_scale(mod, c, dtype, tag):
     for k, g in c["grad"].items():
         got = params[k].grad
         got = torch.zeros_like(params[k]) if got is None else got
-        assert_close(got, g, GRAD_TOL[dtype], f"{tag} grad {k}", floor=_zero_floor(c, k))
+        # d logit_scale: one scalar per head summed over every (window, query, key): 5e-2 of its value in bf16
+        tol = 5e-2 if (k.endswith("logit_scale") and dtype == torch.bfloat16) else GRAD_TOL[dtype]
+        assert_close(got, g, tol, f"{tag} grad {k}", floor=_zero_floor(c, k))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -169,9 +171,9 @@ def test_whole_model_reference_scale_golden(name, dtype):
     model.compute_dtype = dtype
     x = torch.from_numpy(c["x"]).to(DEV).requires_grad_(True)
     y = model(x)
-    assert y.dtype == dtype and y.shape == tuple(c["y"].shape)
+    assert y.dtype == torch.float32 and y.shape == tuple(c["y"].shape)  # logits leave the model in fp32 whatever the compute dtype
     assert_close(y, c["y"], TOL[dtype], "refinit logits")
-    y.backward(torch.from_numpy(c["dy"]).to(DEV).to(dtype))
+    y.backward(torch.from_numpy(c["dy"]).to(DEV))
     assert_close(x.grad, c["dx"], GRAD_TOL[dtype], "refinit dx")
     _check_grads_own_scale(model, c, dtype, "refinit model")
 

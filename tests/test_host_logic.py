@@ -30,6 +30,40 @@ def test_param_cast_cache_refreshes_only_after_parameter_updates():
     assert not torch.equal(cache.get(params[1], torch.bfloat16), before[1])
 
 
+def test_param_cast_cache_survives_fused_optimizers_that_do_not_bump_versions():
+    """`torch.optim.Adam(fused=True)` updates parameters WITHOUT bumping `_version` (asserted here, so that a PyTorch that
+    changes this is noticed): a grad-enabled forward therefore refreshes unconditionally (`force`), and the first no-grad
+    forward after one does too (`dirty`); later no-grad forwards stay free."""
+    from heal_swin_amd import ops
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(16, 8))
+    try:
+        opt = torch.optim.Adam([p], lr=0.1, fused=True)
+    except (RuntimeError, ValueError):
+        import pytest
+        pytest.skip("no fused Adam for CPU tensors in this PyTorch")
+    cache = ops.ParamCastCache([p], torch.bfloat16)
+    calls = []
+    orig = torch._foreach_copy_
+    torch._foreach_copy_ = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        for _ in range(3):                      # three training steps
+            cache.refresh(force=True)           # what SwinHPTransformerSys.forward does when grad is enabled
+            assert torch.equal(cache.get(p, torch.bfloat16), p.detach().to(torch.bfloat16))
+            v0 = p._version
+            p.grad = torch.randn_like(p)
+            opt.step()
+            fused_is_silent = p._version == v0
+        assert len(calls) == 3
+        cache.refresh()                         # evaluation after training: `dirty` forces the copy even if the version is unchanged
+        assert len(calls) == 4 and torch.equal(cache.get(p, torch.bfloat16), p.detach().to(torch.bfloat16))
+        cache.refresh()                         # second evaluation: nothing happened in between
+        assert len(calls) == 4
+    finally:
+        torch._foreach_copy_ = orig
+    assert fused_is_silent, "fused Adam now bumps _version: the `force` rule in ParamCastCache could be relaxed"
+
+
 def test_cast_param_falls_back_to_a_plain_cast_without_a_cache():
     from heal_swin_amd import ops
     p = torch.nn.Parameter(torch.randn(4, 4))

@@ -63,3 +63,32 @@ def test_seg_loss_has_no_cpu_path():
 def test_losses_gpu():
     _check_seg("cuda")
     _check_depth("cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_seg_loss_padded_row_fast_path_equals_the_generic_kernels(dtype):
+    """The model's own logits layout -- [B, Npix, 16] rows with K = 12 used columns, viewed as [B, K, Npix] -- takes the
+    `seg_ce_*_row16` kernels (bf16: 32-byte rows, fp32: 64-byte rows since round 3); a class-major copy of the same values takes
+    the generic strided kernels.  Same loss and the same gradient, which arrives in the padded buffer's layout with zero pads."""
+    from heal_swin_amd import losses as L
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B, P, K = 2, 5000, 12
+    rows = (torch.randn(B, P, 16, generator=g, device="cuda") * 3).to(dtype)
+    rows[..., K:] = 0
+    labels = torch.randint(0, K, (B, P), generator=g, device="cuda", dtype=torch.uint8)
+    w = torch.rand(K, generator=g, device="cuda") + 0.5
+    fast = rows.clone().requires_grad_(True)
+    lf = L.seg_loss(fast[..., :K].transpose(1, 2), labels, w)
+    lf.backward()
+    slow = rows[..., :K].transpose(1, 2).contiguous().requires_grad_(True)  # [B, K, P] class-major: the generic kernels
+    ls = L.seg_loss(slow, labels, w)
+    ls.backward()
+    assert abs(float(lf) - float(ls)) <= 1e-6 * abs(float(ls))
+    assert torch.equal(fast.grad[..., K:], torch.zeros_like(fast.grad[..., K:]))
+    assert torch.allclose(fast.grad[..., :K].transpose(1, 2).float(), slow.grad.float(), rtol=0, atol=1e-8 if dtype == torch.float32 else 0)
+    # a view that starts in the middle of a padded row must NOT take the whole-row loads (ADVICE round 2)
+    mid = rows.clone()[..., 4:16].transpose(1, 2)
+    lm = L.seg_loss(mid, labels, w)
+    lr = L.seg_loss(mid.contiguous(), labels, w)
+    assert abs(float(lm) - float(lr)) <= 1e-6 * abs(float(lr))
