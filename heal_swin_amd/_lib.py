@@ -68,6 +68,8 @@ _SIGNATURES = {
     "hs_gemm_nt": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int,
                    ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_gemm_nt_set_tile": [c_int],
+    "hs_set_reserved_cus": [c_int],
+    "hs_debug_occupy_cus": [c_int, c_int, c_int, ctypes.c_double, c_ptr],
     "hs_window_attn_module_supported": [c_int, c_int, c_int, c_int],
     "hs_window_attn_module_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_i64,
                                   c_int, c_int, c_int, c_uint, c_int, c_ptr],
@@ -84,6 +86,7 @@ _OTHER = {
     "hs_last_error": ([], ctypes.c_char_p),
     "hs_status_string": ([c_int], ctypes.c_char_p),
     "hs_device_count": ([], c_int),
+    "hs_get_reserved_cus": ([], c_int),
     "hs_layernorm_bwd_workspace": ([c_i64, c_int], c_i64),
     "hs_seg_ce_partials": ([c_i64, c_i64], c_i64),
     "hs_ln_head_partials": ([c_i64], c_i64),

@@ -495,7 +495,7 @@ int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
     if (tiles > 0x7fffffff) return fail(HS_ERR_UNSUPPORTED, "too many output tiles");
     p.tiles = (int)tiles;
     p.per_xcd = (p.tiles + 7) / 8;
-    const int resident = 32 * wgs_per_cu;  // workgroups per XCD in one resident round (32 CUs per XCD)
+    const int resident = usable_cus_per_xcd() * wgs_per_cu;  // workgroups per XCD in one resident round (32 CUs per XCD minus the reserved ones)
     p.blocks_per_xcd = p.per_xcd < resident ? p.per_xcd : resident;
     const dim3 grid((unsigned)(8 * p.blocks_per_xcd)), block(WM * WN * 64);
     const bool drop = p.drop_p > 0.f;

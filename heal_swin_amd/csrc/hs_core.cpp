@@ -1,11 +1,25 @@
 // Status / error plumbing of libhealswin.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include "hs_common.h"
 
 namespace hs {
+namespace {
+std::atomic<int>& reserved_slot() {
+    static std::atomic<int> v{[] {
+        const char* e = getenv("HS_RESERVED_CUS");
+        const int n = e ? atoi(e) : 0;
+        return n < 0 ? 0 : (n > 128 ? 128 : (n / 8) * 8);
+    }()};
+    return v;
+}
+}  // namespace
+int reserved_cus() { return reserved_slot().load(std::memory_order_relaxed); }
+
 char* error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
@@ -32,6 +46,12 @@ const char* hs_status_string(int status) {
         default: return "unknown status";
     }
 }
+int hs_set_reserved_cus(int n) {
+    HS_CHECK_ARG(n >= 0 && n <= 128 && n % 8 == 0, "hs_set_reserved_cus: a multiple of 8 in [0, 128] (one CU per XCD at a time)");
+    hs::reserved_slot().store(n, std::memory_order_relaxed);
+    return HS_OK;
+}
+int hs_get_reserved_cus(void) { return hs::reserved_cus(); }
 int hs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

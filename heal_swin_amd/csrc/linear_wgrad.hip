@@ -60,8 +60,9 @@ inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int 
     g.tiles_n = (n_out + g.tile_n - 1) / g.tile_n;
     g.tiles_k = (k_in + tile_k - 1) / tile_k;
     g.tiles = g.tiles_n * g.tiles_k;
-    // one resident round of equal workgroups over the 256 CUs; at least 512 tokens per slice
-    int64_t want = (256 * wgs_per_cu) / g.tiles;
+    // one resident round of equal workgroups over the CUs this library may plan for (256 minus hs_set_reserved_cus()); at
+    // least 512 tokens per slice
+    int64_t want = ((int64_t)usable_cus() * wgs_per_cu) / g.tiles;
     int64_t max_by_rows = (rows + 511) / 512;
     if (want > max_by_rows) want = max_by_rows;
     if (want > kMaxSlices) want = kMaxSlices;

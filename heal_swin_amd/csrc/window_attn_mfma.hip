@@ -866,7 +866,7 @@ __global__ void reduce_scale_partials_kernel(const float* __restrict__ src, floa
 // run as a second round and double the launch time.
 int persistent_slots(const AttnParams& p, int groups, int waves_per_wg) {
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    const int capacity = 32 * (8 / waves_per_wg);
+    const int capacity = usable_cus_per_xcd() * (8 / waves_per_wg);
     int64_t per_xcd = capacity / groups;
     if (per_xcd < 1) per_xcd = 1;
     int64_t slots = 8 * per_xcd;

@@ -480,7 +480,7 @@ __global__ void reduce_parts_f32_kernel(const float* __restrict__ src, float* __
 
 int f32_slots(const AttnParams& p, int waves_per_cu) {
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    int64_t slots = (256 * waves_per_cu) / p.nH;  // rounded DOWN: a workgroup beyond the resident set would double the run time
+    int64_t slots = ((int64_t)usable_cus() * waves_per_cu) / p.nH;  // rounded DOWN: a workgroup beyond the resident set would double the run time
     if (slots > windows) slots = windows;
     return (int)(slots < 1 ? 1 : slots);
 }

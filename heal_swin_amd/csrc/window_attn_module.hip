@@ -535,7 +535,8 @@ template <int NH>
 int launch_module(const ModParams& p0, bool cosine, hipStream_t stream) {
     ModParams p = p0;
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
-    p.slots = (int)(windows < 256 ? windows : 256);  // one persistent workgroup per CU (144 KB of LDS each)
+    const int cus = usable_cus();
+    p.slots = (int)(windows < cus ? windows : cus);  // one persistent workgroup per CU (144 KB of LDS each)
     if (cosine)
         hipLaunchKernelGGL((attn_module_fwd_kernel<NH, true>), dim3(p.slots), dim3(NH * 64), 0, stream, p);
     else

@@ -28,7 +28,14 @@ import torch.distributed as dist
 
 class GradBucketAllReduce:
     def __init__(self, params, bucket_bytes=64 << 20, process_group=None, async_wgrad=False, direct_wgrad=True,
-                 exchange_single_rank=False):
+                 exchange_single_rank=False, comm_dtype=None, reserved_cus="auto"):
+        """comm_dtype: None / torch.float32 exchanges the fp32 buckets themselves; torch.bfloat16 exchanges a bf16 copy of each
+        bucket (half the bytes on the xGMI links: 298 instead of 596 MB per step for HEAL-SWIN-B) -- the gradients are still
+        ACCUMULATED in the fp32 buckets (kernels' direct deposit, micro-batches under no_sync()); only the wire format and the
+        cross-rank sum are bf16, as with DDP's bf16 compression hook.
+        reserved_cus: compute units the library's chip-filling launches leave free for RCCL's kernels while this exchange is
+        active ("auto": 16 when more than one rank exchanges, else 0; see include/healswin.h:hs_set_reserved_cus and
+        profiles/r03_cu_contention.json)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.async_wgrad = None
@@ -41,6 +48,8 @@ class GradBucketAllReduce:
         self._where = {}        # param -> bucket id
         self._views = {}        # param -> its .grad view into the bucket
         self._build(bucket_bytes)
+        self.comm_dtype = None if comm_dtype in (None, torch.float32) else comm_dtype
+        self._comm = [torch.empty_like(f, dtype=self.comm_dtype) for f in self.buckets] if self.comm_dtype is not None else None
         self._sync = True       # False inside no_sync()
         self._reduced = False   # a bucket has been exchanged since the gradients were last zeroed
         self._stepped = False   # an attached optimizer has stepped since the last exchange
@@ -48,6 +57,13 @@ class GradBucketAllReduce:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._direct = False
         on_gpu = bool(self.params) and self.params[0].is_cuda
+        self._reserved_prev = None
+        if on_gpu:
+            from . import _lib
+            want = (16 if (self._exchange and self.world > 1) else 0) if reserved_cus == "auto" else int(reserved_cus)
+            self._reserved_prev = int(_lib.lib.hs_get_reserved_cus())
+            if want != self._reserved_prev:
+                _lib.check(_lib.lib.hs_set_reserved_cus(want), "hs_set_reserved_cus")
         if (direct_wgrad or async_wgrad) and on_gpu:
             # kernels accumulate Linear / LayerNorm parameter gradients straight into the bucket views of the parameters
             # REGISTERED HERE (ops asks grad_buffer(p) per parameter; other models in the process are unaffected)
@@ -202,11 +218,18 @@ class GradBucketAllReduce:
         flat = self.buckets[b]
         if self.async_wgrad is not None:
             self.async_wgrad.sync()  # gradients deposited from the side stream must have landed before the exchange
-        if self._avg_in_collective:  # RCCL averages inside the all-reduce: no extra pass over the bucket
-            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-        else:
+        buf = flat
+        if self._comm is not None:  # wire format: a bf16 copy of the bucket (copied back into the fp32 bucket in finish())
+            buf = self._comm[b]
+            if self._avg_in_collective:
+                buf.copy_(flat)
+            else:
+                torch.mul(flat, 1.0 / self.world, out=flat)
+                buf.copy_(flat)
+        elif not self._avg_in_collective:
             flat.mul_(1.0 / self.world)  # average, as DDP does (gloo has no AVG op)
-            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM  # RCCL averages inside the all-reduce
+        self._works.append((b, dist.all_reduce(buf, op=op, group=self.group, async_op=True)))
         self._launched[b] = True
         self._reduced = True
 
@@ -223,14 +246,20 @@ class GradBucketAllReduce:
                     raise RuntimeError("a gradient bucket was only partially produced; unused parameters are not supported")
                 # untouched in this pass (parameters without gradient, or gradients accumulated under no_sync() earlier)
                 self._launch(b)
-        for w in self._works:
+        for b, w in self._works:
             w.wait()
+            if self._comm is not None:
+                self.buckets[b].copy_(self._comm[b])
         self._reset_pass()
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._reserved_prev is not None:
+            from . import _lib
+            _lib.lib.hs_set_reserved_cus(self._reserved_prev)
+            self._reserved_prev = None
         if not self._direct and self.async_wgrad is None:
             return
         from . import ops

@@ -48,6 +48,18 @@ const char* hs_status_string(int status);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
 int hs_device_count(void);
 
+/* Compute units that the persistent / one-resident-round launches of this library leave FREE (a multiple of 8 in [0, 128]: the same
+ * number on each of the 8 XCDs; default 0, or the environment variable HS_RESERVED_CUS).  Data-parallel training (the reference's
+ * Lightning DDP, train.py:182-189) runs RCCL's all-reduce kernels on their own stream DURING the backward; a kernel whose grid
+ * is sized to fill every CU for its whole duration either delays them to its end or, if they were resident first, runs its
+ * last workgroups as a second round.  heal_swin_amd.parallel.GradBucketAllReduce sets this when world_size > 1.
+ * Affects hs_linear_wgrad (+ _workspace), hs_gemm_nt, hs_window_attn_* (+ _workspace), hs_window_attn_module_fwd. */
+int hs_set_reserved_cus(int n);
+int hs_get_reserved_cus(void);
+/* Diagnostic: `n_workgroups` workgroups of `threads` threads and `lds_bytes` of LDS each that stay resident for `microseconds`
+ * on `stream` -- a stand-in for a communication library's long-lived ring kernels (tools/cu_contention.py). */
+int hs_debug_occupy_cus(int n_workgroups, int threads, int lds_bytes, double microseconds, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host-side HEALPix index tables, built once per model on the host (plain C++, no GPU needed).
  * ---------------------------------------------------------------------------------------------- */

@@ -187,4 +187,5 @@ def test_bench_self_launches_multi_rank():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
     assert out["rccl"]["rccl_ranks"] == 2 and len(out["rccl"]["allreduce_ms_per_step_standalone_per_rank"]) == 2
-    assert out["roofline"]["bound"] == "mfma" and out["roofline"]["hbm"]["frac"] > 0
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] > 0 and out["roofline"]["mfma"]["frac"] > 0
+    assert len(out["rccl"]["step_ms_per_rank"]) == 2
