@@ -278,6 +278,9 @@ def main():
                     help="(maintenance) run PyTorch TunableOp tuning over this workload's library GEMMs during the warm-up and "
                          "write the results file CSV (copy it to heal_swin_amd/tuning/); the timed numbers of such a run are not a benchmark")
     ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
+    ap.add_argument("--reserved-cus", default="auto",
+                    help="compute units the chip-filling launches leave free for RCCL (multiple of 8; auto: 16 when N > 1, else 0)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient buckets")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -302,6 +305,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
         if rank == 0 and not shared_gpu:
             os.environ.setdefault("NCCL_DEBUG", "VERSION")  # one line with the RCCL version on stderr of rank 0
+        # RCCL's ring kernels are long-lived workgroups that share the chip with the backward.  A kernel that fills all 256 CUs
+        # loses 45-65 % when even 8 of them hold a foreign 128-VGPR workgroup (profiles/r03_cu_contention.json), so the exchange
+        # gets a bounded number of channels and the library leaves that many CUs free (GradBucketAllReduce(reserved_cus=...)).
+        # 596 MB of gradients per 160 ms step need < 10 GB/s: 16 channels are ample.  Both can be overridden from the environment.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         t_init = time.perf_counter()
         if shared_gpu:
             dist.init_process_group(backend="gloo")
@@ -480,7 +488,9 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
     model, cfg, spec = build_model(wl)
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-    dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad)
+    dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad,
+                             reserved_cus=args.reserved_cus if args.reserved_cus == "auto" else int(args.reserved_cus),
+                             comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else None)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=args.graph)  # ref: training/optimizer.py:57-66
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -572,7 +582,8 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
                 "step_ms_per_rank": step_ms_per_rank, "buckets": len(dp.buckets),
                 "allreduce_bytes_per_step": nbytes, "allreduce_ms_per_step_standalone_per_rank": [round(v, 3) for v in ms],
                 "allreduce_bus_GBps": 2 * (world - 1) / world * nbytes / (max(ms) * 1e-3) / 1e9,
-                "exchange": "fp32 flat buckets, async all-reduce launched from gradient hooks during backward"}
+                "reserved_cus": int(__import__("heal_swin_amd")._lib.lib.hs_get_reserved_cus()), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "exchange": f"{args.comm_dtype} wire format of fp32 flat buckets, async all-reduce launched from gradient hooks during backward"}
     res = types.SimpleNamespace(elapsed=elapsed, loss=float(loss.item()), timings=timings if rank == 0 else None, rccl=rccl,
                                 params_m=round(sum(p.numel() for p in model.parameters()) / 1e6, 2))
     dp.remove()

@@ -572,6 +572,14 @@ class UnetDecoder(nn.Module):
         w = self.output.weight  # 1x1 conv without bias (ref :756-761) as the [f_out, C] matrix it is (ops.LinearFn)
         f_out = w.shape[0]
         up = self.up
+        if (isinstance(up.norm, HSLayerNorm) and isinstance(up.expand, HSLinear) and up.expand.bias is None and
+                ops.expand_ln_head_ok(x, up.dim, up.patch_size, f_out)):
+            # the whole tail in one forward kernel (hs_expand_ln_head_fwd): expand -> view -> LayerNorm -> head with fp32 statistics
+            # on the expand product's accumulators; the [B, Npix, C] tensor is written once for the backward, or not at all
+            xn = self.norm_up(x)
+            B, N0, _ = xn.shape
+            lg = ops.expand_ln_head(xn.reshape(B * N0, up.dim), up.expand.weight, up.norm.weight, up.norm.bias, w)
+            return ops.pad_slice(lg.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2)  # B, f_out, Npix (fp32)
         if isinstance(up.norm, HSLayerNorm) and ops.ln_head_ok(x, up.dim, f_out):
             # the tail's LayerNorm and the class head in one pass over the expanded rows (hs_ln_head_*): the normalised
             # [B, Npix, C] tensor is neither written nor kept for the backward

@@ -845,13 +845,7 @@ class LnHeadFn(torch.autograd.Function):
     def forward(ctx, y2, gamma, beta, weight):
         _require_gpu(y2, gamma, beta, weight)
         rows, C = y2.shape
-        f_out = weight.shape[0]
-        w = weight.detach().reshape(f_out, C).float()
-        g32, b32 = gamma.detach().float(), beta.detach().float()
-        wfold = torch.zeros((32, C), dtype=torch.bfloat16, device=y2.device)
-        wfold[:f_out] = (w * g32).to(torch.bfloat16)
-        bvec = torch.zeros(32, dtype=torch.float32, device=y2.device)
-        bvec[:f_out] = w @ b32
+        wfold, bvec = _fold_head(gamma, beta, weight, C, y2.device)
         # fp32 logits: the tail's roundings (norm_up -> expand -> xhat -> logits) dominate the bf16 logit error of the whole
         # model (csrc/ln_head.hip); the logits therefore keep their accumulator value and xhat enters the head as hi + lo
         logits = torch.empty((rows, LnHeadFn.KP), dtype=torch.float32, device=y2.device)
@@ -866,30 +860,102 @@ class LnHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         y2, mean, rstd, gamma, beta, weight = ctx.saved_tensors
-        rows, C = y2.shape
-        f_out, KP = weight.shape[0], LnHeadFn.KP
-        dev = y2.device
-        w = weight.detach().reshape(f_out, C).float()
-        g32, b32 = gamma.detach().float(), beta.detach().float()
-        afold = torch.zeros((C, KP), dtype=torch.bfloat16, device=dev)
-        afold[:, :f_out] = (w * g32).t().to(torch.bfloat16)
-        dlogits = dlogits.to(torch.float32).contiguous()
-        dy = torch.empty_like(y2)
-        dprime = torch.empty((rows, KP), dtype=torch.bfloat16, device=dev)
-        part = torch.empty((int(lib.hs_ln_head_partials(rows)), 32), dtype=torch.float32, device=dev)
-        with _timed("ln_head_bwd", dev, rows * (4 * C + 6 * KP) + 8 * rows, 2 * rows * C * KP):
-            check(lib.hs_ln_head_bwd(ptr(y2), ptr(mean), ptr(rstd), ptr(dlogits), ptr(afold), ptr(dy), ptr(dprime), ptr(part), rows, C,
-                                     _lib.HS_BF16, _lib.HS_F32, stream_ptr(dev)), "hs_ln_head_bwd")
+        dy, dgamma, dbeta, dw = _ln_head_backward(y2, mean, rstd, gamma, beta, weight, dlogits, any(ctx.needs_input_grad[1:]))
+        return (dy if ctx.needs_input_grad[0] else None), dgamma, dbeta, dw
+
+
+def _ln_head_backward(y2, mean, rstd, gamma, beta, weight, dlogits, want_params):
+    """(dy, dgamma, dbeta, dWhead) of logits = head(LayerNorm(y2)) by `hs_ln_head_bwd` + one weight-gradient product (LnHeadFn)."""
+    rows, C = y2.shape
+    f_out, KP = weight.shape[0], LnHeadFn.KP
+    dev = y2.device
+    w = weight.detach().reshape(f_out, C).float()
+    g32, b32 = gamma.detach().float(), beta.detach().float()
+    afold = torch.zeros((C, KP), dtype=torch.bfloat16, device=dev)
+    afold[:, :f_out] = (w * g32).t().to(torch.bfloat16)
+    dlogits = dlogits.to(torch.float32).contiguous()
+    dy = torch.empty_like(y2)
+    dprime = torch.empty((rows, KP), dtype=torch.bfloat16, device=dev)
+    part = torch.empty((int(lib.hs_ln_head_partials(rows)), 32), dtype=torch.float32, device=dev)
+    with _timed("ln_head_bwd", dev, rows * (4 * C + 6 * KP) + 8 * rows, 2 * rows * C * KP):
+        check(lib.hs_ln_head_bwd(ptr(y2), ptr(mean), ptr(rstd), ptr(dlogits), ptr(afold), ptr(dy), ptr(dprime), ptr(part), rows, C,
+                                 _lib.HS_BF16, _lib.HS_F32, stream_ptr(dev)), "hs_ln_head_bwd")
+    dgamma = dbeta = dw = None
+    if want_params:
         ut = part.sum(0)
         u, t = ut[:f_out], ut[KP:KP + f_out]
-        dgamma = dbeta = dw = None
-        if any(ctx.needs_input_grad[1:]):
-            G = LinearFn._wgrad_hip(dprime, y2, KP, C, False)[0][:f_out]
-            X = G - t[:, None]
-            dw = (g32 * X + b32 * u[:, None]).to(weight.dtype).view(weight.shape)
-            dgamma = (w * X).sum(0).to(gamma.dtype)
-            dbeta = (w * u[:, None]).sum(0).to(beta.dtype)
-        return (dy if ctx.needs_input_grad[0] else None), dgamma, dbeta, dw
+        G = LinearFn._wgrad_hip(dprime, y2, KP, C, False)[0][:f_out]
+        X = G - t[:, None]
+        dw = (g32 * X + b32 * u[:, None]).to(weight.dtype).view(weight.shape)
+        dgamma = (w * X).sum(0).to(gamma.dtype)
+        dbeta = (w * u[:, None]).sum(0).to(beta.dtype)
+    return dy, dgamma, dbeta, dw
+
+
+def _fold_head(gamma, beta, weight, C, device):
+    """(wfold [32, C] bf16 = gamma * W rows, bvec [32] f32 = W beta) of the fused LayerNorm + head kernels."""
+    f_out = weight.shape[0]
+    w = weight.detach().reshape(f_out, C).float()
+    wfold = torch.zeros((32, C), dtype=torch.bfloat16, device=device)
+    wfold[:f_out] = (w * gamma.detach().float()).to(torch.bfloat16)
+    bvec = torch.zeros(32, dtype=torch.float32, device=device)
+    bvec[:f_out] = w @ beta.detach().float()
+    return wfold, bvec
+
+
+FUSED_EXPAND_HEAD = os.environ.get("HS_FUSED_EXPAND_HEAD", "1") != "0"
+
+
+def expand_ln_head_ok(x, width, children, n_classes):
+    """Whether `expand_ln_head` (hs_expand_ln_head_fwd) runs the decoder tail: bf16 rows on the GPU, 4 children, C in {64, 96, 128}."""
+    return bool(FUSED_EXPAND_HEAD and FUSED_LN_HEAD and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == width and
+                lib.hs_expand_ln_head_supported(int(width), int(children), int(n_classes), _lib.HS_BF16))
+
+
+class ExpandLnHeadFn(torch.autograd.Function):
+    """FinalPatchExpand_X4 (Linear C -> 4 C, view, LayerNorm(C)) + the 1x1 head as ONE forward kernel (reference
+    swin_hp_transformer.py:442-452, :785-788; csrc/expand_ln_head.hip).  xn2 [tokens, C] bf16 -> padded fp32 logits [4 tokens, 16].
+    With a gradient wanted the kernel also writes the expanded rows once (the backward's LayerNorm input); the backward is
+    `hs_ln_head_bwd` on them followed by the Linear's input / weight gradients.  Without, the [4 tokens, C] tensor never exists."""
+
+    @staticmethod
+    def forward(ctx, xn2, wexp, gamma, beta, weight):
+        _require_gpu(xn2, wexp, gamma, beta, weight)
+        tokens, C = xn2.shape
+        xn2 = xn2.contiguous()
+        P = wexp.shape[0] // C
+        wq = _cast_param(wexp, torch.bfloat16).contiguous()
+        wfold, bvec = _fold_head(gamma, beta, weight, C, xn2.device)
+        need = any(ctx.needs_input_grad)
+        rows = tokens * P
+        logits = torch.empty((rows, LnHeadFn.KP), dtype=torch.float32, device=xn2.device)
+        y = torch.empty((rows, C), dtype=torch.bfloat16, device=xn2.device) if need else None
+        mean = torch.empty(rows, dtype=torch.float32, device=xn2.device) if need else None
+        rstd = torch.empty_like(mean) if need else None
+        # algorithmic traffic: xn in, logits out (+ the expanded rows once in training); flops: expand + head (hi + lo)
+        with _timed("expand_ln_head_fwd", xn2.device, 2 * tokens * C + rows * (4 * LnHeadFn.KP + (2 * C + 8 if need else 0)),
+                    2 * rows * C * C + 4 * rows * C * 32):
+            check(lib.hs_expand_ln_head_fwd(ptr(xn2), ptr(wq), ptr(wfold), ptr(bvec), ptr(y), ptr(logits), ptr(mean), ptr(rstd), tokens, C, P,
+                                            _lib.HS_BF16, stream_ptr(xn2.device)), "hs_expand_ln_head_fwd")
+        ctx.save_for_backward(xn2, y, mean, rstd, gamma, beta, weight, wexp)
+        ctx.w_cast = wq if wq.dtype != wexp.dtype else None
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        xn2, y, mean, rstd, gamma, beta, weight, wexp = ctx.saved_tensors
+        tokens, C = xn2.shape
+        dy, dgamma, dbeta, dw = _ln_head_backward(y, mean, rstd, gamma, beta, weight, dlogits, any(ctx.needs_input_grad[2:]))
+        dy2 = dy.view(tokens, wexp.shape[0])  # 'b (n p) c -> b n (p c)': the children of a token are consecutive rows
+        dxn = _input_grad(dy2, wexp, ctx.w_cast) if ctx.needs_input_grad[0] else None
+        ctx.w_cast = None
+        dwexp, _ = _param_grads(dy2, xn2, wexp, None, ctx.needs_input_grad[1], False)
+        return dxn, dwexp, dgamma, dbeta, dw
+
+
+def expand_ln_head(xn2, wexp, gamma, beta, weight):
+    """Padded fp32 logits [4 tokens, 16] of head(LayerNorm(expand(xn2) viewed per child)); the caller slices [..., :f_out]."""
+    return ExpandLnHeadFn.apply(xn2, wexp, gamma, beta, weight)
 
 
 def ln_head(y2, gamma, beta, weight):

@@ -390,6 +390,17 @@ int hs_ln_head_fwd(const void* y, const void* wfold, const float* bvec, void* lo
 int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const void* dlogits, const void* afold, void* dy,
                    void* dprime, float* partials, int64_t rows, int width, int dtype, int logits_dtype, void* stream);
 
+/* The whole decoder tail forward in one launch: FinalPatchExpand_X4's Linear(C -> 4 C) (models_torch/swin_hp_transformer.py:442-447),
+ * the 'b n (p c) -> b (n p) c' view (:449), its LayerNorm(C) (:450-452) and the 1x1 class head (:785-788).  LayerNorm reads the fp32
+ * accumulators of the expand product, xhat enters the head as hi + lo, the logits leave in fp32: of the tail's four bf16 roundings
+ * only the input's remains (csrc/expand_ln_head.hip).  bf16, 4 children, C in {64, 96, 128} (the expand weight lives in LDS).
+ *   xn [dev] bf16[tokens, C] (the norm_up output); wexp [dev] bf16[4 C, C] as nn.Linear stores it; wfold / bvec as for hs_ln_head_fwd;
+ *   logits [dev] f32[4 tokens, 16]; y [dev] bf16[4 tokens, C] + mean, rstd [dev] f32[4 tokens]: what the backward (hs_ln_head_bwd on y,
+ *   then the Linear's gradients) needs -- all three NULL for a forward without gradient, in which case the expanded tensor never exists. */
+int hs_expand_ln_head_supported(int width, int children, int n_classes, int dtype);
+int hs_expand_ln_head_fwd(const void* xn, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits, float* mean,
+                          float* rstd, int64_t tokens, int width, int children, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * PatchMerging / PatchExpand / FinalPatchExpand_X4 as one operator call per module and direction (SURVEY 8b's proposed
  * hs_patch_merge_* / hs_patch_expand_*).  In nested HEALPix order the reference's data movement is a free view -- the four

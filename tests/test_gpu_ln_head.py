@@ -90,3 +90,47 @@ def test_model_tail_uses_the_fused_kernels_and_matches_the_unfused_path():
     for n in ("decoder.up.norm.weight", "decoder.up.norm.bias", "decoder.output.weight", "decoder.up.expand.weight", "encoder.patch_embed.proj.weight"):
         key = n if n in res[True][1] else [k for k in res[True][1] if k.endswith(n.split(".", 1)[1])][0]
         assert_close(res[True][1][key], res[False][1][key], 0.05, f"fused tail: grad {key} vs unfused")
+
+
+def reference_tail(xn, wexp, gamma, beta, w, dlogits, P=4):
+    """fp32 composition of FinalPatchExpand_X4 (Linear, 'b n (p c) -> b (n p) c', LayerNorm) + head, on bf16-exact inputs."""
+    xn = xn.float().detach().requires_grad_(True)
+    wexp, gamma, beta, w = (t.detach().clone().requires_grad_(True) for t in (wexp, gamma, beta, w))
+    C = xn.shape[-1]
+    yv = F.linear(xn, wexp).reshape(-1, C)
+    out = F.linear(F.layer_norm(yv, (C,), gamma, beta, 1e-5), w)
+    out.backward(dlogits.float())
+    return out, xn.grad, wexp.grad, gamma.grad, beta.grad, w.grad
+
+
+@pytest.mark.parametrize("tokens,C,f_out", [(4096, 128, 12), (1000, 96, 12), (33, 64, 5), (70000, 128, 1)])
+def test_expand_ln_head_matches_the_composition(tokens, C, f_out):
+    """`hs_expand_ln_head_fwd` (expand Linear -> view -> LayerNorm -> head in one kernel) + its backward against the fp32 composition
+    of the reference modules.  The forward keeps fp32 between the expand product and the logits, so the logits are held to 2e-3
+    (weights are bf16-exact on both sides; without a gradient the expanded tensor is never written and the logits are identical)."""
+    from heal_swin_amd import ops
+
+    torch.manual_seed(tokens + C)
+    dev = "cuda"
+    xn = (torch.randn(tokens, C, device=dev) * 1.3 + 0.2).to(torch.bfloat16)
+    wexp = (torch.randn(4 * C, C, device=dev) * C ** -0.5).to(torch.bfloat16).float().requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, device=dev)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, device=dev)).requires_grad_(True)
+    w = (torch.randn(f_out, C, 1, device=dev) * C ** -0.5).requires_grad_(True)
+    dlog = torch.randn(4 * tokens, f_out, device=dev).to(torch.bfloat16).float()
+    assert ops.expand_ln_head_ok(xn, C, 4, f_out)
+    xq = xn.clone().requires_grad_(True)
+    out = ops.expand_ln_head(xq, wexp, gamma, beta, w)
+    assert out.dtype == torch.float32 and out.shape == (4 * tokens, 16) and not out[:, f_out:].any()
+    out[:, :f_out].backward(dlog)
+    ref_out, ref_dx, ref_dwe, ref_dg, ref_db, ref_dw = reference_tail(xn, wexp, gamma, beta, w.reshape(f_out, C), dlog)
+    tag = f"expand_ln_head[{tokens}x{C}->{f_out}]"
+    assert_close(out[:, :f_out], ref_out, 2e-3, tag + " logits")
+    assert_close(xq.grad, ref_dx, GRAD_TOL[torch.bfloat16], tag + " dxn")
+    assert_close(wexp.grad, ref_dwe, GRAD_TOL[torch.bfloat16], tag + " dWexpand")
+    assert_close(gamma.grad, ref_dg, GRAD_TOL[torch.bfloat16], tag + " dgamma")
+    assert_close(beta.grad, ref_db, GRAD_TOL[torch.bfloat16], tag + " dbeta")
+    assert_close(w.grad.reshape(f_out, C), ref_dw, GRAD_TOL[torch.bfloat16], tag + " dWhead")
+    with torch.no_grad():  # nothing saved, nothing written but the logits
+        out2 = ops.expand_ln_head(xn, wexp, gamma, beta, w)
+    assert torch.equal(out2, out.detach())
