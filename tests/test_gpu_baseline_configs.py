@@ -101,6 +101,7 @@ def test_baseline_architecture_fwd_bwd_vs_oracle(name, dtype):
     params = dict(model.named_parameters())
     worst = ("", 0.0)
     rms = []
+    ls_pairs = []  # (name, bf16 d logit_scale, oracle d logit_scale) of every cosine-attention module
     for k, g in ref_grads.items():
         got = params[k].grad
         got = torch.zeros_like(params[k]) if got is None else got
@@ -118,11 +119,23 @@ def test_baseline_architecture_fwd_bwd_vs_oracle(name, dtype):
             tol = 0.15
         if k.endswith("logit_scale") and dtype == torch.bfloat16:
             # one scalar per head = sum over every (window, query, key) of dS * S_raw with terms of both signs: results of
-            # 1e-7 .. 1e-5 from terms of 1e-2, i.e. pure rounding noise in bf16 (observed relative errors 0.08 .. 0.6).
-            # Checked in fp32 (4.6e-5 here); in bf16 only that it stays at the noise level of the reference's own scale
+            # 1e-7 .. 1e-5 from terms of 1e-2.  The kernel accumulates it in fp32 from fp32 scores (D = rowsum(P o dP) from the
+            # same registers since round 3, so sum_k dS = 0 holds to fp32 rounding); what remains is the bf16 rounding of the
+            # ACTIVATIONS feeding it.  Checked per tensor against the noise level of the reference's own scale, and over all
+            # heads of the model as a direction (cosine similarity, below)
             assert float((got.float().cpu() - g).abs().max()) <= 1e-5, (k, float((got.float().cpu() - g).abs().max()))
+            ls_pairs.append((k, got.float().cpu().reshape(-1), g.reshape(-1)))
             continue
         assert_close(got, g, tol, f"{tag} grad {k}", floor=floor + (1e-7 if dtype == torch.bfloat16 else 1e-9))
+    if ls_pairs:
+        a = torch.cat([p_[1] for p_ in ls_pairs]).double()
+        b = torch.cat([p_[2] for p_ in ls_pairs]).double()
+        cos = float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-300))
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-300))
+        worst_ls = max(ls_pairs, key=lambda t: float((t[1] - t[2]).abs().max() / t[2].abs().max().clamp_min(1e-30)))
+        conftest.NOTES.append(f"{tag}: d logit_scale over {a.numel()} heads: cosine {cos:.4f}, ||a-b||/||b|| {rel:.3f}; worst tensor "
+                              f"{worst_ls[0]} max|a-b|/max|b| {float((worst_ls[1] - worst_ls[2]).abs().max() / worst_ls[2].abs().max()):.2f}")
+        assert cos >= 0.9, (cos, rel)  # a sign / scale error in the dscale or normalisation-Jacobian path would give ~0 or < 0
     edx = errors(xg.grad, ref_dx)
     assert_close(xg.grad, ref_dx, GRAD_TOL[dtype], tag + " dx")
     conftest.NOTES.append(f"{tag}: {len(ref_grads)} parameter gradients, worst max|a-b|/max|b| {worst[1]:.2e} ({worst[0]}), "
