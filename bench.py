@@ -335,10 +335,24 @@ def main():
         torch.cuda.tunable.set_max_tuning_iterations(int(os.environ.get("HS_TUNE_ITERS", "200")))
         torch.cuda.tunable.set_rotating_buffer_size(int(os.environ.get("HS_TUNE_ROTATE_MB", "512")))
     elif os.path.exists(tuned) and not args.no_tuned_gemm:
+        # one results file per process: the headline workload's picks plus those of the companions this run will execute (the
+        # fp32 re-run of the same workload, the fp32 depth-head config), merged into a scratch file
+        extra = [os.path.join(os.path.dirname(tuned), f"tunableop_gfx950_{args.workload}_bs{args.batch}_fp32.csv"),
+                 os.path.join(os.path.dirname(tuned), "tunableop_gfx950_D256_bs2_fp32.csv")]
+        merged = tuned
+        have = [f for f in extra if os.path.exists(f) and f != tuned]
+        if have and args.dtype == "bf16":
+            import tempfile
+            lines = open(tuned).read().splitlines()
+            for f in have:
+                lines += [ln for ln in open(f).read().splitlines() if ln and not ln.startswith("Validator")]
+            fd, merged = tempfile.mkstemp(prefix=f"tunableop_merged_r{rank}_", suffix=".csv")
+            with os.fdopen(fd, "w") as fh:
+                fh.write("\n".join(lines) + "\n")
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
-        torch.cuda.tunable.set_filename(tuned, insert_device_ordinal=False)
-        torch.cuda.tunable.read_file(tuned)
+        torch.cuda.tunable.set_filename(merged, insert_device_ordinal=False)
+        torch.cuda.tunable.read_file(merged)
 
     wl = WORKLOADS[args.workload]
     if args.paper_drop_rates:
@@ -382,7 +396,8 @@ def main():
         r32 = run_workload(ctx, "fp32", k, 1, timing=False)
         out["fp32"] = {"value": args.batch * k / r32.elapsed, "unit": "images/s", "ms_per_step": 1e3 * r32.elapsed / k, "steps": k,
                        "warmup": 1, "batch_per_gpu": args.batch, "workload": wl["name"], "final_loss": r32.loss,
-                       "note": "fp32 activations and MFMA-f32 kernels; library GEMMs with the default heuristic"}
+                       "note": "fp32 activations and MFMA-f32 kernels; fp32 library GEMMs with " + (
+                           "TunableOp picks" if os.path.exists(tuned.replace("_bf16.csv", "_fp32.csv")) and not args.no_tuned_gemm else "the default heuristic")}
     # BASELINE configs[4] at its stated size next to it: HEAL-SWIN-T, nside 256, 8 base pixels, depth head (f_out = 1), fp32, masked
     # L1 loss; batch 2 per GPU as in the reference's run configs (run_configs/*/..._train_run_config.py: batch_size 2)
     if world == 1 and args.dtype == "bf16" and args.workload == "B256" and not args.no_fp32_companion and not args.graph and not args.tune_gemm:

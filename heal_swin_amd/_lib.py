@@ -42,7 +42,7 @@ _SIGNATURES = {
     "hs_pix2ang_nest": [c_int, c_i64, c_i64, c_ptr, c_ptr],
     "hs_ln_head_supported": [c_int, c_int, c_int],
     "hs_expand_ln_head_supported": [c_int, c_int, c_int, c_int],
-    "hs_expand_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
+    "hs_expand_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_ln_head_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_sample_bilinear_u8": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],

@@ -7,7 +7,8 @@
 // Why fused: (1) parity -- the four bf16 roundings of the tail (norm_up output, expand output, xhat, logits) are not averaged by
 // anything downstream and make up 6.4e-3 of the 7.7e-3 logit error of HEAL-SWIN-B, the whole rest of the network 2.9e-3
 // (tests/experiments/bf16_error_budget.py); here LayerNorm sees the fp32 accumulators of the expand product, xhat enters the
-// head as hi + lo and the logits leave in fp32, so only the norm_up rounding remains; (2) traffic -- the [B, 4 N0, C] tensor
+// head as hi + lo and the logits leave in fp32; with xn_lo (the rounding remainder of the norm_up output) not even that of
+// the input remains; (2) traffic -- the [B, 4 N0, C] tensor
 // (1.6 GB at nside 256, batch 8) is written at most once (training: the backward's LayerNorm input) and never read by the
 // forward; without a gradient it does not exist at all.
 //
@@ -38,7 +39,8 @@ __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 template <int NB>
-__global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ wexp,
+__global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ xn_lo,
+                                                                    const uint16_t* __restrict__ wexp,
                                                                     const uint16_t* __restrict__ wfold, const float* __restrict__ bvec,
                                                                     uint16_t* __restrict__ y, float* __restrict__ logits,
                                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -98,6 +100,18 @@ __global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16
                 for (int ct = 0; ct < NB; ++ct) {
                     const bf16x8 a = *(const bf16x8*)(wrow + ct * 32 * kRowB + co);
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[ks], acc[ct], 0, 0, 0);
+                }
+            }
+            if (xn_lo) {  // the rounding remainder of the norm_up output as a second operand (re-fetched per child: L1 / L2 hits)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const uint4 v = live ? *(const uint4*)(xn_lo + tok * C + 16 * ks + 8 * half) : make_uint4(0, 0, 0, 0);
+                    const int co = ((2 * ks + half) ^ sx) << 4;
+#pragma unroll
+                    for (int ct = 0; ct < NB; ++ct) {
+                        const bf16x8 a = *(const bf16x8*)(wrow + ct * 32 * kRowB + co);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, v), acc[ct], 0, 0, 0);
+                    }
                 }
             }
             // ------------------------------------------------------------ the expanded rows, once, for the backward (training)
@@ -193,8 +207,8 @@ int hs_expand_ln_head_supported(int width, int children, int n_classes, int dtyp
     return dtype == HS_BF16 && children == hs::kP && width % 32 == 0 && width >= 64 && width <= 128 && n_classes >= 1 && n_classes <= 16;
 }
 
-int hs_expand_ln_head_fwd(const void* xn, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits, float* mean,
-                          float* rstd, int64_t tokens, int width, int children, int dtype, void* stream) {
+int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits,
+                          float* mean, float* rstd, int64_t tokens, int width, int children, int dtype, void* stream) {
     using namespace hs;
     HS_CHECK_ARG(xn && wexp && wfold && bvec && logits, "hs_expand_ln_head_fwd: null pointer");
     HS_CHECK_ARG(tokens > 0, "hs_expand_ln_head_fwd: bad shape");
@@ -218,7 +232,7 @@ int hs_expand_ln_head_fwd(const void* xn, const void* wexp, const void* wfold, c
             HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));           \
             configured = true;                                                                                                      \
         }                                                                                                                           \
-        hipLaunchKernelGGL(kern, grid, block, smem, s, (const uint16_t*)xn, (const uint16_t*)wexp, (const uint16_t*)wfold, bvec,   \
+        hipLaunchKernelGGL(kern, grid, block, smem, s, (const uint16_t*)xn, (const uint16_t*)xn_lo, (const uint16_t*)wexp, (const uint16_t*)wfold, bvec, \
                            (uint16_t*)y, logits, mean, rstd, tokens);                                                              \
     } break;
     switch (nb) {

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                     if (!add_in) o[k] *= rs;  // v2: DropPath scales the normalised branch
                     if (residual) o[k] += r[k];
                 }
-                if (residual && lo_out && !add_in) {  // v2: y = hi, remainder to lo_out
+                if (lo_out && !add_in) {  // v2 stream (y = residual + LN) or a plain LN whose consumer wants hi + lo: y = hi, remainder to lo_out
                     float ol[VEC];
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
@@ -529,7 +529,7 @@ int hs_layernorm_fwd_ex(const void* x, const void* residual, const void* add_in,
                         void* y, void* sum_out, void* lo_out, float* mean, float* rstd, const float* row_scale, int64_t rows_per_sample,
                         float drop_p, uint64_t seed, int64_t rows, int width, int dtype, void* stream) {
     HS_CHECK_ARG(!(residual && add_in), "hs_layernorm_fwd_ex: residual and add_in are exclusive");
-    HS_CHECK_ARG(!(lo_in || lo_out) || residual || add_in, "hs_layernorm_fwd_ex: lo_in / lo_out need a stream operand (residual or add_in)");
+    HS_CHECK_ARG(!lo_in || residual || add_in, "hs_layernorm_fwd_ex: lo_in needs a stream operand (residual or add_in)");
     hs::LnExtra ex = make_extra(row_scale, rows_per_sample, drop_p, seed);
     ex.lo_in = lo_in;
     ex.lo_out = lo_out;

@@ -401,7 +401,9 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
 // the then-free V/dO tiles), wave 0 its dK half to wave 1 (into the P/dS' scratch).
 template <int HG, bool DROP, bool COS>
 __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
-                                                                     float* __restrict__ dscale_part, int slots, int groups) {
+                                                                     float* __restrict__ dscale_part, int slots, int groups, int abl) {
+    // abl: timing-only ablation mask of tools/attn_bwd_ablation.py (HS_ATTN_BWD_ABLATE; 0 in every product run): 1 no global
+    // stores, 2 no softmax / dS arithmetic, 4 no partial-sum exchange, 8 no X / dK / dV products, 16 no global loads after the first
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayoutBwd L(HG);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -456,6 +458,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     int64_t tok_next[2];
     float lse_next = 0.f;
     auto issue_loads = [&](int64_t wi_l) {
+        if ((abl & 16) && wi_l != bx) return;
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));  // (keeps the address arithmetic out of long-lived registers, see below)
         const int srow_l = tid_l / (4 * HG), sc_l = tid_l % (4 * HG);
@@ -593,7 +596,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 
         __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
         // ------------------------------------------------------------ P, dS' (fp32); bias / scale gradients
-        {
+        if (!(abl & 2)) {
             const bool has_bias = p.bias != nullptr;
             const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
             const float fqn = hscale * qinv;  // d s / d (q . k^)
@@ -668,7 +671,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         // Order chosen for register pressure: X first (its A operand is the dS' registers), then dS' -> scratch -> dK^,
         // then P -> scratch -> dV; each accumulator set dies before the next one is born.
         // ------------------------------------------------------------ X = dS' K^ for this wave's 32 query rows
-        {
+        if (!(abl & 8)) {
             f32x16 dq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -703,6 +706,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             dk[0][r] = 0.f;
             dk[1][r] = 0.f;
         }
+        if (!(abl & 8))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {  // 16 of this wave's queries per step: half 0 -> +0..7, half 1 -> +8..15
             const int qrow = qt * 32 + ks * 16 + 8 * half;
@@ -726,6 +730,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             dv[0][r] = 0.f;
             dv[1][r] = 0.f;
         }
+        if (!(abl & 8))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int qrow = qt * 32 + ks * 16 + 8 * half;
@@ -743,7 +748,8 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         if (PREFETCH && wi + slots < total_windows) issue_loads(wi + slots);  // in flight during the exchange and the stores
         float4* xch_v = (float4*)v_tile;  // 8 KB = V + dO tiles: wave 1 -> wave 0, [kt][r / 4][lane] x 4 floats (b128 accesses)
         float4* xch_k = (float4*)scr;     // 8 KB of the scratch:  wave 0 -> wave 1
-        if (qt == 1) {
+        if (abl & 4) {
+        } else if (qt == 1) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -757,7 +763,8 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                     xch_k[(kt * 4 + rg) * 64 + lane] = make_float4(dk[kt][4 * rg], dk[kt][4 * rg + 1], dk[kt][4 * rg + 2], dk[kt][4 * rg + 3]);
         }
         lds_barrier();
-        if (qt == 0) {
+        if (abl & 4) {
+        } else if (qt == 0) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -819,9 +826,11 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 xk = make_uint4(c2[0], c2[1], c2[2], c2[3]);
             }
             uint16_t* dst = dqkv + tok[rb] * 3 * C + col0;
-            *(uint4*)dst = xq;
-            *(uint4*)(dst + C) = xk;
-            *(uint4*)(dst + 2 * (int64_t)C) = xv;
+            if (!(abl & 1)) {
+                *(uint4*)dst = xq;
+                *(uint4*)(dst + C) = xk;
+                *(uint4*)(dst + 2 * (int64_t)C) = xv;
+            }
         }
         lds_barrier();
     }
@@ -902,7 +911,8 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     float* dbias_part = p.dbias ? workspace : nullptr;
     float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
     const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part, slots, groups);
+    static const int abl = getenv("HS_ATTN_BWD_ABLATE") ? atoi(getenv("HS_ATTN_BWD_ABLATE")) : 0;  // timing experiments only
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part, slots, groups, abl);
     HS_LAUNCH_CHECK("attn_bwd_mfma");
     if (dbias_part) {
         const int64_t n = (int64_t)p.nH * kWs * kWs;

@@ -576,9 +576,13 @@ class UnetDecoder(nn.Module):
                 ops.expand_ln_head_ok(x, up.dim, up.patch_size, f_out)):
             # the whole tail in one forward kernel (hs_expand_ln_head_fwd): expand -> view -> LayerNorm -> head with fp32 statistics
             # on the expand product's accumulators; the [B, Npix, C] tensor is written once for the backward, or not at all
-            xn = self.norm_up(x)
+            xn_lo = None
+            if isinstance(self.norm_up, HSLayerNorm):  # norm_up output as hi + lo: no rounding between norm_up and the logits
+                xn, xn_lo = ops.layer_norm_hilo(x, self.norm_up.weight, self.norm_up.bias)
+            else:
+                xn = self.norm_up(x)
             B, N0, _ = xn.shape
-            lg = ops.expand_ln_head(xn.reshape(B * N0, up.dim), up.expand.weight, up.norm.weight, up.norm.bias, w)
+            lg = ops.expand_ln_head(xn.reshape(B * N0, up.dim), up.expand.weight, up.norm.weight, up.norm.bias, w, xn_lo)
             return ops.pad_slice(lg.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2)  # B, f_out, Npix (fp32)
         if isinstance(up.norm, HSLayerNorm) and ops.ln_head_ok(x, up.dim, f_out):
             # the tail's LayerNorm and the class head in one pass over the expanded rows (hs_ln_head_*): the normalised

@@ -280,7 +280,7 @@ class LayerNormFn(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
         y_lo = None
         if want_lo or res_lo is not None:
-            assert res is not None and not passthrough
+            assert not passthrough and (res is not None or res_lo is None)
             y_lo = torch.empty_like(x) if want_lo else None
             rs, rps, p, seed = extras if extras is not None else (None, 1, 0.0, 0)
             check(lib.hs_layernorm_fwd_ex(ptr(x), ptr(res), None, ptr(None if res_lo is None else res_lo.contiguous()), ptr(g), ptr(b),
@@ -333,6 +333,12 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, weight, bias, residual=None, row_scale=None, drop_p=0.0, seed=None):
     return LayerNormFn.apply(x, weight, bias, residual, _extras(x, row_scale, drop_p, seed))
+
+
+def layer_norm_hilo(x, weight, bias):
+    """(y, y_lo): LayerNorm(x) as the plain activation tensor y plus its rounding remainder y_lo (not differentiable), for a
+    consumer that takes its operand as hi + lo (the fused decoder tail, `expand_ln_head`)."""
+    return LayerNormFn.apply(x, weight, bias, None, None, False, None, True)
 
 
 def layer_norm_stream(x, weight, bias, residual, res_lo=None, row_scale=None, drop_p=0.0, seed=None):
@@ -919,10 +925,11 @@ class ExpandLnHeadFn(torch.autograd.Function):
     `hs_ln_head_bwd` on them followed by the Linear's input / weight gradients.  Without, the [4 tokens, C] tensor never exists."""
 
     @staticmethod
-    def forward(ctx, xn2, wexp, gamma, beta, weight):
-        _require_gpu(xn2, wexp, gamma, beta, weight)
+    def forward(ctx, xn2, wexp, gamma, beta, weight, xn_lo=None):
+        _require_gpu(xn2, wexp, gamma, beta, weight, xn_lo)
         tokens, C = xn2.shape
         xn2 = xn2.contiguous()
+        xn_lo = None if xn_lo is None else xn_lo.reshape(tokens, C).contiguous()
         P = wexp.shape[0] // C
         wq = _cast_param(wexp, torch.bfloat16).contiguous()
         wfold, bvec = _fold_head(gamma, beta, weight, C, xn2.device)
@@ -935,8 +942,8 @@ class ExpandLnHeadFn(torch.autograd.Function):
         # algorithmic traffic: xn in, logits out (+ the expanded rows once in training); flops: expand + head (hi + lo)
         with _timed("expand_ln_head_fwd", xn2.device, 2 * tokens * C + rows * (4 * LnHeadFn.KP + (2 * C + 8 if need else 0)),
                     2 * rows * C * C + 4 * rows * C * 32):
-            check(lib.hs_expand_ln_head_fwd(ptr(xn2), ptr(wq), ptr(wfold), ptr(bvec), ptr(y), ptr(logits), ptr(mean), ptr(rstd), tokens, C, P,
-                                            _lib.HS_BF16, stream_ptr(xn2.device)), "hs_expand_ln_head_fwd")
+            check(lib.hs_expand_ln_head_fwd(ptr(xn2), ptr(xn_lo), ptr(wq), ptr(wfold), ptr(bvec), ptr(y), ptr(logits), ptr(mean), ptr(rstd),
+                                            tokens, C, P, _lib.HS_BF16, stream_ptr(xn2.device)), "hs_expand_ln_head_fwd")
         ctx.save_for_backward(xn2, y, mean, rstd, gamma, beta, weight, wexp)
         ctx.w_cast = wq if wq.dtype != wexp.dtype else None
         return logits
@@ -950,12 +957,13 @@ class ExpandLnHeadFn(torch.autograd.Function):
         dxn = _input_grad(dy2, wexp, ctx.w_cast) if ctx.needs_input_grad[0] else None
         ctx.w_cast = None
         dwexp, _ = _param_grads(dy2, xn2, wexp, None, ctx.needs_input_grad[1], False)
-        return dxn, dwexp, dgamma, dbeta, dw
+        return dxn, dwexp, dgamma, dbeta, dw, None
 
 
-def expand_ln_head(xn2, wexp, gamma, beta, weight):
-    """Padded fp32 logits [4 tokens, 16] of head(LayerNorm(expand(xn2) viewed per child)); the caller slices [..., :f_out]."""
-    return ExpandLnHeadFn.apply(xn2, wexp, gamma, beta, weight)
+def expand_ln_head(xn2, wexp, gamma, beta, weight, xn_lo=None):
+    """Padded fp32 logits [4 tokens, 16] of head(LayerNorm(expand(xn2 [+ xn_lo]) viewed per child)); the caller slices [..., :f_out].
+    xn_lo: the rounding remainder of xn2 (`layer_norm_hilo`), used by the forward product only (the gradients take xn2)."""
+    return ExpandLnHeadFn.apply(xn2, wexp, gamma, beta, weight, xn_lo)
 
 
 def ln_head(y2, gamma, beta, weight):

@@ -26,6 +26,12 @@ import torch
 import torch.distributed as dist
 
 
+def _graph_task_id():
+    """Id of the autograd graph task (one per backward() call) this thread is executing, -1 outside one, None if unavailable."""
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return fn() if fn is not None else None
+
+
 class GradBucketAllReduce:
     def __init__(self, params, bucket_bytes=64 << 20, process_group=None, async_wgrad=False, direct_wgrad=True,
                  exchange_single_rank=False, comm_dtype=None, reserved_cus="auto"):
@@ -110,6 +116,7 @@ class GradBucketAllReduce:
         self._seen = set()                   # parameters already counted in this pass
         self._works = []
         self._pass_open = False
+        self._pass_task = None               # autograd graph-task id of the backward() that opened this pass
 
     # ------------------------------------------------------------------ step protocol
     def zero_grad(self):
@@ -184,6 +191,16 @@ class GradBucketAllReduce:
             self._reduced = False  # the attached optimizer stepped: the caller zeroed in place (as with DDP, not verified)
         self._stepped = False
         self._pass_open = True
+        self._pass_task = _graph_task_id()
+
+    def _check_same_backward(self):
+        """A gradient event of ANOTHER backward() while the previous pass is still open means finish() was skipped: its
+        in-flight buckets were never waited for, and the direct-deposit kernels would add this pass's gradients on top of
+        the last one's while autograd-managed parameters start afresh."""
+        t = _graph_task_id()
+        if self._pass_open and t is not None and self._pass_task is not None and t >= 0 and self._pass_task >= 0 and t != self._pass_task:
+            raise RuntimeError("GradBucketAllReduce: a new backward() started before finish() closed the previous pass; call "
+                               "dp.finish() after every backward() (inside dp.no_sync() for all micro-batches but the last)")
 
     # ------------------------------------------------------------------ gradient events
     def grad_buffer(self, p):
@@ -192,6 +209,8 @@ class GradBucketAllReduce:
             return None
         if not self._pass_open:
             self._begin_pass()
+        else:
+            self._check_same_backward()
         view = self._views[p]
         if p.grad is not view and self._detached(p):
             p.grad = view  # only reachable if the caller dropped .grad in the middle of a pass
@@ -206,6 +225,8 @@ class GradBucketAllReduce:
         # and PyTorch may ALSO run its post-accumulate hook (it does, with an undefined gradient)
         if not self._pass_open:
             self._begin_pass()
+        else:
+            self._check_same_backward()
         if p in self._seen:
             return
         self._seen.add(p)

@@ -231,8 +231,9 @@ int hs_add_layernorm_drop_fwd(const void* a, const void* b, const float* gamma, 
  * block, swin_hp_transformer.py:316 / :338 (v1) and :334-335 (v2), whose results it keeps to 16 instead of 8 mantissa bits in bf16):
  * exactly one of `residual` (v2: y = residual + rs LN(drop(x))) and `add_in` (v1: sum_out = x + rs drop(add_in), y = LN(sum_out)).
  * lo_in (optional) is the rounding remainder of the stream operand (x for v1, residual for v2) left by the previous call, lo_out
- * (optional) receives the remainder of the new stream (sum_out for v1, y for v2): stream = hi + lo with hi the plain activation
- * tensor every other kernel reads.  Backward: the plain hs_*layernorm*_bwd entry points on the hi tensors. */
+ * (optional) receives the remainder of the new stream (sum_out for v1, y for v2; for a plain LayerNorm -- neither residual nor add_in
+ * -- the rounding remainder of y, for a consumer that takes its operand as hi + lo: hs_expand_ln_head_fwd): stream = hi + lo with hi
+ * the plain activation tensor every other kernel reads.  Backward: the plain hs_*layernorm*_bwd entry points on the hi tensors. */
 int hs_layernorm_fwd_ex(const void* x, const void* residual, const void* add_in, const void* lo_in, const float* gamma,
                         const float* beta, void* y, void* sum_out, void* lo_out, float* mean, float* rstd,
                         const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed, int64_t rows, int width,
@@ -394,12 +395,14 @@ int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const vo
  * the 'b n (p c) -> b (n p) c' view (:449), its LayerNorm(C) (:450-452) and the 1x1 class head (:785-788).  LayerNorm reads the fp32
  * accumulators of the expand product, xhat enters the head as hi + lo, the logits leave in fp32: of the tail's four bf16 roundings
  * only the input's remains (csrc/expand_ln_head.hip).  bf16, 4 children, C in {64, 96, 128} (the expand weight lives in LDS).
- *   xn [dev] bf16[tokens, C] (the norm_up output); wexp [dev] bf16[4 C, C] as nn.Linear stores it; wfold / bvec as for hs_ln_head_fwd;
+ *   xn [dev] bf16[tokens, C] (the norm_up output), xn_lo [dev] bf16[tokens, C] or NULL: its rounding remainder (hs_layernorm_fwd_ex lo_out) --
+ *   with it the expand product takes its input as hi + lo and the tail has NO bf16 rounding between norm_up and the logits;
+ *   wexp [dev] bf16[4 C, C] as nn.Linear stores it; wfold / bvec as for hs_ln_head_fwd;
  *   logits [dev] f32[4 tokens, 16]; y [dev] bf16[4 tokens, C] + mean, rstd [dev] f32[4 tokens]: what the backward (hs_ln_head_bwd on y,
  *   then the Linear's gradients) needs -- all three NULL for a forward without gradient, in which case the expanded tensor never exists. */
 int hs_expand_ln_head_supported(int width, int children, int n_classes, int dtype);
-int hs_expand_ln_head_fwd(const void* xn, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits, float* mean,
-                          float* rstd, int64_t tokens, int width, int children, int dtype, void* stream);
+int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits,
+                          float* mean, float* rstd, int64_t tokens, int width, int children, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PatchMerging / PatchExpand / FinalPatchExpand_X4 as one operator call per module and direction (SURVEY 8b's proposed

@@ -250,8 +250,10 @@ def test_direct_and_async_wgrad_match_autograd_path():
     # accumulation semantics: two backwards without zeroing double the gradient
     dp = GradBucketAllReduce(model.parameters())
     dp.zero_grad()
-    for _ in range(2):
+    with dp.no_sync():  # every backward() is closed by finish(); all micro-batches but the last under no_sync()
         model(x).float().square().mean().backward()
+        dp.finish()
+    model(x).float().square().mean().backward()
     dp.finish()
     torch.cuda.synchronize()
     w = dict(model.named_parameters())["layers.0.blocks.0.mlp.fc1.weight"]

@@ -95,6 +95,21 @@ def test_single_process_is_a_noop_wrapper():
     assert torch.equal(flat, dp.buckets[0])  # .grad tensors are views into the flat bucket
 
 
+def test_skipped_finish_is_reported():
+    """Two backward() calls without finish() in between (easy to do on one GPU, where nothing is exchanged) used to let the
+    direct-deposit gradients pile up silently; the second backward now raises."""
+    sys.path.insert(0, ROOT)
+    from heal_swin_amd.parallel import GradBucketAllReduce
+
+    model = _model()
+    dp = GradBucketAllReduce(model.parameters())
+    dp.zero_grad()
+    model(torch.randn(4, 12)).sum().backward()
+    with pytest.raises(RuntimeError, match="finish"):
+        model(torch.randn(4, 12)).sum().backward()
+    dp.remove()
+
+
 def _accum_worker(rank, world, port, mode, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -47,7 +47,7 @@ def main():
     for cfg in range(len(fs) // 12):
         stage, shifted = cfg // 2, cfg % 2
         E = B * (N0 // 4 ** stage) * (C0 * 2 ** stage) * 2  # bytes of one [B, N, C] bf16 tensor
-        for kern, mult in (("hs_window_attn_fwd", 4), ("hs_window_attn_bwd", 8)):
+        for kern, mult in (("hs_window_attn_fwd", 4), ("hs_window_attn_bwd", 7)):  # bwd: q, k, v, dO in, dq, dk, dv out (no O read since round 3)
             f = [v for k, v, _ in fs[cfg * 12:(cfg + 1) * 12] if k == kern]
             w = [v for k, v, _ in ws[cfg * 12:(cfg + 1) * 12] if k == kern]
             t = [dur[d] for k, _, d in fs[cfg * 12:(cfg + 1) * 12] if k == kern and d in dur]
