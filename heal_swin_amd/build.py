@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libhealswin.so")
 
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+CXXFLAGS += os.environ.get("HS_EXTRA_CXXFLAGS", "").split()  # e.g. -DHS_ATTN_ABLATION for tools/attn_bwd_ablation.py
 
 
 def _hipcc():

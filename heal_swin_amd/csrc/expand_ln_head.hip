@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16
     }
     // folded head weight (gamma * Whead) as A operands: accumulator register 8 j + i of channel tile ct is channel
     // 32 ct + 16 j + 8 (i >> 2) + 4 half + (i & 3): two 8-byte pieces per fragment
-    bf16x8 wfa[NB][2];
+    // wfold holds 64 rows: 0..31 the bf16 rounding of gamma * Whead, 32..63 its rounding remainder (hi + lo = the fp32 product
+    // to 16 bits: the head weights are the last rounding between norm_up and the logits)
+    bf16x8 wfa[NB][2], wfl[NB][2];
 #pragma unroll
     for (int ct = 0; ct < NB; ++ct)
 #pragma unroll
@@ -66,6 +68,8 @@ __global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16
             const uint16_t* src = wfold + l31 * C + 32 * ct + 16 * j + 4 * half;
             const uint2 a = *(const uint2*)src, b = *(const uint2*)(src + 8);
             wfa[ct][j] = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+            const uint2 al = *(const uint2*)(src + 32 * C), bl = *(const uint2*)(src + 32 * C + 8);
+            wfl[ct][j] = __builtin_bit_cast(bf16x8, make_uint4(al.x, al.y, bl.x, bl.y));
         }
     float bk[8];
 #pragma unroll
@@ -184,6 +188,7 @@ __global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16
                     }
                     lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfa[ct][j], __builtin_bit_cast(bf16x8, hb), lg, 0, 0, 0);
                     lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfa[ct][j], __builtin_bit_cast(bf16x8, pack8f(lo)), lg, 0, 0, 0);
+                    lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfl[ct][j], __builtin_bit_cast(bf16x8, hb), lg, 0, 0, 0);
                 }
             if (live) {
                 // accumulator register r = class 4 half + (r & 3) + 8 (r >> 2) of this lane's row: classes 0..15 are r = 0..7

@@ -11,6 +11,7 @@ int fill_params(hs::AttnParams& p, const void* qkv, void* out, float* lse, const
     HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
     HS_CHECK_ARG(batch > 0 && n_tokens > 0 && channels > 0 && num_heads > 0, "non-positive size");
     HS_CHECK_ARG(n_tokens < (1ll << 31), "n_tokens must fit int32 (gather table is int32)");
+    HS_CHECK_ARG((int64_t)batch * n_tokens < (1ll << 31), "batch * n_tokens must fit int32 (token rows are carried as 32-bit indices)");
     HS_CHECK_ARG(channels % num_heads == 0, "channels %d not divisible by num_heads %d", channels, num_heads);
     // hp_windowing.py:16 asserts a power of two.  Square nested blocks (4^k) are only needed by the relative-position index
     // and the grid shift, which are validated where those tables are built; the kernels take any power of two

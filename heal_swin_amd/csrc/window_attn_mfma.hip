@@ -100,9 +100,11 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
     // workgroup keeps ~HG*12 KB of HBM requests outstanding all the time instead of only during a load phase
     int64_t tok[4], tok_next[4];
     uint4 ld[3][4];
+    unsigned lab_next = 0;  // this thread's region label of the next window (threads 0..63), prefetched with the rows
     auto issue_loads = [&](int64_t wi_l) {
         const int b_l = (int)(wi_l / nW);
         const int64_t j_l = (wi_l - (int64_t)b_l * nW) * kWs;
+        if (p.labels && tid < kWs) lab_next = p.labels[j_l + tid];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) tok_next[rb] = (int64_t)b_l * N + shifted_source(p, j_l + rb * 16 + srow);
 #pragma unroll
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
         // ------------------------------------------------------------ stage q, k, v of this window (already loaded) into LDS
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) tok[rb] = tok_next[rb];
-        if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
+        if (p.labels && tid < kWs) lab_s[tid] = (unsigned char)lab_next;
 
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
@@ -325,6 +327,18 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
                 *(uint16_t*)(q_tile + qq * 64 + l31 * 2) = float_to_bf16(o[qt][r]);
             }
         __syncthreads();
+        // vmcnt counts loads AND stores on this target, and the two complete out of order with respect to each other: the wait
+        // for the next window's prefetched rows is a full `vmcnt(0)`.  Left to the top of the next iteration it would also wait
+        // for the stores issued right here, i.e. every iteration would pay a store's round trip to memory (timing ablation,
+        // profiles/r03_attn_bwd_ablation.txt: 9 % of the backward).  So the rows -- requested a whole iteration ago, long
+        // landed -- are claimed HERE, in front of the stores: the compiler puts its wait before this statement and has
+        // nothing to wait for at the top; the stores then drain under the next window's staging and arithmetic.
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                asm volatile("" : "+v"(ld[part][rb].x), "+v"(ld[part][rb].y), "+v"(ld[part][rb].z), "+v"(ld[part][rb].w));
+        asm volatile("" : "+v"(lab_next), "+v"(tok_next[0]), "+v"(tok_next[1]), "+v"(tok_next[2]), "+v"(tok_next[3]));
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const int row = rb * 16 + srow;
@@ -401,9 +415,15 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
 // the then-free V/dO tiles), wave 0 its dK half to wave 1 (into the P/dS' scratch).
 template <int HG, bool DROP, bool COS>
 __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
-                                                                     float* __restrict__ dscale_part, int slots, int groups, int abl) {
-    // abl: timing-only ablation mask of tools/attn_bwd_ablation.py (HS_ATTN_BWD_ABLATE; 0 in every product run): 1 no global
-    // stores, 2 no softmax / dS arithmetic, 4 no partial-sum exchange, 8 no X / dK / dV products, 16 no global loads after the first
+                                                                     float* __restrict__ dscale_part, int slots, int groups, int abl_arg) {
+    // abl: timing-only ablation mask of tools/attn_bwd_ablation.py (a library built with -DHS_ATTN_ABLATION reads it from
+    // HS_ATTN_BWD_ABLATE; the product build compiles the branches away): 1 no global stores, 2 no softmax / dS arithmetic, 4 no
+    // partial-sum exchange, 8 no X / dK / dV products, 16 no global loads after the first window
+#ifdef HS_ATTN_ABLATION
+    const int abl = abl_arg;
+#else
+    constexpr int abl = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayoutBwd L(HG);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -457,6 +477,17 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     uint4 ldq[2], ldk[2], ldv[2], lddo[2];
     int64_t tok_next[2];
     float lse_next = 0.f;
+    unsigned lab_next = 0;  // this thread's region label of the next window (threads 0..63), requested with the rows
+    // Deferred stores (PREFETCH variants): a window's dq / dk / dv rows stay in their LDS staging tiles at the end of its
+    // iteration and leave for HBM at the START of the next one, behind that iteration's input staging.  vmcnt counts loads AND
+    // stores on this target and the two complete out of order with respect to each other, so the wait for the prefetched
+    // rows at the top of an iteration is a full `vmcnt(0)`; with the stores issued right in front of it every iteration paid
+    // a store's round trip to memory (timing ablation, profiles/r03_attn_bwd_ablation.txt: 9 % of the launch).  Issued
+    // behind that wait they have a whole iteration to land, and the iteration's last barrier goes away.
+    // Only the plain instantiation (no cosine attention, no attention dropout: every BASELINE bench workload but the paper
+    // config) has the ~10 registers this costs; the others keep the immediate stores (they spill 12-24 registers with it).
+    constexpr bool DEFER = PREFETCH && !COS && !DROP;
+    int tok_prev[2] = {0, 0};  // (token rows fit 31 bits: B * N < 2^31 is checked by the dispatcher)
     auto issue_loads = [&](int64_t wi_l) {
         if ((abl & 16) && wi_l != bx) return;
         int tid_l = tid;
@@ -475,6 +506,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         }
         // this lane's query row of the saved log-sum-exp (needed first thing in the P / dS' phase)
         lse_next = p.lse[((int64_t)b_l * p.nH + h) * N + j_l + qt * 32 + (lane & 31)];
+        if (p.labels && tid < kWs) lab_next = p.labels[j_l + tid];
     };
     auto lds_barrier = [&]() {  // workgroup barrier that orders LDS traffic only (global loads may stay in flight)
         if constexpr (PREFETCH) {
@@ -511,7 +543,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) tok[rb] = tok_next[rb];
         const float lse_cur = lse_next;
-        if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
+        if (p.labels && tid < kWs) lab_s[tid] = (unsigned char)lab_next;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int row = rb * 32 + srow;
@@ -547,7 +579,30 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             *(uint4*)(st + 2 * kTileBytes + off) = vv;
             *(uint4*)(st + 3 * kTileBytes + off) = vdo;
         }
+        uint4 pq0, pk0, pv0, pq1, pk1, pv1;  // the previous window's staged results (this thread's pieces)
+        const bool flush_prev = DEFER && wi != bx;
+        if (flush_prev) {
+            const unsigned char* src = st + L.stage_off + srow * 64 + scc * 16;
+            pq0 = *(const uint4*)src;
+            pk0 = *(const uint4*)(src + kTileBytes);
+            pv0 = *(const uint4*)(src + 2 * kTileBytes);
+            pq1 = *(const uint4*)(src + 32 * 64);
+            pk1 = *(const uint4*)(src + kTileBytes + 32 * 64);
+            pv1 = *(const uint4*)(src + 2 * kTileBytes + 32 * 64);
+        }
         __syncthreads();
+        if (flush_prev && !(abl & 1)) {
+            int t0 = tok_prev[0], t1 = tok_prev[1];
+            asm volatile("" : "+v"(t0), "+v"(t1));  // (addresses formed here, not carried through the iteration)
+            uint16_t* d0 = dqkv + (int64_t)t0 * 3 * C + col0;
+            uint16_t* d1 = dqkv + (int64_t)t1 * 3 * C + col0;
+            *(uint4*)d0 = pq0;
+            *(uint4*)(d0 + C) = pk0;
+            *(uint4*)(d0 + 2 * (int64_t)C) = pv0;
+            *(uint4*)d1 = pq1;
+            *(uint4*)(d1 + C) = pk1;
+            *(uint4*)(d1 + 2 * (int64_t)C) = pv1;
+        }
 
         bool mixed = false;
         if (p.labels) {
@@ -793,13 +848,18 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         }
         lds_barrier();
 
-        // ------------------------------------------------------------ staged results -> global (cosine: normalisation Jacobian)
+        // ------------------------------------------------------------ staged results: cosine normalisation Jacobian; -> global
+        // The DEFER variant leaves the rows in LDS (each thread reads back only its own pieces at the next staging, so no
+        // barrier is needed behind this block); the other variants store them now.
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int row = rb * 32 + srow;
-            uint4 xq = *(const uint4*)(st + L.stage_off + row * 64 + scc * 16);
-            uint4 xk = *(const uint4*)(st + L.stage_off + kTileBytes + row * 64 + scc * 16);
-            const uint4 xv = *(const uint4*)(st + L.stage_off + 2 * kTileBytes + row * 64 + scc * 16);
+            unsigned char* sp = st + L.stage_off + row * 64 + scc * 16;
+            uint4 xq, xk;
+            if constexpr (!DEFER) {
+                xq = *(const uint4*)sp;
+                xk = *(const uint4*)(sp + kTileBytes);
+            }
             if (cosine) {  // remove the component along q^ / k^ (gradient through x / |x|)
                 const uint4 rq = *(const uint4*)(st + swz(row, scc));
                 const uint4 rk = *(const uint4*)(st + kTileBytes + swz(row, scc));
@@ -825,14 +885,32 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 xq = make_uint4(a[0], a[1], a[2], a[3]);
                 xk = make_uint4(c2[0], c2[1], c2[2], c2[3]);
             }
-            uint16_t* dst = dqkv + tok[rb] * 3 * C + col0;
-            if (!(abl & 1)) {
-                *(uint4*)dst = xq;
-                *(uint4*)(dst + C) = xk;
-                *(uint4*)(dst + 2 * (int64_t)C) = xv;
+            if constexpr (!DEFER) {
+                const uint4 xv = *(const uint4*)(sp + 2 * kTileBytes);
+                uint16_t* dst = dqkv + tok[rb] * 3 * C + col0;
+                if (!(abl & 1)) {
+                    *(uint4*)dst = xq;
+                    *(uint4*)(dst + C) = xk;
+                    *(uint4*)(dst + 2 * (int64_t)C) = xv;
+                }
             }
+            if constexpr (DEFER) tok_prev[rb] = (int)tok[rb];
         }
-        lds_barrier();
+        if constexpr (!DEFER) lds_barrier();
+    }
+    if (DEFER && (int64_t)bx < total_windows && !(abl & 1)) {  // the last window's rows (this thread's own pieces)
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;
+        const int64_t col0 = (int64_t)by * HG * kHd + sc * 8;
+        const unsigned char* src = smem + sg * L.head + L.stage_off + srow * 64 + scc * 16;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            uint16_t* dst = dqkv + (int64_t)tok_prev[rb] * 3 * C + col0;
+            *(uint4*)dst = *(const uint4*)(src + rb * 32 * 64);
+            *(uint4*)(dst + C) = *(const uint4*)(src + kTileBytes + rb * 32 * 64);
+            *(uint4*)(dst + 2 * (int64_t)C) = *(const uint4*)(src + 2 * kTileBytes + rb * 32 * 64);
+        }
     }
 
     // ------------------------------------------------------------ per-workgroup partial parameter gradients

@@ -899,11 +899,14 @@ def _ln_head_backward(y2, mean, rstd, gamma, beta, weight, dlogits, want_params)
 
 
 def _fold_head(gamma, beta, weight, C, device):
-    """(wfold [32, C] bf16 = gamma * W rows, bvec [32] f32 = W beta) of the fused LayerNorm + head kernels."""
+    """(wfold [64, C] bf16: rows 0..31 = gamma * W rounded to bf16, rows 32..63 the rounding remainder (read by
+    hs_expand_ln_head_fwd only); bvec [32] f32 = W beta) of the fused LayerNorm + head kernels."""
     f_out = weight.shape[0]
     w = weight.detach().reshape(f_out, C).float()
-    wfold = torch.zeros((32, C), dtype=torch.bfloat16, device=device)
-    wfold[:f_out] = (w * gamma.detach().float()).to(torch.bfloat16)
+    wfold = torch.zeros((64, C), dtype=torch.bfloat16, device=device)
+    prod = w * gamma.detach().float()
+    wfold[:f_out] = prod.to(torch.bfloat16)
+    wfold[32:32 + f_out] = (prod - wfold[:f_out].float()).to(torch.bfloat16)
     bvec = torch.zeros(32, dtype=torch.float32, device=device)
     bvec[:f_out] = w @ beta.detach().float()
     return wfold, bvec

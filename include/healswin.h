@@ -397,7 +397,8 @@ int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const vo
  * only the input's remains (csrc/expand_ln_head.hip).  bf16, 4 children, C in {64, 96, 128} (the expand weight lives in LDS).
  *   xn [dev] bf16[tokens, C] (the norm_up output), xn_lo [dev] bf16[tokens, C] or NULL: its rounding remainder (hs_layernorm_fwd_ex lo_out) --
  *   with it the expand product takes its input as hi + lo and the tail has NO bf16 rounding between norm_up and the logits;
- *   wexp [dev] bf16[4 C, C] as nn.Linear stores it; wfold / bvec as for hs_ln_head_fwd;
+ *   wexp [dev] bf16[4 C, C] as nn.Linear stores it; wfold [dev] bf16[64, C]: rows 0..31 = gamma * W[k, :] rounded to bf16 (rows >=
+ *   n_classes zero), rows 32..63 its rounding remainder; bvec as for hs_ln_head_fwd;
  *   logits [dev] f32[4 tokens, 16]; y [dev] bf16[4 tokens, C] + mean, rstd [dev] f32[4 tokens]: what the backward (hs_ln_head_bwd on y,
  *   then the Linear's gradients) needs -- all three NULL for a forward without gradient, in which case the expanded tensor never exists. */
 int hs_expand_ln_head_supported(int width, int children, int n_classes, int dtype);

@@ -138,8 +138,8 @@ def test_expand_ln_head_matches_the_composition(tokens, C, f_out):
 
 def test_tail_with_hi_lo_norm_up_output():
     """norm_up -> expand -> LayerNorm -> head with the norm_up output handed over as hi + lo (`layer_norm_hilo`,
-    `expand_ln_head(..., xn_lo)`): the logits follow the fp32 composition on the UN-rounded LayerNorm output to 1e-3, three times
-    closer than with the rounded operand alone; gradients are those of the plain call."""
+    `expand_ln_head(..., xn_lo)`): the logits follow the fp32 composition on the UN-rounded LayerNorm output to 1e-3 (head
+    weights enter as hi + lo too), well inside what the rounded operand alone gives; gradients are those of the plain call."""
     from heal_swin_amd import ops
 
     torch.manual_seed(11)
@@ -161,4 +161,4 @@ def test_tail_with_hi_lo_norm_up_output():
     e_lo, e_hi = float((with_lo - ref).abs().max()) / scale, float((without - ref).abs().max()) / scale
     import conftest
     conftest.NOTES.append(f"fused tail logits vs fp32 composition on the exact norm_up output: {e_lo:.2e} with xn_lo, {e_hi:.2e} without")
-    assert e_lo <= 1e-3 and e_lo < e_hi
+    assert e_lo <= 1e-3 and e_lo < 0.6 * e_hi

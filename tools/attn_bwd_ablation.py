@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Timing-only ablations of attn_bwd_mfma_kernel (HS_ATTN_BWD_ABLATE bit mask; results are wrong by construction): what does each
 part of the backward cost at the HEAL-SWIN-B stage shapes?  One subprocess per mask (the mask is read once per process).
+Needs a library built with the hooks compiled in:   HS_EXTRA_CXXFLAGS=-DHS_ATTN_ABLATION python heal_swin_amd/build.py --force
+(the product build compiles them away: they cost the dropout instantiations 7-12 spilled registers).
    python tools/attn_bwd_ablation.py            -> table on stdout
    python tools/attn_bwd_ablation.py --one S    (internal) time stage S under the current environment"""
 import os
