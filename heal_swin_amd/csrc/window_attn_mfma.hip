@@ -33,6 +33,19 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// A/B switches of two store-placement experiments of round 3 (tools/attn_store_ab.sh builds all four combinations;
+// profiles/r03_attn_store_ab.txt).  Motivation: vmcnt counts loads AND stores here, the wait for the prefetched rows at the top
+// of an iteration is a full vmcnt(0) and therefore also waits for the stores issued just before it; a timing ablation without
+// the stores ran 9 % faster.  Neither re-ordering realised that: claiming the forward's prefetched rows in front of its stores
+// costs 12 % at stage 0 (4 spilled registers in a kernel at the 256-VGPR limit), deferring the backward's stores to the next
+// iteration is within the run-to-run noise (+-10 % at stages 2-3 between processes).  Both default OFF.
+#ifndef HS_ATTN_FWD_CLAIM
+#define HS_ATTN_FWD_CLAIM 0
+#endif
+#ifndef HS_ATTN_BWD_DEFER
+#define HS_ATTN_BWD_DEFER 0
+#endif
+
 constexpr int kWs = 64, kHd = 32;
 constexpr int kTileBytes = kWs * kHd * 2;  // 4096: [64][32] bf16, rows of 64 B = 4 chunks of 16 B
 constexpr int kVtLd = 136;                 // bytes per feature row of the transposed tile (64 keys * 2 B + 8 pad)
@@ -100,11 +113,9 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
     // workgroup keeps ~HG*12 KB of HBM requests outstanding all the time instead of only during a load phase
     int64_t tok[4], tok_next[4];
     uint4 ld[3][4];
-    unsigned lab_next = 0;  // this thread's region label of the next window (threads 0..63), prefetched with the rows
     auto issue_loads = [&](int64_t wi_l) {
         const int b_l = (int)(wi_l / nW);
         const int64_t j_l = (wi_l - (int64_t)b_l * nW) * kWs;
-        if (p.labels && tid < kWs) lab_next = p.labels[j_l + tid];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) tok_next[rb] = (int64_t)b_l * N + shifted_source(p, j_l + rb * 16 + srow);
 #pragma unroll
@@ -153,7 +164,7 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
         // ------------------------------------------------------------ stage q, k, v of this window (already loaded) into LDS
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) tok[rb] = tok_next[rb];
-        if (p.labels && tid < kWs) lab_s[tid] = (unsigned char)lab_next;
+        if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
 
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
@@ -333,12 +344,14 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
         // profiles/r03_attn_bwd_ablation.txt: 9 % of the backward).  So the rows -- requested a whole iteration ago, long
         // landed -- are claimed HERE, in front of the stores: the compiler puts its wait before this statement and has
         // nothing to wait for at the top; the stores then drain under the next window's staging and arithmetic.
+#if HS_ATTN_FWD_CLAIM
 #pragma unroll
         for (int part = 0; part < 3; ++part)
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
                 asm volatile("" : "+v"(ld[part][rb].x), "+v"(ld[part][rb].y), "+v"(ld[part][rb].z), "+v"(ld[part][rb].w));
-        asm volatile("" : "+v"(lab_next), "+v"(tok_next[0]), "+v"(tok_next[1]), "+v"(tok_next[2]), "+v"(tok_next[3]));
+        asm volatile("" : "+v"(tok_next[0]), "+v"(tok_next[1]), "+v"(tok_next[2]), "+v"(tok_next[3]));
+#endif
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const int row = rb * 16 + srow;
@@ -486,7 +499,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     // behind that wait they have a whole iteration to land, and the iteration's last barrier goes away.
     // Only the plain instantiation (no cosine attention, no attention dropout: every BASELINE bench workload but the paper
     // config) has the ~10 registers this costs; the others keep the immediate stores (they spill 12-24 registers with it).
-    constexpr bool DEFER = PREFETCH && !COS && !DROP;
+    constexpr bool DEFER = HS_ATTN_BWD_DEFER && PREFETCH && !COS && !DROP;
     int tok_prev[2] = {0, 0};  // (token rows fit 31 bits: B * N < 2^31 is checked by the dispatcher)
     auto issue_loads = [&](int64_t wi_l) {
         if ((abl & 16) && wi_l != bx) return;

@@ -361,3 +361,30 @@ def test_activation_checkpointing_reproduces_the_plain_run(rates):
     for n, gref in out[False][1].items():
         scale = max(float(gref.abs().max()), 1e-6)
         assert float((gref - out[True][1][n]).abs().max()) <= 3e-2 * scale, n
+
+
+@pytest.mark.parametrize("name", list(REFINIT_MODEL_CASES))
+def test_compensated_residual_stream_option(name):
+    """`ops.COMP_RESIDUAL` (opt-in, HS_COMP_RESIDUAL=1): the residual stream carried as hi + lo through a stage.  On the
+    reference-scale golden models (v1 / nest_roll and v2 / ring / cosine) the logits stay within north_star's bf16 bound of the
+    reference's own tensors and every gradient within the bf16 gradient bound -- the option changes rounding, not arithmetic."""
+    M = _M()
+    from heal_swin_amd import ops
+    from heal_swin_amd.data_spec import DataSpec
+    cfg, spec = refinit_cfg_spec(name)
+    c = case("refinit", "model/" + name)
+    prev = ops.COMP_RESIDUAL
+    ops.COMP_RESIDUAL = True
+    try:
+        model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), DataSpec(**spec))
+        model.load_state_dict(state_dict(c), strict=True)
+        model = model.train().to(DEV)
+        model.compute_dtype = torch.bfloat16
+        x = torch.from_numpy(c["x"]).to(DEV).requires_grad_(True)
+        y = model(x)
+        assert_close(y, c["y"], TOL[torch.bfloat16], "compensated stream: refinit logits")
+        y.backward(torch.from_numpy(c["dy"]).to(DEV))
+        assert_close(x.grad, c["dx"], GRAD_TOL[torch.bfloat16], "compensated stream: refinit dx")
+        _check_grads_own_scale(model, c, torch.bfloat16, "compensated stream: refinit model")
+    finally:
+        ops.COMP_RESIDUAL = prev
