@@ -135,7 +135,9 @@ def test_baseline_architecture_fwd_bwd_vs_oracle(name, dtype):
         worst_ls = max(ls_pairs, key=lambda t: float((t[1] - t[2]).abs().max() / t[2].abs().max().clamp_min(1e-30)))
         conftest.NOTES.append(f"{tag}: d logit_scale over {a.numel()} heads: cosine {cos:.4f}, ||a-b||/||b|| {rel:.3f}; worst tensor "
                               f"{worst_ls[0]} max|a-b|/max|b| {float((worst_ls[1] - worst_ls[2]).abs().max() / worst_ls[2].abs().max()):.2f}")
-        assert cos >= 0.9, (cos, rel)  # a sign / scale error in the dscale or normalisation-Jacobian path would give ~0 or < 0
+        # observed on MI355X (paper config, 228 heads): cosine 1.0000, ||a-b||/||b|| 9e-3, worst single tensor 0.10 of its scale.
+        # A sign / scale error in the dscale or normalisation-Jacobian path would give a cosine near 0 or negative
+        assert cos >= 0.995 and rel <= 5e-2, (cos, rel)
     edx = errors(xg.grad, ref_dx)
     assert_close(xg.grad, ref_dx, GRAD_TOL[dtype], tag + " dx")
     conftest.NOTES.append(f"{tag}: {len(ref_grads)} parameter gradients, worst max|a-b|/max|b| {worst[1]:.2e} ({worst[0]}), "
