@@ -545,7 +545,8 @@ class ParamCastCache:
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.versions = None
         self.dirty = False    # a grad-enabled forward has run since the last refresh: the parameters are about to change
-        self.transposed = {}  # index -> (transposed shadow, the `versions` list object it was made from)
+        self.transposed = {}  # index -> [transposed shadow, the `versions` list object it was made from]
+        self._jobs = None     # device table of hs_transpose_many_16 over the entries of `transposed`
 
     def invalidate(self):
         self.versions = None
@@ -569,16 +570,38 @@ class ParamCastCache:
 
     def get_t(self, p, dtype):
         """[in, out] (transposed) activation-dtype copy of a 2-D weight: the B operand of its input-gradient product in
-        `hs_gemm_nt`.  Made on first use and re-made after every refresh that found changed parameters."""
+        `hs_gemm_nt`.  Made on first use; after a refresh ALL copies made so far are re-made together by one launch
+        (`hs_transpose_many_16`) the first time any of them is asked for."""
         i = self.index.get(id(p)) if dtype == self.dtype else None
         if i is None:
             return None
         ent = self.transposed.get(i)
-        if ent is None or ent[1] is not self.versions:
-            t = self.shadows[i].t().contiguous() if ent is None else ent[0].copy_(self.shadows[i].t())
-            ent = (t, self.versions)
-            self.transposed[i] = ent
+        if ent is None:
+            t = self.shadows[i].t().contiguous()
+            self.transposed[i] = ent = [t, self.versions]
+            self._jobs = None  # the job table is rebuilt with this entry
+        elif ent[1] is not self.versions:
+            self._retranspose_all()
         return ent[0]
+
+    def _retranspose_all(self):
+        ents = sorted(self.transposed.items())
+        if self.dtype.itemsize != 2 or not self.shadows[0].is_cuda:
+            for i, ent in ents:
+                ent[0].copy_(self.shadows[i].t())
+                ent[1] = self.versions
+            return
+        if getattr(self, "_jobs", None) is None:
+            rec = []
+            for i, ent in ents:
+                rows, cols = self.shadows[i].shape
+                rec.append([self.shadows[i].data_ptr(), ent[0].data_ptr(), rows, cols])
+            self._jobs = torch.tensor(rec, dtype=torch.int64).to(self.shadows[0].device)
+            self._job_blocks = int(min(64, max(1, max((r[2] + 31) // 32 * ((r[3] + 31) // 32) for r in rec))))
+        check(lib.hs_transpose_many_16(ptr(self._jobs), len(ents), self._job_blocks, stream_ptr(self.shadows[0].device)),
+              "hs_transpose_many_16")
+        for _, ent in ents:
+            ent[1] = self.versions
 
 
 CAST_CACHE = None  # a refreshed ParamCastCache while a model forward is running (set by SwinHPTransformerSys.forward)

@@ -48,6 +48,11 @@ const char* hs_status_string(int status);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
 int hs_device_count(void);
 
+/* `count` 2-D transposes of 16-bit matrices in one launch.  jobs [dev]: `count` records {const void* src [rows, cols] row-major;
+ * void* dst [cols, rows] row-major; int64 rows; int64 cols} (32 bytes each).  The per-step [in, out] copies of the Linear weights
+ * (B operand of the input-gradient products of hs_gemm_nt; autograd of nn.Linear, models_torch/swin_hp_transformer.py:33-35). */
+int hs_transpose_many_16(const void* jobs, int count, int blocks_per_job, void* stream);
+
 /* Compute units that the persistent / one-resident-round launches of this library leave FREE (a multiple of 8 in [0, 128]: the same
  * number on each of the 8 XCDs; default 0, or the environment variable HS_RESERVED_CUS).  Data-parallel training (the reference's
  * Lightning DDP, train.py:182-189) runs RCCL's all-reduce kernels on their own stream DURING the backward; a kernel whose grid

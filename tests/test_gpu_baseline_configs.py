@@ -234,3 +234,42 @@ def test_headline_config_full_size_logits_vs_oracle(seed, dtype):
         assert_close(logits, f["logits"], LOGIT_TOL[dtype], tag + " logits")
         assert abs(loss - f["loss"]) <= (1e-4 if dtype == torch.float32 else 2e-3) * max(1.0, abs(f["loss"]))
     f["model"].cpu()
+
+
+# ----------------------------------------------------------------------------- the paper's run config at its FULL size (forward)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_paper_config_full_size_logits_vs_oracle(dtype):
+    """The paper's model exactly as its run config builds it (HEAL-SWIN-T, nside 256, 8 base pixels = 524 288 pixels, window 64,
+    ring_shift 4, cosine attention, v2 norm placement; run_configs/segmentation/swin_hp_*_train_run_config.py:48-65) -- also
+    BASELINE configs[3]'s non-trivial shift permutation at nside 256: the ring-shift tables of all four stages, the int64-mask
+    semantics and the cosine path at full size.  Default initialisation + N(0, 0.02) bias tables, one image, forward under
+    no_grad on the oracle side: logits within north_star's 1e-3 (fp32) / 1e-2 (bf16), CE loss equal."""
+    from heal_swin_amd.losses import seg_loss
+    from oracle import model as OM
+    CASES["_paper_full"] = (T_CFG, 256, 8, 1, dict(shift_strategy="ring_shift", shift_size=4, use_cos_attn=True, use_v2_norm_placement=True))
+    try:
+        model, cfg, spec, x, y = _setup_seeded("_paper_full", 21)
+    finally:
+        del CASES["_paper_full"]
+    key = "_paper_full_oracle"
+    if key not in _FULL:
+        sd = {k: v.detach() for k, v in model.state_dict().items() if not k.endswith("attn_mask")}
+        torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+        with torch.no_grad():
+            logits = OM.forward(sd, types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec), x)
+            loss = float(OM.seg_loss(logits, y))
+        _FULL.clear()
+        _FULL[key] = (logits, loss)
+    ref_logits, ref_loss = _FULL[key]
+    model = model.to(DEV).eval()
+    model.compute_dtype = dtype
+    for grad_mode in (True, False):
+        with torch.set_grad_enabled(grad_mode):
+            logits = model(x.to(DEV))
+            loss = float(seg_loss(logits, y.to(DEV)))
+        tag = f"paper_T_ring_cos_v2_nside256_bp8_FULL[{'bf16' if dtype == torch.bfloat16 else 'fp32'}{'' if grad_mode else ', no_grad'}]"
+        e = errors(logits, ref_logits)
+        conftest.NOTES.append(f"{tag}: logits max|a-b|/max|b| {e['scale_err']:.2e} (scale {e['scale']:.2f}), rms {e['rms_err']:.2e}; "
+                              f"loss {loss:.6f} vs oracle {ref_loss:.6f}")
+        assert_close(logits, ref_logits, LOGIT_TOL[dtype], tag + " logits")
+        assert abs(loss - ref_loss) <= (1e-4 if dtype == torch.float32 else 2e-3) * max(1.0, abs(ref_loss))

@@ -748,3 +748,22 @@ def test_seg_cross_entropy_padded_row_fast_path(K):
     ref.backward()
     assert abs(float(loss_p) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
     assert float((zp.grad[..., :K].float().cpu().transpose(1, 2) - ref_in.grad).abs().max()) <= 1e-2 * float(ref_in.grad.abs().max())
+
+
+def test_batched_weight_transposes_follow_the_parameters():
+    """`ops.ParamCastCache.get_t`: the [in, out] bf16 copies of the weights are re-made by ONE launch (`hs_transpose_many_16`) after
+    every refresh -- odd shapes included -- and equal `param.to(bf16).t()` exactly."""
+    ops, _, _ = _mods()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(384, 128), (128, 512), (40, 24), (33, 100), (2048, 512), (16, 128)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    cache = ops.ParamCastCache(params, torch.bfloat16)
+    for step in range(3):
+        cache.refresh(force=True)
+        for p in params:
+            t = cache.get_t(p, torch.bfloat16)
+            assert t.shape == (p.shape[1], p.shape[0]) and t.is_contiguous()
+            assert torch.equal(t, p.detach().to(torch.bfloat16).t()), (step, tuple(p.shape))
+        with torch.no_grad():
+            for p in params:
+                p.add_(0.37 * (step + 1))  # an optimizer step (fused ones do not bump versions: hence force=True above)
