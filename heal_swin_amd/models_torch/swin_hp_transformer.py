@@ -293,12 +293,12 @@ class SwinTransformerBlock(nn.Module):
             return None, self.shift_size % x.shape[1], labels
         return idx, 0, labels
 
-    def forward_deferred(self, x, pending, x_lo=None):
+    def forward_deferred(self, x, pending, x_lo=None, comp=None):
         """v1 block on the input `x (+ x_lo) + rs*drop(p)` for pending = (p, rs, drop_p) (or None); returns (x1, pending', x1_lo)
         with the block output = x1 (+ x1_lo) + rs'*drop(m) (ref :337-338 and :316 of the next block).  x_lo / x1_lo are the
         rounding remainders of the compensated residual stream (bf16 runs; None when off or not yet started)."""
         train = self.training
-        comp = ops.COMP_RESIDUAL and x.dtype == torch.bfloat16
+        comp = (ops.COMP_RESIDUAL if comp is None else comp) and x.dtype == torch.bfloat16
         if self.attn.fusable(x, self.window_size) and not (train and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0):
             # no-grad forward: x1 = xs + proj(attn(qkv(norm1(xs)))) is ONE launch (norm1 as the kernel's prologue, the
             # residual add as its epilogue), xs = x + previous block's MLP branch
@@ -447,13 +447,18 @@ class _Stage(nn.Module):
                 x, pending, x_lo = SwinTransformerBlock.resolve_pending(x, pending), None, None
                 x = checkpoint.checkpoint(blk, x, use_reentrant=False)
             elif blk.can_defer():
-                x, pending, x_lo = blk.forward_deferred(x, pending, x_lo)
-            elif blk.can_stream_v2() and ops.COMP_RESIDUAL and x.dtype == torch.bfloat16 and x.is_cuda:
+                x, pending, x_lo = blk.forward_deferred(x, pending, x_lo, comp=self._comp())
+            elif blk.can_stream_v2() and self._comp() and x.dtype == torch.bfloat16 and x.is_cuda:
                 x, x_lo = blk.forward_stream_v2(x, x_lo)
             else:
                 x, pending, x_lo = SwinTransformerBlock.resolve_pending(x, pending), None, None
                 x = blk(x)
         return SwinTransformerBlock.resolve_pending(x, pending)
+
+    comp_residual = None  # None: follow ops.COMP_RESIDUAL; True / False: this stage's own setting (see UnetDecoder)
+
+    def _comp(self):
+        return ops.COMP_RESIDUAL if self.comp_residual is None else bool(self.comp_residual)
 
     def extra_repr(self):
         return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"
@@ -556,6 +561,9 @@ class UnetDecoder(nn.Module):
                 drop_path=dpr[lo:lo + config.depths[down]], norm_layer=config.norm_layer,
                 use_v2_norm_placement=config.use_v2_norm_placement, upsample=PatchExpand if down > 0 else None,
                 use_checkpoint=config.use_checkpoint))
+        if ops.COMP_RESIDUAL_LAST_STAGE and isinstance(self.layers_up[-1], BasicLayer_up):
+            # the last decoder stage feeds the tail directly: its residual stream is carried as hi + lo (ops.COMP_RESIDUAL_LAST_STAGE)
+            self.layers_up[-1].comp_residual = True
         self.up = FinalPatchExpand_X4(patch_size=config.patch_size, dim=config.embed_dim)
         self.output = nn.Conv1d(in_channels=config.embed_dim, out_channels=data_spec.f_out, kernel_size=1, bias=False)
         self.norm_up = _make_norm(config.norm_layer, config.embed_dim)

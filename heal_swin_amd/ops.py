@@ -182,6 +182,8 @@ def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window
 # halves the error of the stage outputs (enc.2: 2.6e-2 -> 1.3e-2 of scale) but moves the LOGIT error by only 0-12 % (the decoder
 # tail's roundings dominate it, tests/experiments/bf16_error_budget.py) and costs 2.4 % of the step (158.7 -> 162.6 ms).
 COMP_RESIDUAL = os.environ.get("HS_COMP_RESIDUAL", "0") == "1"
+# the same for the LAST decoder stage only (the two blocks in front of the tail; 2 of 46 blocks of HEAL-SWIN-B): experiment switch
+COMP_RESIDUAL_LAST_STAGE = os.environ.get("HS_COMP_RESIDUAL_LAST", "0") == "1"
 
 
 FUSED_ATTN_MODULE = os.environ.get("HS_FUSED_ATTN_MODULE", "1") != "0"  # A/B switch of the no-grad fused module path
