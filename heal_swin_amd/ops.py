@@ -685,9 +685,12 @@ def _lib_matmul(dy2, w, res=None):
         return dy2 @ w if res is None else torch.addmm(res, dy2, w)
 
 
-def _cast_param_t(p, dtype):
-    """[in, out] copy of weight p ([out, in, ...]) in `dtype` for the input-gradient product."""
-    cache = CAST_CACHE if CAST_CACHE is not None else LAST_CAST_CACHE
+def _cast_param_t(p, dtype, cache=None):
+    """[in, out] copy of weight p ([out, in, ...]) in `dtype` for the input-gradient product.  `cache`: the ParamCastCache the
+    FORWARD of this autograd node ran under (kept on its ctx, so that several models in one process each take their own
+    copies); falls back to the cache of the most recent forward."""
+    if cache is None:
+        cache = CAST_CACHE if CAST_CACHE is not None else LAST_CAST_CACHE
     c = cache.get_t(p, dtype) if (cache is not None and p.dim() == 2 and cache.current(p)) else None
     if c is None:
         n_out = p.shape[0]
@@ -752,6 +755,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.bias_param = bias
         ctx.w_cast = w if w.dtype != weight.dtype else None  # activation-dtype copy, reused by the input-gradient GEMM
+        ctx.cast_cache = CAST_CACHE
         ctx.passthrough = passthrough
         if own_gemm_ok(_lib.HS_EPI_BIAS, n_out, k_in, x.dtype) and x.is_contiguous():
             y = gemm_nt(x.reshape(-1, k_in), w, bias)[0].view(x.shape[:-1] + (n_out,))  # fp32 master bias added in the epilogue
@@ -792,20 +796,20 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy2, weight, ctx.w_cast, None if dx_res is None else dx_res.reshape(-1, k_in)).reshape(x.shape)
-        ctx.w_cast = None
+            dx = _input_grad(dy2, weight, ctx.w_cast, None if dx_res is None else dx_res.reshape(-1, k_in), ctx.cast_cache).reshape(x.shape)
+        ctx.w_cast = ctx.cast_cache = None
         dw, db = _param_grads(dy2, x2, weight, bias, ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 
-def _input_grad(dy2, weight, w_cast, dx_res2=None):
+def _input_grad(dy2, weight, w_cast, dx_res2=None, cache=None):
     """dx = dy2 @ W (+ dx_res2): `hs_gemm_nt` on the transposed weight copy where that wins, else the library GEMM."""
     n_out = weight.shape[0]
     k_in = weight.numel() // n_out
     epi = _lib.HS_EPI_BIAS if dx_res2 is None else _lib.HS_EPI_RESID
     if own_gemm_ok(epi, k_in, n_out, dy2.dtype):
         res = None if dx_res2 is None else dx_res2.to(dy2.dtype).contiguous()
-        return gemm_nt(dy2, _cast_param_t(weight, dy2.dtype), None, epi, aux=res)[0]
+        return gemm_nt(dy2, _cast_param_t(weight, dy2.dtype, cache), None, epi, aux=res)[0]
     w = w_cast if (w_cast is not None and w_cast.dtype == dy2.dtype) else (
         weight if weight.dtype == dy2.dtype else weight.to(dy2.dtype)).view(n_out, k_in)
     if dx_res2 is not None:
@@ -974,6 +978,7 @@ class ExpandLnHeadFn(torch.autograd.Function):
                                             tokens, C, P, _lib.HS_BF16, stream_ptr(xn2.device)), "hs_expand_ln_head_fwd")
         ctx.save_for_backward(xn2, y, mean, rstd, gamma, beta, weight, wexp)
         ctx.w_cast = wq if wq.dtype != wexp.dtype else None
+        ctx.cast_cache = CAST_CACHE
         return logits
 
     @staticmethod
@@ -982,8 +987,8 @@ class ExpandLnHeadFn(torch.autograd.Function):
         tokens, C = xn2.shape
         dy, dgamma, dbeta, dw = _ln_head_backward(y, mean, rstd, gamma, beta, weight, dlogits, any(ctx.needs_input_grad[2:]))
         dy2 = dy.view(tokens, wexp.shape[0])  # 'b (n p) c -> b n (p c)': the children of a token are consecutive rows
-        dxn = _input_grad(dy2, wexp, ctx.w_cast) if ctx.needs_input_grad[0] else None
-        ctx.w_cast = None
+        dxn = _input_grad(dy2, wexp, ctx.w_cast, None, ctx.cast_cache) if ctx.needs_input_grad[0] else None
+        ctx.w_cast = ctx.cast_cache = None
         dwexp, _ = _param_grads(dy2, xn2, wexp, None, ctx.needs_input_grad[1], False)
         return dxn, dwexp, dgamma, dbeta, dw, None
 
@@ -1030,6 +1035,7 @@ class MlpFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h, a, w1, w2)
         ctx.biases = (b1, b2)
         ctx.casts = (w1c if w1c.dtype != w1.dtype else None, w2c if w2c.dtype != w2.dtype else None)
+        ctx.cast_cache = CAST_CACHE
         ctx.meta = (float(drop_p), int(seed), x.shape)
         y = y.view(x.shape[:-1] + (w2.shape[0],))
         return (y, x.view_as(x)) if passthrough else y
@@ -1049,7 +1055,7 @@ class MlpFn(torch.autograd.Function):
         dt = dy2.dtype
         # dh = (dy W2) * mask * gelu'(h)
         if own_gemm_ok(_lib.HS_EPI_DGELU, hid, c_out, dt):
-            dh = gemm_nt(dy2, _cast_param_t(w2, dt), None, _lib.HS_EPI_DGELU, aux=h, drop_p=p, seed=seed)[0]
+            dh = gemm_nt(dy2, _cast_param_t(w2, dt, ctx.cast_cache), None, _lib.HS_EPI_DGELU, aux=h, drop_p=p, seed=seed)[0]
         else:
             da = _lib_matmul(dy2, w2c if (w2c is not None and w2c.dtype == dt) else w2.to(dt))
             dh = torch.empty_like(h)
@@ -1057,8 +1063,8 @@ class MlpFn(torch.autograd.Function):
             del da
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dh, w1, w1c, None if dx_res is None else dx_res.reshape(-1, c_in)).reshape(xshape)
-        ctx.casts = None
+            dx = _input_grad(dh, w1, w1c, None if dx_res is None else dx_res.reshape(-1, c_in), ctx.cast_cache).reshape(xshape)
+        ctx.casts = ctx.cast_cache = None
         dw2, db2 = _param_grads(dy2, a, w2, b2, ctx.needs_input_grad[3], b2 is not None and ctx.needs_input_grad[4])
         dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[1], b1 is not None and ctx.needs_input_grad[2])
         return dx, dw1, db1, dw2, db2, None, None, None
@@ -1091,6 +1097,7 @@ class ConcatLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, skip, weight)
         ctx.bias_param = bias
         ctx.w_cast = w if w is not weight else None
+        ctx.cast_cache = CAST_CACHE
         return y.reshape(x.shape[:-1] + (weight.shape[0],))
 
     @staticmethod
@@ -1106,7 +1113,7 @@ class ConcatLinearFn(torch.autograd.Function):
         w = ctx.w_cast if (ctx.w_cast is not None and ctx.w_cast.dtype == dy.dtype) else _cast_param(weight, dy.dtype)
         ctx.w_cast = None
         if own_gemm_ok(_lib.HS_EPI_BIAS, c, n_out, dy2.dtype) and own_gemm_ok(_lib.HS_EPI_BIAS, cs, n_out, dy2.dtype):
-            wt = _cast_param_t(weight, dy2.dtype)  # [c + cs, n_out]: the two row blocks are the B operands
+            wt = _cast_param_t(weight, dy2.dtype, ctx.cast_cache)  # [c + cs, n_out]: the two row blocks are the B operands
             dx = gemm_nt(dy2, wt[:c])[0].reshape(x.shape) if ctx.needs_input_grad[0] else None
             dskip = gemm_nt(dy2, wt[c:])[0].reshape(skip.shape) if ctx.needs_input_grad[1] else None
         else:
