@@ -22,7 +22,30 @@ def _np(a):
     return np.asarray(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float64)
 
 
+def _errors_gpu(a, b):
+    """The same measures computed on the GPU in float64 (large tensors: the numpy path converts both operands to float64 on the
+    host and sorts for the quantile -- seconds per comparison at the full-size shapes, minutes on a slow host)."""
+    dev = a.device if (torch.is_tensor(a) and a.is_cuda) else b.device
+    a = (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).detach().to(dev).to(torch.float64)
+    b = (b if torch.is_tensor(b) else torch.from_numpy(np.ascontiguousarray(b))).detach().to(dev).to(torch.float64)
+    assert a.shape == b.shape, (tuple(a.shape), tuple(b.shape))
+    d = (a - b).abs()
+    scale = float(b.abs().max()) if b.numel() else 0.0
+    if scale == 0.0:
+        m = float(d.max()) if d.numel() else 0.0
+        return dict(scale=0.0, abs=m, scale_err=m, rms_err=0.0, elem_err=0.0)
+    rms = float(torch.sqrt((d * d).sum()) / torch.sqrt((b * b).sum()).clamp_min(1e-300))
+    el = (d / torch.maximum(b.abs(), torch.full((), 1e-2 * scale, dtype=torch.float64, device=dev))).flatten()
+    if el.numel() > (1 << 22):  # the percentile is a diagnostic: a strided sample of <= 4 M elements
+        el = el[:: (el.numel() + (1 << 22) - 1) // (1 << 22)]
+    elem = float(torch.quantile(el, 0.999)) if el.numel() > 1000 else float(el.max())
+    dmax = float(d.max())
+    return dict(scale=scale, abs=dmax, scale_err=dmax / scale, rms_err=rms, elem_err=elem)
+
+
 def errors(a, b):
+    if (torch.is_tensor(a) and a.is_cuda) or (torch.is_tensor(b) and b.is_cuda):
+        return _errors_gpu(a, b)
     a, b = _np(a), _np(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     d = np.abs(a - b)

@@ -27,7 +27,7 @@ T_CFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24])
 B_CFG = dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32])
 CASES = {
     # name: (arch, nside, base_pix, batch, overrides)
-    "configs1_T_nside128_bp8": (T_CFG, 128, 8, 2, dict(shift_strategy="nest_roll", shift_size=32)),
+    "configs1_T_nside128_bp8": (T_CFG, 128, 8, 1, dict(shift_strategy="nest_roll", shift_size=32)),  # (one image: the oracle's fwd + bwd is the suite's slowest item)
     "configs2_B_nside64_bp12": (B_CFG, 64, 12, 1, dict(shift_strategy="nest_roll", shift_size=32)),
     "paper_T_ring_cos_v2_nside64_bp8": (T_CFG, 64, 8, 1, dict(shift_strategy="ring_shift", shift_size=4, use_cos_attn=True,
                                                                 use_v2_norm_placement=True)),
