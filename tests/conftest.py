@@ -14,8 +14,26 @@ _PER_TEST = {}  # test id -> (n comparisons, worst scale_err, worst rms_err, wor
 NOTES = []      # free-form measured-error lines the parity tests want in the terminal summary
 
 
+def _usable_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256
+    hardware threads under a 16-CPU quota; torch's default of one thread per visible core then throttles the CPU oracle)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+        torch.set_num_threads(min(16, _usable_cores()))
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
