@@ -304,7 +304,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
         if rank == 0 and not shared_gpu:
-            os.environ.setdefault("NCCL_DEBUG", "VERSION")  # one line with the RCCL version on stderr of rank 0
+            # one line with the RCCL version -- on STDERR (RCCL logs to stdout by default; stdout carries the JSON line alone)
+            if "NCCL_DEBUG" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "VERSION"
+                os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         # RCCL's ring kernels are long-lived workgroups that share the chip with the backward.  A kernel that fills all 256 CUs
         # loses 45-65 % when even 8 of them hold a foreign 128-VGPR workgroup (profiles/r03_cu_contention.json), so the exchange
         # gets a bounded number of channels and the library leaves that many CUs free (GradBucketAllReduce(reserved_cus=...)).
