@@ -24,6 +24,9 @@ struct vec_io<float, 4> {
     static __device__ __forceinline__ void store(void* p, int64_t i, const float* v) {
         *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    static __device__ __forceinline__ void decode(const uint4& t, float* v) {
+        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+    }
 };
 template <>
 struct vec_io<bf16_t, 8> {
@@ -42,11 +45,40 @@ struct vec_io<bf16_t, 8> {
         for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
         *(uint4*)((uint16_t*)p + i) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    static __device__ __forceinline__ void decode(const uint4& t, float* v) {
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(w[k] << 16);
+            v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
 };
+// A/B switch (tools/ln_store_ab.sh): non-temporal stores for the residual-stream sum of the fused add + LayerNorm (it is not
+// read again before the next block's norm, 100+ MB later; its neighbour y is read by the very next GEMM)
+#ifndef HS_LN_NT_SUM
+#define HS_LN_NT_SUM 0
+#endif
+template <typename T, int VEC>
+__device__ __forceinline__ void store_stream(void* p, int64_t i, const float* v) {
+#if HS_LN_NT_SUM
+    if constexpr (std::is_same<T, bf16_t>::value && VEC == 8) {
+        typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
+        u32x4nt w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        __builtin_nontemporal_store(w, (u32x4nt*)((uint16_t*)p + i));
+        return;
+    }
+#endif
+    vec_io<T, VEC>::store(p, i, v);
+}
+
 template <typename T>
 struct vec_io<T, 1> {
     static __device__ __forceinline__ void load(const void* p, int64_t i, float* v) { v[0] = io<T>::load(p, i); }
     static __device__ __forceinline__ void store(void* p, int64_t i, const float* v) { io<T>::store(p, i, v[0]); }
+    static __device__ __forceinline__ void decode(const uint4&, float*) {}
 };
 
 // A wavefront normalises 64/LPR rows at a time: LPR lanes per row (a power of two >= the row's 16-byte chunk
@@ -92,21 +124,53 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int nchunk = width / VEC;
     const float inv_w = 1.f / (float)width;
+    // Software prefetch (16-byte chunks, one chunk per lane: rows up to 1024 bytes): the x (and add_in) chunks of the wave's NEXT rows are
+    // requested before the current rows are reduced.  One row group per wave kept only 1 KB per wave (32 KB per CU) in
+    // flight: the plain norm streamed at 3.0 TB/s where the fused add + norm, with two loads per lane, reached 4.4
+    // (tools/bench_ln.py on 400 MB tensors).
+    constexpr bool PF = (VEC * (int)sizeof(T) == 16) && ITERS == 1;  // (ITERS == 2 would drop the kernel from 4 to 3 waves per SIMD)
+    uint4 px[ITERS], pa[ITERS];
+    auto fetch = [&](int64_t r0) {
+        const int64_t row_l = r0 + rsub;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (row_l < rows && c < nchunk) {
+                const int64_t off = (row_l * width + (int64_t)c * VEC) * (int64_t)sizeof(T);
+                px[it] = *(const uint4*)((const char*)x + off);
+                if (add_in) pa[it] = *(const uint4*)((const char*)add_in + off);
+            }
+        }
+    };
+    if constexpr (PF) {
+        if (wave * RPW < rows) fetch(wave * RPW);
+    }
     for (int64_t row0 = wave * RPW; row0 < rows; row0 += nwaves * RPW) {
         const int64_t row = row0 + rsub;
         const bool live = row < rows;
         const int64_t base = row * width;
         const float rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
         float v[ITERS][VEC];
+        uint4 cx[ITERS], ca[ITERS];
+        if constexpr (PF) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                cx[it] = px[it];
+                ca[it] = pa[it];
+            }
+            if (row0 + nwaves * RPW < rows) fetch(row0 + nwaves * RPW);
+        }
         float sum = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
-                vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, v[it]);
+                if constexpr (PF) vec_io<T, VEC>::decode(cx[it], v[it]);
+                else vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, v[it]);
                 if (add_in) {  // s = x + rs*drop(add_in), rounded to the activation dtype exactly as a separate add would store it
                     float a2[VEC], l2[VEC], hi[VEC];
-                    vec_io<T, VEC>::load(add_in, base + (int64_t)c * VEC, a2);
+                    if constexpr (PF) vec_io<T, VEC>::decode(ca[it], a2);
+                    else vec_io<T, VEC>::load(add_in, base + (int64_t)c * VEC, a2);
                     if (lo_in) vec_io<T, VEC>::load(lo_in, base + (int64_t)c * VEC, l2);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
@@ -119,7 +183,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                         // un-rounded one (the backward re-normalises the stored tensor: a 2^-9 relative difference in xhat)
                         v[it][k] = lo_out ? full : hi[k];
                     }
-                    vec_io<T, VEC>::store(sum_out, base + (int64_t)c * VEC, hi);
+                    store_stream<T, VEC>(sum_out, base + (int64_t)c * VEC, hi);
                     if (lo_out) vec_io<T, VEC>::store(lo_out, base + (int64_t)c * VEC, l2);
                 } else if (dropping) {
 #pragma unroll
@@ -235,6 +299,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
                 float dyv[VEC];
+                // (a software prefetch of the next rows' chunks, as in the forward kernel, was measured to change nothing here:
+                // two loads per lane are in flight already, 4.7-5.1 TB/s)
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, xh[it]);
                 vec_io<T, VEC>::load(dy, base + (int64_t)c * VEC, dyv);
 #pragma unroll
