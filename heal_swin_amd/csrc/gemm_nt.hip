@@ -42,6 +42,12 @@ typedef unsigned int u32x2 __attribute__((__vector_size__(8)));    // the types 
 typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+// HS_GEMM_EPI_RING (A/B: 0 = register loads, one HBM round trip per row block behind a full vmcnt(0)): the epilogue's INPUT rows
+// (h for GELU', the residual) of the 256 x 256 tile go global -> LDS by DMA through two patches per wave inside the consumed stage
+// buffer, requested two row blocks ahead and waited for by COUNT
+#ifndef HS_GEMM_EPI_RING
+#define HS_GEMM_EPI_RING 1
+#endif
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RESID = 3 };
 __device__ constexpr uint32_t kOob = 0x7FFFFF00u;  // a byte offset outside every descriptor below
 constexpr int64_t kMaxRecords = 0x7FFFFE00;  // descriptors are clamped to this many bytes (tiles address < 2 GiB from their origin)
@@ -61,7 +67,21 @@ struct GemmParams {
     int tiles_n, tiles, per_xcd, blocks_per_xcd;
     float drop_p;
     uint64_t seed;
+#ifdef HS_GEMM_TRACE
+    uint64_t* trace;  // measurement build: (shader clock << 8 | event code) per wave of workgroups 0 and 9, kTraceCap entries each
+#endif
 };
+#ifdef HS_GEMM_TRACE
+constexpr int kTraceCap = 240;
+#endif
+
+// Vector-memory instructions younger than the input request of row block i at the moment the epilogue waits for it.  Issue
+// order: D_0, D_1, then per block b its 4 stores S_b and the 4 DMA instructions of D_{b+2} (loads and stores retire in order).
+constexpr int epi_younger_ops(int tm, int i) {
+    const int stores = i < 2 ? i : 1;
+    const int last_d = i + 1 < tm - 1 ? i + 1 : tm - 1;
+    return 4 * (stores + (last_d - i));
+}
 
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
@@ -73,7 +93,7 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
 // NSTAGE LDS stage buffers (the DMA runs NSTAGE - 1 k-steps ahead of the MFMAs); ALIAS: the epilogue's per-wave patches lie
 // inside the stage buffer that was just consumed (one extra barrier per tile) instead of in LDS of their own
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI, bool DROP>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 * 256) ? 1 : 2) gemm_nt_kernel(GemmParams p) {
+__global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 accumulators per wave along m / n
@@ -81,7 +101,14 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
     constexpr int AI = AB / 1024 / NW, BI = BB / 1024 / NW;  // 1-KB DMA instructions per wave and stage
     static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
     static_assert(!ALIAS || NW * 4096 <= STAGE, "patches do not fit a stage buffer");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096)];  // stages (+ epilogue patches)
+    constexpr bool HAS_IN = EPI == EPI_DGELU || EPI == EPI_RESID;
+    constexpr bool RING = HS_GEMM_EPI_RING && HAS_IN && ALIAS && TM == 4 && TN == 2 && STAGE >= NW * 8192;
+#ifdef HS_GEMM_TRACE
+    constexpr int TRACE_LDS = NW * kTraceCap * 8;
+#else
+    constexpr int TRACE_LDS = 0;
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096) + TRACE_LDS];  // stages (+ epilogue patches)
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,6 +180,20 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
     // ---- fragment addresses: operand row r (tile row), lane half h supplies k-chunk 2 ksub + h of the 16-deep MFMA step:
     // byte = R * 256 + ((((r & 1) * 8 + 2 ksub + h) ^ (R & 15)) << 4) = frag_base ^ (ksub << 5)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#ifdef HS_GEMM_TRACE
+    const bool tr_on = p.trace && (blockIdx.x == 0 || blockIdx.x == 9);
+    int tr_n = 0;
+    const uint32_t tr_base = lds0 + NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096) + wave * kTraceCap * 8;
+    auto TR = [&](int code) {
+        if (tr_on && tr_n < kTraceCap) {
+            const uint64_t t = (clock64() << 8) | (uint64_t)code;
+            if (lane == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(tr_base + tr_n * 8), "v"(t) : "memory");
+            ++tr_n;
+        }
+    };
+#else
+    auto TR = [&](int) {};
+#endif
     uint32_t a_frag[TM], b_frag[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -166,21 +207,12 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
     }
 
     f32x16 acc[TN][TM];
-    // (128 x 128 wave tile: the 256 accumulator registers are zeroed IN the AGPRs by an MFMA of zero operands -- as VGPR
-    // zeros on their way there they evicted every loop-invariant address)
-    const u32x4 zero_frag = {0u, 0u, 0u, 0u};
-    auto zero_acc = [&](f32x16& a) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(a) : "v"(zero_frag)); };
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if constexpr (TM == 4 && TN == 4) {
-                zero_acc(acc[j][i]);
-            } else {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-            }
-        }
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
     // ---- one k-step out of stage buffer `buf`: four 16-deep MFMA sub-steps, their fragment reads streamed ahead of them, and
     // the DMA pieces of a later k-step (into stage buffer `buf_next`, free since the barrier) issued behind each MFMA group
@@ -188,7 +220,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
         const uint32_t bo = buf * STAGE;
         // fragment reads are streamed one or two 16-deep sub-steps ahead of their MFMAs through a ring of NSET register sets
         // (two for the 128 x 64 wave tile, whose 128 accumulator registers leave no room for a third)
-        constexpr int NSET = (TM == 4 && TN == 2) ? 2 : 3;  // (the 4-wave 128 x 128 wave tile has 512 registers to itself)
+        constexpr int NSET = (TM == 4 && TN == 2) ? 2 : 3;
         u32x4 fa[NSET][TM], fb[NSET][TN];
         auto read_frags = [&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value, set = ks % NSET;
@@ -210,11 +242,6 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
                 asm volatile("s_waitcnt lgkmcnt(%6)"
                              : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1])
                              : "n"(left));
-            else if constexpr (TM == 4 && TN == 4)
-                asm volatile("s_waitcnt lgkmcnt(%8)"
-                             : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1]),
-                               "+v"(fb[set][2]), "+v"(fb[set][3])
-                             : "n"(left));
             else
                 static_assert(TM == 2 || TM == 4, "add a wait form for this wave tile");
         };
@@ -225,10 +252,6 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if constexpr (TM == 4 && TN == 4) {
-                        // 256 accumulator registers: pinned to the AGPR half of the file
-                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(fb[set][j]), "v"(fa[set][i]));
-                    } else
                         acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[set][j]),
                                                                             __builtin_bit_cast(bf16x8, fa[set][i]), acc[j][i], 0, 0, 0);
                 }
@@ -266,9 +289,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
     const uint32_t own_rel = wave * 4096 + l31 * 128 + 8 * half;     // + ((chunk ^ (l31 & 7)) << 4), chunk = 4 j + g
     const uint32_t row_rel = wave * 4096 + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + t * 1024: row lane/8 + 8 t
     auto epilogue = [&](int id, int buf_done) {
-        const uint32_t patch0 = lds0 + (ALIAS ? buf_done * STAGE : NSTAGE * STAGE);
-        const uint32_t own_addr = patch0 + own_rel, row_addr = patch0 + row_rel;
+        const uint32_t patch_off = ALIAS ? buf_done * STAGE : NSTAGE * STAGE;  // byte offset of the patch area inside smem
+        TR(10);
         if (ALIAS) __builtin_amdgcn_s_barrier();  // every wave is done reading the stage buffer the patches live in
+        TR(11);
         const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
         const int64_t m0 = (int64_t)tm * BM;
         const int n0 = tn * BN;
@@ -278,7 +302,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.c + m0 * p.n), 0, (int)(p.c ? cbytes : 0), 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.aux + m0 * p.n), 0, (int)(p.aux ? cbytes : 0), 0x00020000);
         const ElemRng rng(p.drop_p, p.seed);
-        const bool wide = (TN & 1) == 0 && (p.n & 7) == 0;  // whole-row-segment path
+        const bool wide = RING || ((TN & 1) == 0 && (p.n & 7) == 0);  // whole-row-segment path
         // a wave's BN / WN columns are handled 64 at a time (one patch pass per half jh: wave tiles of 64 or 128 columns)
         constexpr int JH = TN / 2 > 0 ? TN / 2 : 1, TJ = TN < 2 ? TN : 2;
 #pragma unroll
@@ -292,27 +316,57 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
                 const int n = ncol0 + j * 32 + 4 * half + 8 * g;
                 bias4[j][g] = (EPI != EPI_DGELU && p.bias && n < p.n) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        // row-lane view of a block: lane -> (row lane/8 + 8 t, 16-byte chunk lane % 8)
+        // row-lane view of a block: lane -> (row lane/8 + 8 t, 16-byte chunk lane % 8).  The per-lane part of the byte offset is ONE
+        // register; the row block / row group part is wave-uniform and rides in the instruction's scalar offset (it takes part
+        // in the descriptor's range check like the vector part).  Per-(i, t) vector offsets were hoisted out of the tile loop
+        // by the compiler and spilled: every reload inside the store sequence is a `s_waitcnt vmcnt(0)`, i.e. a full drain of
+        // the stores issued so far -- two of them cost the bias epilogue 5000 cycles per tile (tools/gemm_trace.py)
         const int rl_col = ncol0 + (lane & 7) * 8;
-        auto row_voff = [&](int i, int t) -> uint32_t {
-            const int r = wm * (BM / WM) + i * 32 + (lane >> 3) + 8 * t;
-            return rl_col < p.n ? (uint32_t)(r * n2 + rl_col * 2) : kOob;
+        const uint32_t rl_voff = rl_col < p.n ? (uint32_t)((lane >> 3) * n2 + rl_col * 2) : kOob;
+        auto row_soff = [&](int i, int t) -> int { return (wm * (BM / WM) + i * 32 + 8 * t) * n2; };
+        // input ring: row block i passes through patch slot i % 2 (slot s of wave w at patch_off + s * NW * 4096 + w * 4096).  A DMA
+        // lane writes LDS position lane * 16 of its 1-KB piece = (row lane / 8, physical chunk lane % 8), so it FETCHES logical
+        // chunk (lane % 8) ^ (lane / 8) of that row: the image the own-lane reads expect, every 128-byte row segment still one
+        // request of 8 adjacent lanes.  (Launched only with n % 8 == 0: hs_gemm_nt.)
+        const int in_col = ncol0 + (((lane & 7) ^ (lane >> 3)) << 3);
+        const uint32_t in_voff = in_col < p.n ? (uint32_t)((lane >> 3) * n2 + in_col * 2) : kOob;
+        auto request_in = [&](int i) {
+            unsigned char* base = smem + patch_off + (i & 1) * (NW * 4096) + wave * 4096;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + t * 1024), 16, in_voff, row_soff(i, t), 0, 0);
         };
+        if constexpr (RING) {
+            request_in(0);
+            request_in(1);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ml = wm * (BM / WM) + i * 32 + l31;
             // ---- input block (h or the residual) in the own-lane view
+            const uint32_t pbase = lds0 + patch_off + (RING ? (i & 1) * (NW * 4096) : 0);
+            const uint32_t own_addr = pbase + own_rel, row_addr = pbase + row_rel;
             u32x2 xin[TJ][4];
-            if (EPI == EPI_DGELU || EPI == EPI_RESID) {
+            if (HAS_IN) {
                 if (wide) {
-                    u32x4 rws[4];
+                    if constexpr (RING) {
+                        // this block's rows have landed once only the younger operations are outstanding
+                        constexpr int Y0 = epi_younger_ops(TM, 0), Y1 = epi_younger_ops(TM, 1), Y2 = epi_younger_ops(TM, 2),
+                                      Y3 = epi_younger_ops(TM, 3);
+                        if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y0) : "memory");
+                        else if (i == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y1) : "memory");
+                        else if (i == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y2) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y3) : "memory");
+                    } else {
+                        u32x4 rws[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        rws[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, row_voff(i, t), 0, 0));
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(row_addr), "v"(rws[0]) : "memory");
-                    asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(row_addr), "v"(rws[1]) : "memory");
-                    asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(row_addr), "v"(rws[2]) : "memory");
-                    asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(row_addr), "v"(rws[3]) : "memory");
+                        for (int t = 0; t < 4; ++t)
+                            rws[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, rl_voff, row_soff(i, t), 0));
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(row_addr), "v"(rws[0]) : "memory");
+                        asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(row_addr), "v"(rws[1]) : "memory");
+                        asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(row_addr), "v"(rws[2]) : "memory");
+                        asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(row_addr), "v"(rws[3]) : "memory");
+                    }
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
 #pragma unroll
@@ -342,19 +396,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
                     for (int g = 0; g < 4; ++g) {
                         const int n = ncol0 + j * 32 + 4 * half + 8 * g;
                         f32x16& a16 = acc[TJ * jh + j][i];
-                        // (AGPR-resident accumulators are read element by element HERE: left to itself the compiler copies all
-                        // 256 of them into VGPRs at the top of the epilogue and spills everything else)
-                        auto rd = [&](int r) -> float {
-                            if constexpr (TM == 4 && TN == 4) {
-                                float x;
-                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a16[r]));
-                                return x;
-                            } else {
-                                return a16[r];
-                            }
-                        };
-                        f32x2 v[2] = {f32x2{rd(4 * g), rd(4 * g + 1)} + f32x2{bias4[j][g].x, bias4[j][g].y},
-                                      f32x2{rd(4 * g + 2), rd(4 * g + 3)} + f32x2{bias4[j][g].z, bias4[j][g].w}};
+                        f32x2 v[2] = {f32x2{a16[4 * g], a16[4 * g + 1]} + f32x2{bias4[j][g].x, bias4[j][g].y},
+                                      f32x2{a16[4 * g + 2], a16[4 * g + 3]} + f32x2{bias4[j][g].z, bias4[j][g].w}};
                         const int64_t e0 = (m0 + ml) * p.n + n;  // element index of v[0].x in the [m, n] tensor (dropout counter)
                         if (EPI == EPI_GELU) {
                             o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
@@ -379,12 +422,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
                             }
                             o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
                         }
-                        if constexpr (!(TM == 4 && TN == 4)) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) a16[4 * g + r] = 0.f;
-                        } else if (g == 3) {
-                            zero_acc(a16);
-                        }
+                        for (int r = 0; r < 4; ++r) a16[4 * g + r] = 0.f;
                     }
             }
             // ---- outputs
@@ -403,7 +442,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rws[0]), "+v"(rws[1]), "+v"(rws[2]), "+v"(rws[3]));
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rws[t]), rs, row_voff(i, t), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rws[t]), rs, rl_voff, row_soff(i, t), 0);
                 } else {
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
@@ -420,9 +459,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
             } else {
                 emit(rc, o1);
             }
-            // 128 x 128 wave tile: the accumulators live in AGPRs and pass through VGPRs one row block at a time; without this
-            // fence the scheduler hoists all the copies to the front and spills the loop-invariant addresses of the main loop
-            if (TM == 4 && TN == 4) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RING) {
+                if (i + 2 < TM) request_in(i + 2);  // the patch is free again: its rows are in registers
+            }
+            TR(12 + i);
         }
         }
     };
@@ -455,14 +495,18 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
     }
     int buf = 0, buf_free = AHEAD;  // buffer being computed; buffer the next issue goes to
     bool drained = false;  // an epilogue's stores are in the queue: the counted wait below would be wrong
+    TR(0);
     while (true) {
+        TR(3);
         // this wave's loads of the current step have landed: everything older than the steps still allowed in flight
         if (AHEAD > 1 && issued == AHEAD && !drained)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PIECES_ALL) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         drained = false;
+        TR(1);
         __builtin_amdgcn_s_barrier();  // ... everyone's have; and everyone is done reading the buffer that is re-filled next
+        TR(2);
         const bool more = id_i < id_end;
         const bool last = ks_c + 1 == nk;
         compute(buf, more, kb_of(ks_i), buf_free);
@@ -484,6 +528,19 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 256 
             ++ks_c;
         }
     }
+#ifdef HS_GEMM_TRACE
+    if (tr_on) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        uint64_t* out = p.trace + ((blockIdx.x == 0 ? 0 : 1) * NW + wave) * kTraceCap;
+        for (int i = lane; i < kTraceCap; i += 64) {
+            u32x2 v = {0u, 0u};
+            if (i < tr_n) {
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tr_base + i * 8) : "memory");
+            }
+            out[i] = ((uint64_t)v[1] << 32) | v[0];
+        }
+    }
+#endif
 #endif
 }
 
@@ -524,6 +581,16 @@ namespace {
 int g_tile_variant = getenv("HS_GEMM_TILE") ? atoi(getenv("HS_GEMM_TILE")) : 0;  // A/B runs: 1 = 128x128, 2 = 256x128; 0 = heuristic
 }
 
+#ifdef HS_GEMM_TRACE
+namespace {
+uint64_t* g_trace = nullptr;
+}
+extern "C" int hs_gemm_nt_set_trace(void* buf) {
+    g_trace = (uint64_t*)buf;
+    return 0;
+}
+#endif
+
 extern "C" {
 
 int hs_gemm_nt_set_tile(int variant) {
@@ -552,6 +619,9 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     p.a2 = (const uint16_t*)a2; p.b2 = (const uint16_t*)b2; p.lda2 = lda2; p.ldb2 = ldb2; p.k2 = k2;
     p.bias = bias; p.c = (uint16_t*)c; p.aux = (uint16_t*)aux; p.m = m; p.n = n;
     p.drop_p = drop_p; p.seed = seed;
+#ifdef HS_GEMM_TRACE
+    p.trace = g_trace;
+#endif
     // Tile variants: 1 = 128x128 x 2 stages, own epilogue patches, two 4-wave workgroups per CU; 2 = 256x128 x 3 stages and
     // 3 = 256x256 x 2 stages: one 8-wave workgroup per CU, patches inside the consumed stage buffer.  Measured choice
     // (tools/bench_gemm_nt.py, profiles/r02_gemm_nt_vs_library.*): 256x128 x 3 is the all-round shape; 256x256 halves the
@@ -568,11 +638,12 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
         else
             variant = 2;
     }
+    // (the 256 x 256 kernels take an epilogue input through the DMA ring, which moves whole 16-byte chunks)
+    if (variant == 3 && (epilogue == EPI_DGELU || epilogue == EPI_RESID) && n % 8) variant = 2;
     hipStream_t st = (hipStream_t)stream;
     switch (variant) {
         case 2: return launch_tile<256, 128, 4, 2, 3, true>(p, epilogue, 1, st);
         case 3: return launch_tile<256, 256, 2, 4, 2, true>(p, epilogue, 1, st);
-        case 4: return launch_tile<256, 256, 2, 2, 2, true>(p, epilogue, 1, st);  // 4 waves x (128 x 128), one per SIMD, AGPR accumulators: A/B only
         default: return launch_tile<128, 128, 2, 2, 2, false>(p, epilogue, 2, st);
     }
 }

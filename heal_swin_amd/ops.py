@@ -625,6 +625,7 @@ OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice bel
 
 OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "256"))
 OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "1024"))
+OWN_BIAS_MAX_K = int(os.environ.get("HS_OWN_BIAS_MAX_K", "0"))  # A/B: > 0 sends every bias / residual product with k <= this to hs_gemm_nt
 
 
 def own_gemm_ok(epi, n, k, dtype, k2=0):
@@ -646,6 +647,8 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
         return kk <= OWN_DGELU_MAX_K
     if epi == _lib.HS_EPI_GELU:
         return kk <= OWN_GELU_MAX_K
+    if OWN_BIAS_MAX_K > 0:
+        return kk <= OWN_BIAS_MAX_K
     return kk <= 128 or n <= 128 or (n <= 256 and kk <= 256)
 
 

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--only", default="")
-    ap.add_argument("--variants", default="1,2,3,4")
+    ap.add_argument("--variants", default="1,2,3")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
     global VARIANTS
