@@ -273,3 +273,117 @@ def test_paper_config_full_size_logits_vs_oracle(dtype):
                               f"loss {loss:.6f} vs oracle {ref_loss:.6f}")
         assert_close(logits, ref_logits, LOGIT_TOL[dtype], tag + " logits")
         assert abs(loss - ref_loss) <= (1e-4 if dtype == torch.float32 else 2e-3) * max(1.0, abs(ref_loss))
+
+
+# ----------------------------------------------------------------------------- configs[2] at its FULL size: the BACKWARD
+def _param_groups(model):
+    """Parameter names grouped the way the network is staged: one finite-difference direction per group, so that an error in a
+    layer with small gradients is not hidden behind the layers with large ones."""
+    groups = {}
+    for n, _ in model.named_parameters():
+        parts = n.split(".")
+        if parts[0] == "layers":
+            key = f"enc{parts[1]}"
+        elif parts[0] == "decoder" and parts[1] == "layers_up":
+            key = f"up{parts[2]}"
+        elif parts[0] == "decoder":
+            key = "dec_rest"
+        else:
+            key = parts[0]
+        groups.setdefault(key, []).append(n)
+    return groups
+
+
+def test_headline_config_full_size_backward_is_the_derivative_of_the_forward():
+    """The oracle's autograd graph of HEAL-SWIN-B at nside 256 does not fit the host (tens of GB of score tensors), so the
+    full-size backward is pinned by the size-independent property that defines it: for a direction d in parameter space,
+    <grad L, d> equals the central difference (L(w + e d) - L(w - e d)) / 2e of the FORWARD -- which the test above pins to the
+    oracle at this size.  fp32 kernels (deterministic, 7e-7 forward accuracy), one direction per stage of the network (each
+    direction = that group's own gradient with random element weights, i.e. a strong signal that still weighs every element
+    differently), two step sizes.  Then the bf16 training kernels' gradients are compared with the fp32 ones tensor by tensor
+    at the bf16 gradient tolerance of the oracle tests."""
+    from heal_swin_amd.losses import seg_loss
+    CASES["_full"] = (B_CFG, 256, 12, 1, dict(shift_strategy="nest_roll", shift_size=32))
+    try:
+        model, cfg, spec, x, y = _setup_seeded("_full", 12)
+    finally:
+        del CASES["_full"]
+    model = model.to(DEV).train()  # (all drop rates are 0: train() only selects the training kernels)
+    xg, yg = x.to(DEV), y.to(DEV)
+
+    def loss_and_grads(dtype):
+        model.compute_dtype = dtype
+        model.zero_grad(set_to_none=True)
+        loss = seg_loss(model(xg), yg)
+        loss.backward()
+        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    def loss_only():
+        with torch.enable_grad():  # the training kernels, as in the differentiated pass (no_grad selects the fused no-grad path)
+            return float(seg_loss(model(xg), yg).detach().double())
+
+    loss32, g32 = loss_and_grads(torch.float32)
+    params = dict(model.named_parameters())
+    assert set(g32) == set(params), sorted(set(params) - set(g32))
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    model.compute_dtype = torch.float32
+    worst = ("", 0.0)
+    report, details = [], []
+    RHO0, MIN_DLOSS, FD_TOL = 8e-3, 8e-5, 1e-2
+    for key, names in _param_groups(model).items():
+        d = {n: g32[n] * (1.0 + 0.5 * torch.randn(g32[n].shape, generator=gen, device=DEV)) for n in names}
+        slope = float(sum((g32[n].double() * d[n].double()).sum() for n in names))
+        if slope <= 0:
+            continue
+        fds = []
+        orig = {n: params[n].detach().clone() for n in names}
+        pnorm = float(sum(orig[n].double().pow(2).sum() for n in names)) ** 0.5
+        dnorm = float(sum(d[n].double().pow(2).sum() for n in names)) ** 0.5
+        # steps: from 8e-3 |w_group| / |d| halving while the first-order change of the loss stays >= 8e-5 (the fp32 forward
+        # reproduces the loss to a few 1e-8 under such perturbations: observed); the truncation error of a central difference is
+        # O(eps^2) (third derivative) and large along a gradient direction of the deep stages, so the estimate is the Richardson
+        # combination (4 f(e/2) - f(e)) / 3 of the two smallest steps
+        eps = RHO0 * pnorm / dnorm
+        while len(fds) < 2 or (eps * slope >= MIN_DLOSS and len(fds) < 14):
+            vals = []
+            for sgn in (+1.0, -1.0):
+                with torch.no_grad():
+                    for n in names:
+                        params[n].copy_(orig[n]).add_(d[n], alpha=sgn * eps)
+                vals.append(loss_only())
+            fds.append((vals[0] - vals[1]) / (2 * eps))
+            eps *= 0.5
+        est = (4 * fds[-1] - fds[-2]) / 3
+        rel = [abs(est - slope) / slope, abs(fds[-1] - slope) / slope]
+        with torch.no_grad():
+            for n in names:
+                params[n].copy_(orig[n])
+        report.append(f"{key}={rel[0]:.1e}")
+        details.append(f"{key}: slope {slope:.3e} |w| {pnorm:.3e} |d| {dnorm:.3e} steps {len(fds)} last eps {2 * eps:.3e} "
+                       f"rel err Richardson {rel[0]:.1e} plain {rel[1]:.1e} all {[f'{abs(f - slope) / slope:.1e}' for f in fds]}")
+        if rel[0] > worst[1]:
+            worst = (key, rel[0])
+    import os
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/fullsize_bwd_fd_details.txt", "w") as fh:
+            fh.write("\n".join(details) + "\n")
+    # observed on MI355X: see the summary line; a wrong or missing term in any layer's backward shows as O(1)
+    assert worst[1] <= FD_TOL, (worst, details)
+    conftest.NOTES.append(f"configs2_B_nside256_bp12_FULL backward: |<grad, d> - central difference| / <grad, d> per group "
+                          f"(fp32 kernels, loss {loss32:.6f}): {' '.join(report)}; worst {worst[0]} {worst[1]:.1e}")
+
+    loss16, g16 = loss_and_grads(torch.bfloat16)
+    assert abs(loss16 - loss32) <= 2e-3 * max(1.0, abs(loss32)), (loss16, loss32)
+    rms, per = [], []
+    for n, g in g32.items():
+        e = errors(g16[n], g)
+        rms.append(e["rms_err"])
+        per.append((e["scale_err"], n))
+        floor = 1e-6 * float(g32[n.replace(".bias", ".weight")].abs().max()) if n.endswith(".bias") else 0.0
+        # relative-position bias tables: each entry sums dS over every window of the image in bf16-rounded terms of both signs
+        # (observed up to 4.9e-2 of the table's scale at this size; every other tensor <= 3e-2)
+        tol = 8e-2 if n.endswith("relative_position_bias_table") else GRAD_TOL[torch.bfloat16]
+        assert_close(g16[n], g, tol, f"full-size bf16 grad vs fp32 grad {n}", floor=floor + 1e-7)
+    per.sort(reverse=True)
+    conftest.NOTES.append(f"configs2_B_nside256_bp12_FULL backward: bf16 vs fp32 kernels, {len(g32)} parameter gradients, median rms "
+                          f"{sorted(rms)[len(rms) // 2]:.2e}; largest max|a-b|/max|b|: " + ", ".join(f"{n} {v:.2e}" for v, n in per[:6]))
