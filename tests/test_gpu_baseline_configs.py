@@ -294,33 +294,63 @@ def _param_groups(model):
     return groups
 
 
-def test_headline_config_full_size_backward_is_the_derivative_of_the_forward():
-    """The oracle's autograd graph of HEAL-SWIN-B at nside 256 does not fit the host (tens of GB of score tensors), so the
+FULL_BWD_CASES = {
+    # name: (arch, nside, base_pix, overrides, f_out, seed, compare bf16 gradients?, bf16 gradient bound)
+    "configs2_B_nside256_bp12": (B_CFG, 256, 12, dict(shift_strategy="nest_roll", shift_size=32), 12, 12, True, GRAD_TOL[torch.bfloat16]),
+    # the paper's run config (BASELINE configs[3]'s ring-shift permutation at nside 256): cosine attention with its normalisation
+    # Jacobian and d logit_scale, v2 norm placement, ring-shift tables and int64-mask semantics of all four stages
+    "paper_T_ring_cos_v2_nside256_bp8": (T_CFG, 256, 8, dict(shift_strategy="ring_shift", shift_size=4, use_cos_attn=True,
+                                                              use_v2_norm_placement=True), 12, 21, True, 0.15),
+    # BASELINE configs[4]: depth head (f_out = 1), masked L1 over the finite targets, fp32 only
+    "configs4_depth_T_nside256_bp8_fp32": (T_CFG, 256, 8, dict(shift_strategy="nest_roll", shift_size=32), 1, 31, False, None),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_BWD_CASES))
+def test_full_size_backward_is_the_derivative_of_the_forward(name):
+    """The oracle's autograd graph of a model at nside 256 does not fit the host (tens of GB of score tensors), so the
     full-size backward is pinned by the size-independent property that defines it: for a direction d in parameter space,
-    <grad L, d> equals the central difference (L(w + e d) - L(w - e d)) / 2e of the FORWARD -- which the test above pins to the
-    oracle at this size.  fp32 kernels (deterministic, 7e-7 forward accuracy), one direction per stage of the network (each
-    direction = that group's own gradient with random element weights, i.e. a strong signal that still weighs every element
-    differently), two step sizes.  Then the bf16 training kernels' gradients are compared with the fp32 ones tensor by tensor
-    at the bf16 gradient tolerance of the oracle tests."""
-    from heal_swin_amd.losses import seg_loss
-    CASES["_full"] = (B_CFG, 256, 12, 1, dict(shift_strategy="nest_roll", shift_size=32))
+    <grad L, d> equals the central difference (L(w + e d) - L(w - e d)) / 2e of the FORWARD -- which the tests above (and
+    tests/test_gpu_model.py for the depth head) pin to the oracle at this size.  fp32 kernels (deterministic, 7e-7 forward
+    accuracy), one direction per stage of the network (each direction = that group's own gradient with random element weights:
+    a strong signal that still weighs every element differently), Richardson-extrapolated over halving steps.  Then the bf16
+    training kernels' gradients are compared with the fp32 ones tensor by tensor at the bf16 gradient bound of the oracle tests."""
+    from heal_swin_amd import losses as L
+    arch, nside, bp, over, f_out, seed, with_bf16, bf16_tol = FULL_BWD_CASES[name]
+    CASES["_full"] = (arch, nside, bp, 1, over)
     try:
-        model, cfg, spec, x, y = _setup_seeded("_full", 12)
+        model, cfg, spec, x, y = _setup_seeded("_full", seed)
     finally:
         del CASES["_full"]
+    if f_out != 12:  # depth head: rebuild with f_out = 1, positive targets with ~4 % infinite (background) pixels (SURVEY 8d)
+        from heal_swin_amd.data_spec import DataSpec
+        from heal_swin_amd.models_torch import swin_hp_transformer as M
+        spec = dict(spec, f_out=f_out)
+        torch.manual_seed(seed)
+        model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), DataSpec(**spec))
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith("relative_position_bias_table"):
+                    p.normal_(0, 0.02)
+        g = torch.Generator().manual_seed(seed)
+        y = torch.randn(1, spec["dim_in"], generator=g).abs() * 10
+        y[torch.rand(1, spec["dim_in"], generator=g) < 0.04] = float("inf")
+        loss_fn = L.depth_l1_loss
+    else:
+        loss_fn = L.seg_loss
     model = model.to(DEV).train()  # (all drop rates are 0: train() only selects the training kernels)
     xg, yg = x.to(DEV), y.to(DEV)
 
     def loss_and_grads(dtype):
         model.compute_dtype = dtype
         model.zero_grad(set_to_none=True)
-        loss = seg_loss(model(xg), yg)
+        loss = loss_fn(model(xg), yg)
         loss.backward()
-        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
     def loss_only():
         with torch.enable_grad():  # the training kernels, as in the differentiated pass (no_grad selects the fused no-grad path)
-            return float(seg_loss(model(xg), yg).detach().double())
+            return float(loss_fn(model(xg), yg).detach().double())
 
     loss32, g32 = loss_and_grads(torch.float32)
     params = dict(model.named_parameters())
@@ -329,7 +359,8 @@ def test_headline_config_full_size_backward_is_the_derivative_of_the_forward():
     model.compute_dtype = torch.float32
     worst = ("", 0.0)
     report, details = [], []
-    RHO0, MIN_DLOSS, FD_TOL = 8e-3, 8e-5, 1e-2
+    # (the masked L1 loss of the depth head has a kink per pixel: a few predictions change sign inside a step; observed <= 9.7e-3)
+    RHO0, MIN_DLOSS, FD_TOL = 8e-3, 8e-5, (1e-2 if f_out == 12 else 2e-2)
     for key, names in _param_groups(model).items():
         d = {n: g32[n] * (1.0 + 0.5 * torch.randn(g32[n].shape, generator=gen, device=DEV)) for n in names}
         slope = float(sum((g32[n].double() * d[n].double()).sum() for n in names))
@@ -365,25 +396,37 @@ def test_headline_config_full_size_backward_is_the_derivative_of_the_forward():
             worst = (key, rel[0])
     import os
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/fullsize_bwd_fd_details.txt", "w") as fh:
+        with open(f"gpurun_out/fullsize_bwd_fd_details_{name}.txt", "w") as fh:
             fh.write("\n".join(details) + "\n")
     # observed on MI355X: see the summary line; a wrong or missing term in any layer's backward shows as O(1)
     assert worst[1] <= FD_TOL, (worst, details)
-    conftest.NOTES.append(f"configs2_B_nside256_bp12_FULL backward: |<grad, d> - central difference| / <grad, d> per group "
+    conftest.NOTES.append(f"{name}_FULL backward: |<grad, d> - central difference| / <grad, d> per group "
                           f"(fp32 kernels, loss {loss32:.6f}): {' '.join(report)}; worst {worst[0]} {worst[1]:.1e}")
 
+    if not with_bf16:
+        return
     loss16, g16 = loss_and_grads(torch.bfloat16)
     assert abs(loss16 - loss32) <= 2e-3 * max(1.0, abs(loss32)), (loss16, loss32)
-    rms, per = [], []
+    rms, per, ls = [], [], []
     for n, g in g32.items():
         e = errors(g16[n], g)
         rms.append(e["rms_err"])
         per.append((e["scale_err"], n))
+        if n.endswith("logit_scale"):  # one noisy scalar per head: judged as a direction over all heads, as in the oracle test
+            ls.append((g16[n].float().reshape(-1), g.reshape(-1)))
+            continue
         floor = 1e-6 * float(g32[n.replace(".bias", ".weight")].abs().max()) if n.endswith(".bias") else 0.0
         # relative-position bias tables: each entry sums dS over every window of the image in bf16-rounded terms of both signs
-        # (observed up to 4.9e-2 of the table's scale at this size; every other tensor <= 3e-2)
-        tol = 8e-2 if n.endswith("relative_position_bias_table") else GRAD_TOL[torch.bfloat16]
-        assert_close(g16[n], g, tol, f"full-size bf16 grad vs fp32 grad {n}", floor=floor + 1e-7)
+        # (observed up to 4.9e-2 of the table's scale on the headline model; every other tensor <= 3e-2)
+        tol = max(bf16_tol, 8e-2) if n.endswith("relative_position_bias_table") else bf16_tol
+        assert_close(g16[n], g, tol, f"{name} full-size bf16 grad vs fp32 grad {n}", floor=floor + 1e-7)
+    if ls:
+        a16 = torch.cat([t[0] for t in ls]).double()
+        b32 = torch.cat([t[1] for t in ls]).double()
+        cos = float((a16 * b32).sum() / (a16.norm() * b32.norm()).clamp_min(1e-300))
+        conftest.NOTES.append(f"{name}_FULL backward: d logit_scale over {a16.numel()} heads, bf16 vs fp32 kernels: cosine {cos:.4f}, "
+                              f"||a-b||/||b|| {float((a16 - b32).norm() / b32.norm().clamp_min(1e-300)):.3f}")
+        assert cos >= 0.99, cos
     per.sort(reverse=True)
-    conftest.NOTES.append(f"configs2_B_nside256_bp12_FULL backward: bf16 vs fp32 kernels, {len(g32)} parameter gradients, median rms "
+    conftest.NOTES.append(f"{name}_FULL backward: bf16 vs fp32 kernels, {len(g32)} parameter gradients, median rms "
                           f"{sorted(rms)[len(rms) // 2]:.2e}; largest max|a-b|/max|b|: " + ", ".join(f"{n} {v:.2e}" for v, n in per[:6]))
