@@ -268,6 +268,9 @@ class LayerNormFn(torch.autograd.Function):
         """res_lo / want_lo: compensated residual stream of the v2 placement (y = residual + LN(x) IS the stream): the stream
         operand is residual + res_lo, and with want_lo the call returns (y, y_lo) with y_lo the rounding remainder of y."""
         _require_gpu(x, weight, bias, residual)
+        # an output nobody differentiates (the alias, or the non-differentiable y_lo) reaches backward as None instead of a
+        # zero-filled activation-sized tensor -- which would also select the residual-gradient form of the kernel
+        ctx.set_materialize_grads(False)
         x = x.contiguous()
         width = x.shape[-1]
         rows = x.numel() // width
@@ -298,6 +301,7 @@ class LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, g, mean, rstd, None if extras is None else extras[0])
         ctx.meta = (rows, width, dt, residual is not None, extras)
         ctx.params = (weight, bias)
+        ctx.second_is_alias = bool(passthrough)  # (with want_lo the second output is the non-differentiable remainder)
         # passthrough (plain norm only): also hand x back as an alias for a second use (the block's residual connection); its
         # gradient then arrives here with dy and is added inside the backward kernel instead of by a separate elementwise add
         assert not passthrough or (extras is None and residual is None)
@@ -311,6 +315,8 @@ class LayerNormFn(torch.autograd.Function):
         x, g, mean, rstd, rs = ctx.saved_tensors
         rows, width, dt, has_res, extras = ctx.meta
         weight, bias = ctx.params
+        if not ctx.second_is_alias:
+            dx_alias = None
         if dy is None:  # only the alias was used downstream
             return dx_alias, None, None, None, None, None, None, None
         dy = dy.contiguous()
