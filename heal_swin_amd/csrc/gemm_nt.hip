@@ -48,6 +48,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef HS_GEMM_EPI_RING
 #define HS_GEMM_EPI_RING 1
 #endif
+// HS_GEMM_EXP (measurement builds only, tools/gemm_overlap_premise.sh): bit 1 = the second half of the waves stores one output
+// tile's worth of bytes (into `aux`, which the bias epilogue does not use) from INSIDE the k-steps, a 1-KB instruction per wave and
+// 16-deep sub-step: the skeleton of an epilogue whose stores ride under the next tile's MFMAs (profiles/r03_gemm_overlap_premise.txt:
+// it costs 65-75 % of what the same bytes cost in a serial epilogue)
+#ifndef HS_GEMM_EXP
+#define HS_GEMM_EXP 0
+#endif
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RESID = 3 };
 __device__ constexpr uint32_t kOob = 0x7FFFFF00u;  // a byte offset outside every descriptor below
 constexpr int64_t kMaxRecords = 0x7FFFFE00;  // descriptors are clamped to this many bytes (tiles address < 2 GiB from their origin)
@@ -92,13 +99,17 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
 
 // NSTAGE LDS stage buffers (the DMA runs NSTAGE - 1 k-steps ahead of the MFMAs); ALIAS: the epilogue's per-wave patches lie
 // inside the stage buffer that was just consumed (one extra barrier per tile) instead of in LDS of their own
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI, bool DROP>
+// FAST (k and k2 multiples of 64: no K tail): the operand DMA of a k-step is issued by the FIRST HALF of the waves alone (twice the
+// pieces each, their k offset in the scalar operand), the other half runs MFMAs and fragment reads only -- 8-16 % on the 256 x 256
+// tile at every shape (profiles/r03_gemm_role_split.txt); the addressing form alone changes nothing
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI, bool DROP, bool FAST>
 __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 accumulators per wave along m / n
     constexpr int AB = BM * 128, BB = BN * 128, STAGE = AB + BB;
-    constexpr int AI = AB / 1024 / NW, BI = BB / 1024 / NW;  // 1-KB DMA instructions per wave and stage
+    constexpr int IW = FAST ? NW / 2 : NW;                   // waves that issue the operand DMA
+    constexpr int AI = AB / 1024 / IW, BI = BB / 1024 / IW;  // 1-KB DMA instructions per issuing wave and stage
     static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
     static_assert(!ALIAS || NW * 4096 <= STAGE, "patches do not fit a stage buffer");
     constexpr bool HAS_IN = EPI == EPI_DGELU || EPI == EPI_RESID;
@@ -123,15 +134,20 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
 
     // ---- DMA lane mapping: LDS position q (16-B units inside a tile) = (super-row R = q / 16, physical chunk q % 16);
     // logical chunk = physical ^ (R & 15); tile row = 2 R + (logical >> 3), 16-byte column chunk = logical & 7
-    int a_row[AI], a_col[AI], b_row[BI], b_col[BI];
+    // (FAST keeps FOUR offsets per operand whatever the piece count: pieces j and j + 4 of a wave differ by 32 tile rows and
+    // nothing else -- the swizzle term depends on j % 4 only -- and that part rides in the scalar offset together with k)
+    constexpr bool SC = FAST;  // scalar-offset form of the DMA addresses
+    static_assert(!FAST || (AI % 4 == 0 && BI % 4 == 0), "FAST: whole groups of four pieces per issuing wave");
+    constexpr int AJ = SC ? 4 : AI, BJ = SC ? 4 : BI;
+    int a_row[AJ], a_col[AJ], b_row[BJ], b_col[BJ];
 #pragma unroll
-    for (int j = 0; j < AI; ++j) {
+    for (int j = 0; j < AJ; ++j) {
         const int q = (wave * AI + j) * 64 + lane, R = q >> 4, lc = (q & 15) ^ (R & 15);
         a_row[j] = 2 * R + (lc >> 3);
         a_col[j] = (lc & 7) << 4;
     }
 #pragma unroll
-    for (int j = 0; j < BI; ++j) {
+    for (int j = 0; j < BJ; ++j) {
         const int q = (wave * BI + j) * 64 + lane, R = q >> 4, lc = (q & 15) ^ (R & 15);
         b_row[j] = 2 * R + (lc >> 3);
         b_col[j] = (lc & 7) << 4;
@@ -140,8 +156,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     // ---- issue side: the (tile, K segment) the DMA currently reads from.  Descriptors, row offsets and the row length are
     // rebuilt only when the issue cursor enters a new tile or segment, not per k-step.
     __amdgpu_buffer_rsrc_t ra, rb;
-    int a_off[AI], b_off[BI];  // byte offset of this lane's (row, chunk) inside the tile, k-step 0
+    int a_off[AJ], b_off[BJ];  // byte offset of this lane's (row, chunk) inside the tile, k-step 0
     int kseg = 0;              // bytes of a row of the current segment
+    int a_ld32 = 0, b_ld32 = 0;  // (FAST) bytes of 32 operand rows
     auto retarget = [&](int id, bool s2) {
         const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
         const int64_t m0 = (int64_t)tm * BM;
@@ -156,16 +173,32 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         ra = __builtin_amdgcn_make_buffer_rsrc((void*)(ap + m0 * lda), 0, (int)abytes, 0x00020000);
         rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + (int64_t)n0 * ldb), 0, (int)bbytes, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < AI; ++j) a_off[j] = a_row[j] * ((int)lda * 2) + a_col[j];
+        for (int j = 0; j < AJ; ++j) a_off[j] = a_row[j] * ((int)lda * 2) + a_col[j];
 #pragma unroll
-        for (int j = 0; j < BI; ++j) b_off[j] = b_row[j] * ((int)ldb * 2) + b_col[j];
+        for (int j = 0; j < BJ; ++j) b_off[j] = b_row[j] * ((int)ldb * 2) + b_col[j];
+        a_ld32 = (int)lda * 64;
+        b_ld32 = (int)ldb * 64;
     };
     // DMA pieces [first, first + count) of the AI + BI pieces of one k-step (byte offset kb inside the row) into stage `buf`
     auto issue_pieces = [&](int kb, int buf, auto first_c, auto count_c) {
         constexpr int first = decltype(first_c)::value, count = decltype(count_c)::value;
+        if (IW < NW && wave >= IW) return;
         unsigned char* base = smem + buf * STAGE;
 #pragma unroll
         for (int q = first; q < first + count; ++q) {
+            if constexpr (SC) {
+            // (k % 64 == 0: no K-tail predicate; the k offset and the 32-row group ride in the scalar operand, which takes
+            // part in the descriptor's range check like the vector part)
+            if (q < AI) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (wave * AI + q) * 1024), 16, (uint32_t)a_off[q % AJ],
+                                                         kb + (q >> 2) * a_ld32, 0, 0);
+            } else {
+                const int j = q - AI;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + AB + (wave * BI + j) * 1024), 16, (uint32_t)b_off[j % BJ],
+                                                         kb + (j >> 2) * b_ld32, 0, 0);
+            }
+            } else {
+
             if (q < AI) {
                 const uint32_t voff = kb + a_col[q] < kseg ? (uint32_t)(a_off[q] + kb) : kOob;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (wave * AI + q) * 1024), 16, voff, 0, 0, 0);
@@ -173,6 +206,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                 const int j = q - AI;
                 const uint32_t voff = kb + b_col[j] < kseg ? (uint32_t)(b_off[j] + kb) : kOob;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + AB + (wave * BI + j) * 1024), 16, voff, 0, 0, 0);
+            }
             }
         }
     };
@@ -213,6 +247,15 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+#if HS_GEMM_EXP & 2
+    // the store stream of the experiment: this workgroup's share of `aux`, 1 KB per instruction
+    int64_t exp_total = p.m * (int64_t)p.n * 2;
+    exp_total = exp_total > kMaxRecords ? kMaxRecords : exp_total;
+    const __amdgpu_buffer_rsrc_t rexp = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, (int)(p.aux ? exp_total : 0), 0x00020000);
+    const uint32_t exp_share = (uint32_t)((exp_total / gridDim.x) & ~(int64_t)1023);
+    uint32_t exp_pos = 0;  // bytes of the share written so far (wraps)
+    const uint32_t exp_base = blockIdx.x * exp_share;
+#endif
 
     // ---- one k-step out of stage buffer `buf`: four 16-deep MFMA sub-steps, their fragment reads streamed ahead of them, and
     // the DMA pieces of a later k-step (into stage buffer `buf_next`, free since the barrier) issued behind each MFMA group
@@ -256,6 +299,15 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                                                                             __builtin_bit_cast(bf16x8, fa[set][i]), acc[j][i], 0, 0, 0);
                 }
             if (decltype(cnt_c)::value > 0 && prefetch) issue_pieces(kb_next, buf_next, first_c, cnt_c);
+#if HS_GEMM_EXP & 2
+            if (wave >= NW / 2) {
+                const uint32_t off = exp_pos + (uint32_t)(wave - NW / 2) * 1024u;
+                const uint32_t so = off + 1024u <= exp_share ? exp_base + off : kOob;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, fa[set][0]), rexp, lane * 16, so, 0);
+            }
+            exp_pos += (NW / 2) * 1024u;
+            if (exp_pos >= exp_share) exp_pos = 0;
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         using I0 = std::integral_constant<int, 0>;
@@ -499,7 +551,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     while (true) {
         TR(3);
         // this wave's loads of the current step have landed: everything older than the steps still allowed in flight
-        if (AHEAD > 1 && issued == AHEAD && !drained)
+        if (IW < NW && wave >= IW) {
+            // (this wave issues no operand DMA -- nothing of its own to wait for; its epilogue stores are fire-and-forget, and
+            // an epilogue waits for its own input loads itself)
+        } else if (AHEAD > 1 && issued == AHEAD && !drained)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PIECES_ALL) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -544,7 +599,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, bool FAST>
 int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
     const int tiles_m = (int)((p.m + BM - 1) / BM);
     p.tiles_n = (p.n + BN - 1) / BN;
@@ -556,7 +611,7 @@ int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
     p.blocks_per_xcd = p.per_xcd < resident ? p.per_xcd : resident;
     const dim3 grid((unsigned)(8 * p.blocks_per_xcd)), block(WM * WN * 64);
     const bool drop = p.drop_p > 0.f;
-#define HS_GEMM_LAUNCH(E, D) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, E, D>), grid, block, 0, s, p)
+#define HS_GEMM_LAUNCH(E, D) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NSTAGE, ALIAS, E, D, FAST>), grid, block, 0, s, p)
     switch (epi) {
         case EPI_BIAS: HS_GEMM_LAUNCH(EPI_BIAS, false); break;
         case EPI_GELU:
@@ -641,10 +696,13 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     // (the 256 x 256 kernels take an epilogue input through the DMA ring, which moves whole 16-byte chunks)
     if (variant == 3 && (epilogue == EPI_DGELU || epilogue == EPI_RESID) && n % 8) variant = 2;
     hipStream_t st = (hipStream_t)stream;
+    // role-separated DMA issue (FAST) wherever there is no K tail; HS_GEMM_FAST=0 keeps the symmetric kernels for A/B runs
+    static const bool fast_on = !(getenv("HS_GEMM_FAST") && atoi(getenv("HS_GEMM_FAST")) == 0);
+    const bool fast = fast_on && k % 64 == 0 && k2 % 64 == 0;
     switch (variant) {
-        case 2: return launch_tile<256, 128, 4, 2, 3, true>(p, epilogue, 1, st);
-        case 3: return launch_tile<256, 256, 2, 4, 2, true>(p, epilogue, 1, st);
-        default: return launch_tile<128, 128, 2, 2, 2, false>(p, epilogue, 2, st);
+        case 2: return fast ? launch_tile<256, 128, 4, 2, 3, true, true>(p, epilogue, 1, st) : launch_tile<256, 128, 4, 2, 3, true, false>(p, epilogue, 1, st);
+        case 3: return fast ? launch_tile<256, 256, 2, 4, 2, true, true>(p, epilogue, 1, st) : launch_tile<256, 256, 2, 4, 2, true, false>(p, epilogue, 1, st);
+        default: return launch_tile<128, 128, 2, 2, 2, false, false>(p, epilogue, 2, st);
     }
 }
 

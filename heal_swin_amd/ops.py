@@ -629,7 +629,7 @@ def _cast_param(p, dtype):
 OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice below; "0": library GEMMs only; "1": own kernel wherever legal
 
 
-OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "256"))
+OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "4096"))
 OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "1024"))
 OWN_BIAS_MAX_K = int(os.environ.get("HS_OWN_BIAS_MAX_K", "0"))  # A/B: > 0 sends every bias / residual product with k <= this to hs_gemm_nt
 
