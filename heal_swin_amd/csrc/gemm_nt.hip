@@ -685,10 +685,15 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     // 128x128 when the launch would not fill the chip otherwise.  (hs_gemm_nt_set_tile forces a variant for A/B runs.)
     int variant = g_tile_variant;
     if (!variant) {
-        const int64_t tiles2 = ((m + 255) / 256) * ((n + 127) / 128);
+        const int64_t tiles2 = ((m + 255) / 256) * ((n + 127) / 128), tiles3 = ((m + 255) / 256) * ((n + 255) / 256);
         if (tiles2 < 256)
             variant = 1;
         else if ((epilogue == EPI_GELU || epilogue == EPI_DGELU) ? n >= 512 : (n >= 1024 && k + k2 >= 512))
+            variant = 3;
+        else if (n >= 256 && tiles3 >= 768 && k % 64 == 0 && k2 % 64 == 0)
+            // with the role-separated DMA issue (FAST) the 256 x 256 tile also wins the narrower outputs (profiles/
+            // r03_gemm_role_split.txt: s0 qkv 365 vs 392 us, s1 qkv 207 vs 258, s2 proj 60 vs 66) as long as its tiles
+            // fill three resident rounds (stage-3 proj / fc2, 384 tiles = 1.5 rounds, stay on the 256 x 128 tile)
             variant = 3;
         else
             variant = 2;
