@@ -26,6 +26,7 @@
 #include "window_attn.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace hs {
 namespace {
@@ -942,6 +943,530 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
     }
 }
 
+// ================================================================================================ backward, second form (round 4)
+// Same 40 MFMAs per (window, head), re-arranged around three observations of profiles/r03_attn_bwd_ablation.txt (the kernel is
+// issue / barrier bound: 34.5 VALU instructions per MFMA, 5 barriers per window, 72 % of its time left with all global traffic
+// removed):
+//  * TRANSPOSED output products.  dQ^T = K^^T dS'^T, dK^^T = Q^T dS', dV^T = dO^T P are the same MFMAs with the A and B operands
+//    exchanged; the accumulator then has lane = token, registers = 4 consecutive features x 4 groups.  bf16 packing gives 8-byte
+//    pieces, one v_permlane32_swap per dword pairs them into 16 contiguous bytes, and each lane stores its token's row piece
+//    straight to HBM: no 2-byte LDS writes, no staging tiles, no read-back pass, no barrier around it.
+//  * dK / dV split by KEY tile instead of by query half.  Wave t of a head writes the P / dS' rows of its 32 queries to two LDS
+//    scratches; after one barrier wave t forms dK^T and dV^T of key tile t over ALL 64 queries (4 + 4 MFMAs, as before).  The
+//    fp32 partial-sum exchange (8 KB per wave and window, two barriers) is gone.
+//  * 32-bit addressing through per-image buffer descriptors, window counters advanced without 64-bit divisions, the
+//    relative-position bias kept in registers (pre-multiplied by log2 e) for the whole launch, the label scan done once per
+//    workgroup by a ballot.  Three barriers per window.
+// Loads of window i+1 are requested right after window i's staging barrier and claimed (s_waitcnt) in front of window i's last
+// stores, so no wait ever covers a store's round trip.
+struct LdsLayoutBwd2 {
+    // per head: Q | K^ | V | dO tiles (4096 each) | dS' scratch | P scratch ([64 q][64 key] bf16, padded rows); then per-row scalars
+    int scr_s, scr_p, head, qinv, kinv, lab, flag, total;
+    __host__ __device__ explicit LdsLayoutBwd2(int hg) {
+        scr_s = 4 * kTileBytes;
+        scr_p = scr_s + kPsBytes;
+        head = scr_p + kPsBytes;  // 33792 bytes per head
+        qinv = hg * head;
+        kinv = qinv + hg * kWs * 4;
+        lab = kinv + hg * kWs * 4;
+        flag = lab + kWs;
+        total = flag + 16;
+    }
+};
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// 16 accumulator values of a transposed output tile (lane = token, register r = feature (r&3) + 8*(r>>2) + 4*half) -> two
+// 16-byte pieces of the token's 64-byte head slice: lanes < 32 hold bytes [0,16) and [32,48), lanes >= 32 bytes [16,32) and [48,64)
+__device__ __forceinline__ void pack_rows_t(const float (&v)[16], u32x4& p0, u32x4& p1) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    // groups m = 0..3 are dwords (2m, 2m+1); pair (0,1) and pair (2,3): vdst = group m, src = group m+1
+#pragma unroll
+    for (int m = 0; m < 4; m += 2)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const auto r = __builtin_amdgcn_permlane32_swap(w[2 * m + d], w[2 * m + 2 + d], false, false);
+            w[2 * m + d] = r[0];
+            w[2 * m + 2 + d] = r[1];
+        }
+    p0 = u32x4{w[0], w[1], w[2], w[3]};
+    p1 = u32x4{w[4], w[5], w[6], w[7]};
+}
+
+template <int HG, bool DROP, bool COS>
+__global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, float* __restrict__ dbias_part,
+                                                                 float* __restrict__ dscale_part, int slots, int groups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LdsLayoutBwd2 L(HG);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
+    const int by = blocal % groups, bx = bxcd + 8 * (blocal / groups);
+    if (bx >= slots) return;
+    const int g = wv >> 1, t = wv & 1;  // head inside the group; query half (score phase) = key tile (dK / dV phase)
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = by * HG + g;
+    const int C = p.C, nH = p.nH;
+    const int N = (int)p.N;
+    const int nW = N / kWs;
+    const int total_windows = p.B * nW;  // B * N < 2^31 is checked by the dispatcher
+    constexpr bool cosine = COS;
+    // register budget (256 at two waves per SIMD): the plain instantiation keeps the bias in registers for the whole launch and
+    // requests the next rows right behind the staging barrier; the cosine / dropout ones re-read the bias per window from L2
+    // and request the rows once the score accumulators are dead
+    // (cosine + dropout: only behind the dQ stores, when the P / dS' operands are dead as well)
+    constexpr bool BIASREG = !COS && !DROP, EARLY = !COS && !DROP, LATEST = COS && DROP;
+    const float hscale = p.head_scale[h];
+    const bool has_idx = p.idx != nullptr;
+    const int roll = (int)p.roll;
+    const uint32_t c3b = 3u * (uint32_t)C * 2u, cb = (uint32_t)C * 2u;  // bytes per token row of qkv / dout
+    const uint32_t img_qkv = (uint32_t)N * c3b, img_do = (uint32_t)N * cb;  // bytes per image (< 2^31, dispatcher)
+
+    unsigned char* my = smem + g * L.head;
+    unsigned char* q_tile = my;
+    unsigned char* k_tile = my + kTileBytes;
+    unsigned char* v_tile = my + 2 * kTileBytes;
+    unsigned char* do_tile = my + 3 * kTileBytes;
+    unsigned char* scr_s = my + L.scr_s;
+    unsigned char* scr_p = my + L.scr_p;
+    float* qinv_s = (float*)(smem + L.qinv);
+    float* kinv_s = (float*)(smem + L.kinv);
+    unsigned char* lab_s = smem + L.lab;
+    uint32_t* flag_s = (uint32_t*)(smem + L.flag);
+    const int qq = t * 32 + l31;  // this lane's query row (score phase) and key row (dK / dV phase)
+
+    // staging geometry: 128*HG threads move 32 rows x HG*64 B per pass, 2 passes per tile.  (Re-derived from an opaque copy
+    // of the thread id wherever it is used: hoisted, the per-thread addresses would be pinned in registers for the whole kernel.)
+#define HS_STAGE_GEOMETRY                                                                          \
+    int tid_o = tid;                                                                               \
+    asm volatile("" : "+v"(tid_o));                                                                \
+    const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;          \
+    const uint32_t colb = (uint32_t)(by * HG * kHd + sc * 8) * 2u;                                 \
+    unsigned char* st = smem + sg * L.head;                                                        \
+    (void)scc;                                                                                     \
+    (void)st;                                                                                      \
+    (void)colb;
+
+    auto image_rsrc = [&](const void* base, uint32_t bytes_per_image, int b_l) {
+        const uint64_t a = (uint64_t)base + (uint64_t)b_l * bytes_per_image;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)bytes_per_image, 0x00020000);
+    };
+    // natural-order token (inside its image) of shifted row j, without a table
+    auto rolled = [&](int j) {
+        const int s = j + roll;
+        return s >= N ? s - N : s;
+    };
+
+    // bias (x log2 e) and bias gradient of this wave's 32 queries, in the S^T accumulator layout, for the whole launch
+    float bias2[2][16], dbacc[2][16];
+    float dscale_acc = 0.f;
+
+    // ---- software pipeline state: rows of the NEXT window (registers), token rows of the one after (table mode)
+    u32x4 ldq[2], ldk[2], ldv[2], lddo[2];
+    int tok_ld[2] = {0, 0}, tok_st = 0;  // token rows (inside the image) of the rows in flight: this thread's 2 staging rows, its store row
+    int tok_ld2[2] = {0, 0}, tok_st2 = 0;  // table mode: the same for the window after (requested one window ahead of the rows)
+    float lse_next = 0.f;
+    unsigned lab_next = 0;
+
+    int b_cur = bx / nW, w_cur = bx - b_cur * nW;  // (one 32-bit division per launch)
+    auto advance = [&](int& b_l, int& w_l) {
+        w_l += slots;
+        while (w_l >= nW) {
+            w_l -= nW;
+            ++b_l;
+        }
+    };
+    auto request_tokens = [&](int w_l) {  // table mode: token rows of window w_l -> tok_ld2 / tok_st2 (loads)
+        HS_STAGE_GEOMETRY
+        const int j_l = w_l * kWs;
+        tok_ld2[0] = p.idx[j_l + srow];
+        tok_ld2[1] = p.idx[j_l + 32 + srow];
+        tok_st2 = p.idx[j_l + qq];
+    };
+    auto issue_loads = [&](int b_l, int w_l) {
+        HS_STAGE_GEOMETRY
+        const int j_l = w_l * kWs;
+        if (has_idx) {
+            tok_ld[0] = tok_ld2[0];
+            tok_ld[1] = tok_ld2[1];
+            tok_st = tok_st2;
+        } else {
+            tok_ld[0] = rolled(j_l + srow);
+            tok_ld[1] = rolled(j_l + 32 + srow);
+            tok_st = rolled(j_l + qq);
+        }
+        const __amdgpu_buffer_rsrc_t rq = image_rsrc(p.qkv, img_qkv, b_l), rd = image_rsrc(p.dout, img_do, b_l);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint32_t vo = (uint32_t)tok_ld[rb] * c3b + colb;
+            ldq[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, 0);
+            ldk[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, cb, 0);
+            ldv[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 2 * cb, 0);
+            lddo[rb] = __builtin_amdgcn_raw_buffer_load_b128(rd, (uint32_t)tok_ld[rb] * cb + colb, 0, 0);
+        }
+        lse_next = p.lse[((int64_t)b_l * nH + h) * N + j_l + qq];
+        if (p.labels && wv == 0) lab_next = p.labels[j_l + lane];
+    };
+    // every value the prefetch produced is claimed at ONE point (the compiler puts its s_waitcnt vmcnt there); see the loop
+    auto claim = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            asm volatile("" : "+v"(ldq[rb]), "+v"(ldk[rb]), "+v"(ldv[rb]), "+v"(lddo[rb]));
+        }
+        asm volatile("" : "+v"(lse_next), "+v"(lab_next), "+v"(tok_ld2[0]), "+v"(tok_ld2[1]), "+v"(tok_st2));
+    };
+    auto lds_barrier = [&]() {  // orders LDS traffic only: global loads and stores stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    if (bx < total_windows) {
+        if (has_idx) {
+            request_tokens(w_cur);
+            asm volatile("" : "+v"(tok_ld2[0]), "+v"(tok_ld2[1]), "+v"(tok_st2));
+        }
+        issue_loads(b_cur, w_cur);
+        int b_n = b_cur, w_n = w_cur;
+        advance(b_n, w_n);
+        if (has_idx && b_n < p.B) request_tokens(w_n);
+    }
+    const bool has_bias = p.bias != nullptr;
+    const float* bsrc = has_bias ? p.bias + ((int64_t)h * kWs + qq) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
+    const float bscale = has_bias ? kLog2e : 0.f;  // (unconditional loads: without a bias they read qkv bytes and are zeroed here)
+    if constexpr (BIASREG) {
+        float4 b4[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) b4[kt][rg] = *(const float4*)(bsrc + kt * 32 + 8 * rg);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                bias2[kt][4 * rg] = b4[kt][rg].x * bscale;
+                bias2[kt][4 * rg + 1] = b4[kt][rg].y * bscale;
+                bias2[kt][4 * rg + 2] = b4[kt][rg].z * bscale;
+                bias2[kt][4 * rg + 3] = b4[kt][rg].w * bscale;
+            }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
+    claim();  // (once in front of the loop: inside it the rows are never "pending" at the loop header)
+
+    for (int wi = bx; wi < total_windows; wi += slots) {
+        const int b = b_cur, w = w_cur;
+        const int j0 = w * kWs;
+        HS_STAGE_GEOMETRY
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // (per-lane LDS addresses are re-derived per window instead of pinned in ~40 registers)
+        const int half = lane_o >> 5, l31 = lane_o & 31;
+        const int qq = t * 32 + l31;
+        const int lane = lane_o;
+        const int tok_store = tok_st;  // this lane's token row of the current window
+        const float lse_cur = lse_next;
+
+        // ------------------------------------------------------------ stage q, k^, v, dO; norms; label scan
+        if (p.labels && wv == 0) {
+            lab_s[lane] = (unsigned char)lab_next;
+            const unsigned first = __builtin_amdgcn_readfirstlane(lab_next);
+            const bool any = __ballot(lab_next != first) != 0ull;
+            if (lane == 0) flag_s[0] = any ? 1u : 0u;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = rb * 32 + srow;
+            const u32x4 vq = ldq[rb];
+            u32x4 vk = ldk[rb];
+            if (cosine) {
+                float sq = 0.f, sk = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sq += bf_lo(vq[i]) * bf_lo(vq[i]) + bf_hi(vq[i]) * bf_hi(vq[i]);
+                    sk += bf_lo(vk[i]) * bf_lo(vk[i]) + bf_hi(vk[i]) * bf_hi(vk[i]);
+                }
+                sq += __shfl_xor(sq, 1, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                sk += __shfl_xor(sk, 1, 64);
+                sk += __shfl_xor(sk, 2, 64);
+                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vk[i] = pack_bf16(bf_lo(vk[i]) * kinv, bf_hi(vk[i]) * kinv);
+                if (scc == 0) {
+                    qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+                    kinv_s[sg * kWs + row] = kinv;
+                }
+            }
+            const int off = swz(row, scc);
+            *(u32x4*)(st + off) = vq;
+            *(u32x4*)(st + kTileBytes + off) = vk;
+            *(u32x4*)(st + 2 * kTileBytes + off) = ldv[rb];
+            *(u32x4*)(st + 3 * kTileBytes + off) = lddo[rb];
+        }
+        lds_barrier();  // A: tiles, norms, labels visible
+
+        // ------------------------------------------------------------ request the next window's rows (a whole window ahead)
+        int b_n = b_cur, w_n = w_cur;
+        advance(b_n, w_n);
+        auto prefetch = [&]() {
+            if (wi + slots < total_windows) {
+                issue_loads(b_n, w_n);
+                if (has_idx) {
+                    int b_nn = b_n, w_nn = w_n;
+                    advance(b_nn, w_nn);
+                    if (b_nn < p.B) request_tokens(w_nn);
+                }
+            }
+        };
+        if constexpr (EARLY) prefetch();
+        b_cur = b_n;
+        w_cur = w_n;
+        const bool mixed = p.labels ? (flag_s[0] != 0u) : false;  // wave-uniform (one LDS word)
+
+        // ------------------------------------------------------------ S^T = K^ Q^T and dP^T = V dO^T for this wave's 32 queries
+        float4 biasv[2][4];
+        if constexpr (!BIASREG) {  // in flight (L2) during the MFMAs below
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) biasv[kt][rg] = *(const float4*)(bsrc + kt * 32 + 8 * rg);
+        }
+        f32x16 accS[2], accP[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accS[kt][r] = 0.f;
+                accP[kt][r] = 0.f;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 2 + half;
+            const bf16x8 qf = *(const bf16x8*)(q_tile + swz(qq, chunk));
+            const bf16x8 df = *(const bf16x8*)(do_tile + swz(qq, chunk));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int off = swz(kt * 32 + l31, chunk);
+                const bf16x8 kf = *(const bf16x8*)(k_tile + off);
+                const bf16x8 vf = *(const bf16x8*)(v_tile + off);
+                accS[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, accS[kt], 0, 0, 0);
+                accP[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df, accP[kt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ------------------------------------------------------------ P, dS' (fp32); bias / scale gradients
+        const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
+        const float fqn = hscale * qinv;  // d s / d (q . k^)
+        const float fq2 = fqn * kLog2e;
+        const float nlse2 = -lse_cur * kLog2e;
+        const DropRng rng(p, ((int64_t)b * nH + h) * N + j0 + qq);
+        if constexpr (!BIASREG) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    bias2[kt][4 * rg] = biasv[kt][rg].x * bscale;
+                    bias2[kt][4 * rg + 1] = biasv[kt][rg].y * bscale;
+                    bias2[kt][4 * rg + 2] = biasv[kt][rg].z * bscale;
+                    bias2[kt][4 * rg + 3] = biasv[kt][rg].w * bscale;
+                }
+        }
+        float dsum = 0.f, s_pds = 0.f, s_ps = 0.f;
+        // pass 1: P and the (dropout-masked) dP in place; D = sum_k P dP over this lane's 32 keys
+        auto pass1 = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            int mylab = 0;
+            if constexpr (MASKED) mylab = lab_s[qq];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sraw = accS[kt][r];
+                    float tt = fmaf(sraw, fq2, bias2[kt][r]);
+                    if constexpr (MASKED)
+                        if (lab_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != mylab) tt += kMaskLog2;
+                    const float pr = __builtin_amdgcn_exp2f(tt + nlse2);
+                    float dpv = accP[kt][r];
+                    if constexpr (DROP) dpv *= rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                    dsum = fmaf(pr, dpv, dsum);
+                    if constexpr (COS) {
+                        const float ps = pr * sraw;
+                        s_ps += ps;
+                        s_pds = fmaf(ps, dpv, s_pds);
+                    }
+                    accS[kt][r] = pr;
+                    accP[kt][r] = dpv;
+                    if constexpr (COS)
+                        if ((r & 7) == 7) asm volatile("" : "+v"(dsum), "+v"(s_ps), "+v"(s_pds));
+                }
+        };
+        if (mixed)
+            pass1(std::true_type{});
+        else
+            pass1(std::false_type{});
+        dsum += __shfl_xor(dsum, 32, 64);  // the other 32 keys of this query
+        if constexpr (COS) dscale_acc = fmaf(qinv, s_pds - dsum * s_ps, dscale_acc);
+        // pass 2: dS = P o (dP - D); bias gradient; bf16 operands  pS = dS' = dS * f_q,  pP = (dropped) P
+        uint32_t pS[2][8], pP[2][8];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float ds2[2], pp2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * i + e;
+                    const float pr = accS[kt][r];
+                    const float dsv = pr * (accP[kt][r] - dsum);
+                    dbacc[kt][r] += dsv;
+                    ds2[e] = dsv * fqn;
+                    if constexpr (DROP)
+                        pp2[e] = pr * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                    else
+                        pp2[e] = pr;
+                }
+                pS[kt][i] = pack_bf16x2(ds2[0], ds2[1]);
+                pP[kt][i] = pack_bf16x2(pp2[0], pp2[1]);
+            }
+        // rows of this lane's query in the two scratches: keys kt*32 + 8*rg + 4*half .. +3 are registers 4rg..4rg+3
+        {
+            unsigned char* rs = scr_s + qq * kPsLd + 8 * half;
+            unsigned char* rp = scr_p + qq * kPsLd + 8 * half;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    *(uint2*)(rs + (kt * 32 + 8 * rg) * 2) = make_uint2(pS[kt][2 * rg], pS[kt][2 * rg + 1]);
+                    *(uint2*)(rp + (kt * 32 + 8 * rg) * 2) = make_uint2(pP[kt][2 * rg], pP[kt][2 * rg + 1]);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!EARLY && !LATEST) prefetch();
+
+        const __amdgpu_buffer_rsrc_t rdq = image_rsrc(p.dqkv, img_qkv, b);
+        const uint32_t vst = (uint32_t)tok_store * c3b + (uint32_t)(h * kHd) * 2u + 16u * half;
+        // ------------------------------------------------------------ dQ^T = K^^T dS'^T for this wave's 32 queries (lane = query)
+        {
+            f32x16 xt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xt[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kt = ks >> 1, c = ks & 1;
+                const int kbase = kt * 32 + c * 16 + 4 * half;
+                const bf16x8 ak = join(tr_read_tile(k_tile, kbase, lane), tr_read_tile(k_tile, kbase + 8, lane));
+                const u32x4 bw = {pS[kt][4 * c], pS[kt][4 * c + 1], pS[kt][4 * c + 2], pS[kt][4 * c + 3]};
+                xt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, __builtin_bit_cast(bf16x8, bw), xt, 0, 0, 0);
+            }
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = xt[r];
+            if (cosine) {  // dq = X - q^ (q^ . X): features 8m + 4*half .. +3 of the raw q row are one 8-byte LDS read
+                float qv[16];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint2 wq = *(const uint2*)(q_tile + swz(qq, m) + 8 * half);
+                    qv[4 * m] = bf_lo(wq.x);
+                    qv[4 * m + 1] = bf_hi(wq.x);
+                    qv[4 * m + 2] = bf_lo(wq.y);
+                    qv[4 * m + 3] = bf_hi(wq.y);
+                }
+                float pq = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pq = fmaf(x[r], qv[r], pq);
+                pq += __shfl_xor(pq, 32, 64);
+                pq *= qinv * qinv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = fmaf(-qv[r], pq, x[r]);
+            }
+            u32x4 p0, p1;
+            pack_rows_t(x, p0, p1);
+            __builtin_amdgcn_raw_buffer_store_b128(p0, rdq, vst, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, rdq, vst + 32u, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LATEST) prefetch();
+        lds_barrier();  // B: both scratches complete
+
+        // ------------------------------------------------------------ dK^^T = Q^T dS' and dV^T = dO^T P for key tile t, all 64 queries
+        u32x4 k0, k1, v0, v1;
+        {
+            f32x16 kt_acc, vt_acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                kt_acc[r] = 0.f;
+                vt_acc[r] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {  // 16 queries per step: half 0 -> +0..7, half 1 -> +8..15
+                const int qrow = ks * 16 + 8 * half;
+                const bf16x8 aq = join(tr_read_tile(q_tile, qrow, lane), tr_read_tile(q_tile, qrow + 4, lane));
+                const bf16x8 bs = join(tr_read_scratch(scr_s, qrow, t, lane), tr_read_scratch(scr_s, qrow + 4, t, lane));
+                kt_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bs, kt_acc, 0, 0, 0);
+                const bf16x8 ao = join(tr_read_tile(do_tile, qrow, lane), tr_read_tile(do_tile, qrow + 4, lane));
+                const bf16x8 bp = join(tr_read_scratch(scr_p, qrow, t, lane), tr_read_scratch(scr_p, qrow + 4, t, lane));
+                vt_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, bp, vt_acc, 0, 0, 0);
+            }
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = kt_acc[r];
+            if (cosine) {  // dk = (dK^ - k^ (k^ . dK^)) / |k|   (the K tile holds the normalised rows)
+                float kv[16];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint2 wk = *(const uint2*)(k_tile + swz(qq, m) + 8 * half);
+                    kv[4 * m] = bf_lo(wk.x);
+                    kv[4 * m + 1] = bf_hi(wk.x);
+                    kv[4 * m + 2] = bf_lo(wk.y);
+                    kv[4 * m + 3] = bf_hi(wk.y);
+                }
+                float pk = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pk = fmaf(x[r], kv[r], pk);
+                pk += __shfl_xor(pk, 32, 64);
+                const float kinv = kinv_s[g * kWs + qq];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = fmaf(-kv[r], pk, x[r]) * kinv;
+            }
+            pack_rows_t(x, k0, k1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = vt_acc[r];
+            pack_rows_t(x, v0, v1);
+        }
+        // The prefetched rows (requested a whole window ago, long landed) are claimed HERE, in front of the last stores: vmcnt
+        // counts loads and stores together and the two complete out of order, so a wait for the rows at the top of the next
+        // window would also wait for these stores' round trip.
+        claim();
+        __builtin_amdgcn_raw_buffer_store_b128(k0, rdq, vst, cb, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(k1, rdq, vst + 32u, cb, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v0, rdq, vst, 2 * cb, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v1, rdq, vst + 32u, 2 * cb, 0);
+        lds_barrier();  // C: every wave is done with the tiles and the scratches
+    }
+
+    // ------------------------------------------------------------ per-workgroup partial parameter gradients
+    if (dbias_part) {
+        float* dst = dbias_part + ((int64_t)bx * nH + h) * kWs * kWs + (int64_t)qq * kWs;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                *(float4*)(dst + kt * 32 + 8 * rg + 4 * half) =
+                    make_float4(dbacc[kt][4 * rg], dbacc[kt][4 * rg + 1], dbacc[kt][4 * rg + 2], dbacc[kt][4 * rg + 3]);
+    }
+    if (dscale_part) {  // two waves per head: [slot][head][t]
+        const float tot = wave_sum(dscale_acc);
+        if (lane == 0) dscale_part[((int64_t)bx * nH + h) * 2 + t] = tot;
+    }
+}
+#undef HS_STAGE_GEOMETRY
+
 // dst[e] += sum over parts of src[part][e]
 __global__ void reduce_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1017,6 +1542,33 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     return HS_OK;
 }
 
+template <int HG, bool DROP, bool COS>
+int launch_bwd2(const AttnParams& p, float* workspace, hipStream_t stream) {
+    const LdsLayoutBwd2 L(HG);
+    auto kern = attn_bwd2_kernel<HG, DROP, COS>;
+    static bool configured = false;
+    if (!configured) {
+        HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        configured = true;
+    }
+    const int groups = p.nH / HG, slots = bwd_slots(p, HG);
+    float* dbias_part = p.dbias ? workspace : nullptr;
+    float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
+    const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part, slots, groups);
+    HS_LAUNCH_CHECK("attn_bwd2");
+    if (dbias_part) {
+        const int64_t n = (int64_t)p.nH * kWs * kWs;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dbias_part, p.dbias, slots, n);
+        HS_LAUNCH_CHECK("reduce dbias partials");
+    }
+    if (dscale_part) {
+        hipLaunchKernelGGL(reduce_scale_partials_kernel, dim3(1), dim3(256), 0, stream, dscale_part, p.dhead_scale, slots, p.nH);
+        HS_LAUNCH_CHECK("reduce dscale partials");
+    }
+    return HS_OK;
+}
+
 int pick_head_group(int nH) {
     static const int forced = getenv("HS_ATTN_FWD_HG") ? atoi(getenv("HS_ATTN_FWD_HG")) : 0;  // A/B runs
     if (forced >= 1 && forced <= 4 && nH % forced == 0) return forced;
@@ -1047,7 +1599,8 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
 
 bool attn_mfma_supported(const AttnParams& p, int dtype) {
     // 16-byte vector access needs 8-element aligned columns: C % 8 == 0 holds since C = 32 * nH
-    return dtype == HS_BF16 && p.Ws == kWs && p.hd == kHd;
+    // (per-image buffer descriptors: one image of qkv must stay below 2 GiB)
+    return dtype == HS_BF16 && p.Ws == kWs && p.hd == kHd && p.N * 3 * (int64_t)p.C * 2 < (1ll << 31);
 }
 
 int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
@@ -1068,6 +1621,15 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
 int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream) {
     if (!workspace) return fail(HS_ERR_INVALID_ARG, "the MFMA backward needs a workspace (hs_window_attn_bwd_workspace)");
     const bool drop = p.drop_p > 0.f, cos = (p.flags & HS_ATTN_COSINE) != 0;
+    static const int version = getenv("HS_ATTN_BWD_V") ? atoi(getenv("HS_ATTN_BWD_V")) : 2;  // A/B runs: 1 = the round-3 kernel
+    if (version == 2) {
+        if (pick_head_group_bwd(p.nH) == 2) {
+            if (cos) return drop ? launch_bwd2<2, true, true>(p, workspace, stream) : launch_bwd2<2, false, true>(p, workspace, stream);
+            return drop ? launch_bwd2<2, true, false>(p, workspace, stream) : launch_bwd2<2, false, false>(p, workspace, stream);
+        }
+        if (cos) return drop ? launch_bwd2<1, true, true>(p, workspace, stream) : launch_bwd2<1, false, true>(p, workspace, stream);
+        return drop ? launch_bwd2<1, true, false>(p, workspace, stream) : launch_bwd2<1, false, false>(p, workspace, stream);
+    }
     if (pick_head_group_bwd(p.nH) == 2) {
         if (cos) return drop ? launch_bwd<2, true, true>(p, workspace, stream) : launch_bwd<2, false, true>(p, workspace, stream);
         return drop ? launch_bwd<2, true, false>(p, workspace, stream) : launch_bwd<2, false, false>(p, workspace, stream);
