@@ -1467,6 +1467,345 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
 }
 #undef HS_STAGE_GEOMETRY
 
+// ================================================================================================ forward, second form (round 4)
+// The forward with the output product transposed like the backward's (O^T = V^T P^T: lane = query, registers = features, each
+// lane stores two 16-byte pieces of its token's head slice per query tile): no 2-byte LDS writes of O, no read-back pass, no
+// barrier around it; V is staged ROW-major like Q and K (one 16-byte LDS write instead of eight 2-byte transposing ones) and its
+// B fragments come from ds_read_b64_tr_b16.  32-bit addressing through per-image buffer descriptors; two barriers per window.
+struct LdsLayoutFwd2 {
+    int head, qinv, lab, flag, total;  // per head: Q | K^ | V tiles (4096 each)
+    __host__ __device__ explicit LdsLayoutFwd2(int hg) {
+        head = 3 * kTileBytes;
+        qinv = hg * head;
+        lab = qinv + hg * kWs * 4;
+        flag = lab + kWs;
+        total = flag + 16;
+    }
+};
+
+template <int HG, bool DROP>
+__global__ void __launch_bounds__(64 * HG, 2) attn_fwd2_kernel(AttnParams p, int slots, int groups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LdsLayoutFwd2 L(HG);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // head inside the group
+    const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
+    const int by = blocal % groups, bx = bxcd + 8 * (blocal / groups);
+    if (bx >= slots) return;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = by * HG + g;
+    const int C = p.C, nH = p.nH;
+    const int N = (int)p.N;
+    const int nW = N / kWs;
+    const int total_windows = p.B * nW;
+    const bool cosine = (p.flags & HS_ATTN_COSINE) != 0;
+    const float hscale = p.head_scale[h];
+    const bool has_idx = p.idx != nullptr;
+    const int roll = (int)p.roll;
+    const uint32_t c3b = 3u * (uint32_t)C * 2u, cb = (uint32_t)C * 2u;
+    const uint32_t img_qkv = (uint32_t)N * c3b, img_out = (uint32_t)N * cb;
+
+    unsigned char* q_tile = smem + g * L.head;
+    unsigned char* k_tile = q_tile + kTileBytes;
+    unsigned char* v_tile = q_tile + 2 * kTileBytes;
+    float* qinv_s = (float*)(smem + L.qinv);
+    unsigned char* lab_s = smem + L.lab;
+    uint32_t* flag_s = (uint32_t*)(smem + L.flag);
+
+    // staging geometry: 12 steps = 3 parts (q, k, v) x 4 row blocks of 16 rows; a step moves 16 rows x HG*64 B.  (Re-derived
+    // from an opaque copy of the thread id wherever it is used instead of being pinned in registers for the whole kernel.)
+#define HS_STAGE_GEOMETRY                                                                          \
+    int tid_o = tid;                                                                               \
+    asm volatile("" : "+v"(tid_o));                                                                \
+    const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;          \
+    const uint32_t colb = (uint32_t)(by * HG * kHd + sc * 8) * 2u;                                 \
+    unsigned char* st = smem + sg * L.head;                                                        \
+    const int l31 = tid_o & 31;                                                                    \
+    (void)scc;                                                                                     \
+    (void)st;                                                                                      \
+    (void)colb;                                                                                    \
+    (void)l31;
+
+    auto image_rsrc = [&](const void* base, uint32_t bytes_per_image, int b_l) {
+        const uint64_t a = (uint64_t)base + (uint64_t)b_l * bytes_per_image;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)bytes_per_image, 0x00020000);
+    };
+    auto rolled = [&](int j) {
+        const int s = j + roll;
+        return s >= N ? s - N : s;
+    };
+
+    u32x4 ld[3][4];
+    int tok_ld[4] = {0, 0, 0, 0}, tok_st[2] = {0, 0};
+    int tok_ld2[4] = {0, 0, 0, 0}, tok_st2[2] = {0, 0};  // table mode: token rows of the window after the one in flight
+    unsigned lab_next = 0;
+    int b_cur = bx / nW, w_cur = bx - b_cur * nW;
+    auto advance = [&](int& b_l, int& w_l) {
+        w_l += slots;
+        while (w_l >= nW) {
+            w_l -= nW;
+            ++b_l;
+        }
+    };
+    auto request_tokens = [&](int w_l) {
+        HS_STAGE_GEOMETRY
+        const int j_l = w_l * kWs;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) tok_ld2[rb] = p.idx[j_l + rb * 16 + srow];
+        tok_st2[0] = p.idx[j_l + l31];
+        tok_st2[1] = p.idx[j_l + 32 + l31];
+    };
+    auto issue_loads = [&](int b_l, int w_l) {
+        HS_STAGE_GEOMETRY
+        const int j_l = w_l * kWs;
+        if (has_idx) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) tok_ld[rb] = tok_ld2[rb];
+            tok_st[0] = tok_st2[0];
+            tok_st[1] = tok_st2[1];
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) tok_ld[rb] = rolled(j_l + rb * 16 + srow);
+            tok_st[0] = rolled(j_l + l31);
+            tok_st[1] = rolled(j_l + 32 + l31);
+        }
+        const __amdgpu_buffer_rsrc_t rq = image_rsrc(p.qkv, img_qkv, b_l);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const uint32_t vo = (uint32_t)tok_ld[rb] * c3b + colb;
+            ld[0][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, 0);
+            ld[1][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, cb, 0);
+            ld[2][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 2 * cb, 0);
+        }
+        if (p.labels && g == 0) lab_next = p.labels[j_l + lane];
+    };
+    auto claim = [&]() {
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) asm volatile("" : "+v"(ld[part][rb]));
+        asm volatile("" : "+v"(lab_next), "+v"(tok_ld2[0]), "+v"(tok_ld2[1]), "+v"(tok_ld2[2]), "+v"(tok_ld2[3]), "+v"(tok_st2[0]),
+                     "+v"(tok_st2[1]));
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    if (bx < total_windows) {
+        if (has_idx) {
+            request_tokens(w_cur);
+            asm volatile("" : "+v"(tok_ld2[0]), "+v"(tok_ld2[1]), "+v"(tok_ld2[2]), "+v"(tok_ld2[3]), "+v"(tok_st2[0]), "+v"(tok_st2[1]));
+        }
+        issue_loads(b_cur, w_cur);
+        int b_n = b_cur, w_n = w_cur;
+        advance(b_n, w_n);
+        if (has_idx && b_n < p.B) request_tokens(w_n);
+    }
+
+    // relative-position bias of this head (x log2 e), in the S^T accumulator layout: tile (kt, qt), register r holds query
+    // qt*32 + l31, key kt*32 + (r&3) + 8*(r>>2) + 4*half.  Unconditional loads (without a bias they read qkv bytes, zeroed below).
+    float biasr[2][2][16];
+    {
+        const bool has_bias = p.bias != nullptr;
+        const float* bsrc = has_bias ? p.bias + ((int64_t)h * kWs + l31) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
+        const float bs = has_bias ? kLog2e : 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            float4 b4[2][4];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) b4[qt][m] = *(const float4*)(bsrc + (has_bias ? qt * 32 * kWs : 0) + kt * 32 + 8 * m);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    biasr[kt][qt][4 * m] = b4[qt][m].x * bs;
+                    biasr[kt][qt][4 * m + 1] = b4[qt][m].y * bs;
+                    biasr[kt][qt][4 * m + 2] = b4[qt][m].z * bs;
+                    biasr[kt][qt][4 * m + 3] = b4[qt][m].w * bs;
+                }
+        }
+    }
+    claim();
+
+    for (int wi = bx; wi < total_windows; wi += slots) {
+        const int b = b_cur, w = w_cur;
+        const int j0 = w * kWs;
+        const int tq0 = tok_st[0], tq1 = tok_st[1];
+        HS_STAGE_GEOMETRY
+        const int half = tid_o >> 5 & 1;
+        const int lane = tid_o & 63;
+
+        // ------------------------------------------------------------ stage q, k^, v (row-major, swizzled); norms; label scan
+        if (p.labels && g == 0) {
+            lab_s[lane] = (unsigned char)lab_next;
+            const unsigned first = __builtin_amdgcn_readfirstlane(lab_next);
+            const bool any = __ballot(lab_next != first) != 0ull;
+            if (lane == 0) flag_s[0] = any ? 1u : 0u;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int row = rb * 16 + srow;
+            const u32x4 vq = ld[0][rb];
+            u32x4 vk = ld[1][rb];
+            if (cosine) {
+                float sq = 0.f, sk = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sq += bf_lo(vq[i]) * bf_lo(vq[i]) + bf_hi(vq[i]) * bf_hi(vq[i]);
+                    sk += bf_lo(vk[i]) * bf_lo(vk[i]) + bf_hi(vk[i]) * bf_hi(vk[i]);
+                }
+                sq += __shfl_xor(sq, 1, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                sk += __shfl_xor(sk, 1, 64);
+                sk += __shfl_xor(sk, 2, 64);
+                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vk[i] = pack_bf16(bf_lo(vk[i]) * kinv, bf_hi(vk[i]) * kinv);
+                if (scc == 0) qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+            }
+            const int off = swz(row, scc);
+            *(u32x4*)(st + off) = vq;
+            *(u32x4*)(st + kTileBytes + off) = vk;
+            *(u32x4*)(st + 2 * kTileBytes + off) = ld[2][rb];
+        }
+        lds_barrier();  // A
+
+        int b_n = b_cur, w_n = w_cur;
+        advance(b_n, w_n);
+        auto prefetch = [&]() {
+            if (wi + slots < total_windows) {
+                issue_loads(b_n, w_n);
+                if (has_idx) {
+                    int b_nn = b_n, w_nn = w_n;
+                    advance(b_nn, w_nn);
+                    if (b_nn < p.B) request_tokens(w_nn);
+                }
+            }
+        };
+        // (the dropout instantiation is at the register limit during the softmax: it requests the rows behind it)
+        if constexpr (!DROP) prefetch();
+        b_cur = b_n;
+        w_cur = w_n;
+        const bool mixed = p.labels ? (flag_s[0] != 0u) : false;
+
+        // ------------------------------------------------------------ S^T = K^ Q^T
+        f32x16 acc[2][2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 kf[2], qf[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int row = tt * 32 + l31, chunk = ks * 2 + half;
+                kf[tt] = *(const bf16x8*)(k_tile + swz(row, chunk));
+                qf[tt] = *(const bf16x8*)(q_tile + swz(row, chunk));
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qf[qt], ks == 0 ? zero16 : acc[kt][qt], 0, 0, 0);
+        }
+
+        // ------------------------------------------------------------ softmax over the keys of each query (log2 domain)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qq = qt * 32 + l31;
+            const float fq = hscale * kLog2e * (cosine ? qinv_s[g * kWs + qq] : 1.f);
+            float m = -INFINITY;
+            if (!mixed) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float tv = fmaf(acc[kt][qt][r], fq, biasr[kt][qt][r]);
+                        acc[kt][qt][r] = tv;
+                        m = fmaxf(m, tv);
+                    }
+            } else {  // rare: windows cut by the shift boundary
+                const int my = lab_s[qq];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float tv = fmaf(acc[kt][qt][r], fq, biasr[kt][qt][r]);
+                        if (lab_s[key] != my) tv += kMaskLog2;
+                        acc[kt][qt][r] = tv;
+                        m = fmaxf(m, tv);
+                    }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(acc[kt][qt][r] - m);
+                    acc[kt][qt][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 32, 64);
+            const float linv = 1.f / l;
+            if constexpr (DROP) {
+                const DropRng rng(p, ((int64_t)b * nH + h) * N + j0 + qq);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[kt][qt][r] *= linv * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv;
+            }
+            if (p.lse && half == 0) p.lse[((int64_t)b * nH + h) * N + j0 + qq] = (m + __builtin_amdgcn_logf(l)) * kLn2;
+        }
+
+        if constexpr (DROP) prefetch();
+        // ------------------------------------------------------------ O^T = V^T P^T (lane = query, registers = features)
+        f32x16 o[2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kt = ks >> 1, c = ks & 1;
+            const int kbase = kt * 32 + c * 16 + 4 * half;  // slots 0..3 -> keys kbase.., slots 4..7 -> kbase+8..
+            const bf16x8 vf = join(tr_read_tile(v_tile, kbase, lane), tr_read_tile(v_tile, kbase + 8, lane));
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                bf16x8 pf;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)acc[kt][qt][8 * c + jj];
+                o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ks == 0 ? zero16 : o[qt], 0, 0, 0);
+            }
+        }
+        u32x4 o00, o01, o10, o11;
+        {
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = o[0][r];
+            pack_rows_t(x, o00, o01);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = o[1][r];
+            pack_rows_t(x, o10, o11);
+        }
+        // the next window's rows are claimed in front of the stores (see the backward)
+        claim();
+        const __amdgpu_buffer_rsrc_t ro = image_rsrc(p.out, img_out, b);
+        const uint32_t hb = (uint32_t)(h * kHd) * 2u + 16u * half;
+        __builtin_amdgcn_raw_buffer_store_b128(o00, ro, (uint32_t)tq0 * cb + hb, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o01, ro, (uint32_t)tq0 * cb + hb + 32u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o10, ro, (uint32_t)tq1 * cb + hb, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o11, ro, (uint32_t)tq1 * cb + hb + 32u, 0, 0);
+        lds_barrier();  // B: every wave is done with the tiles
+    }
+}
+#undef HS_STAGE_GEOMETRY
+
 // dst[e] += sum over parts of src[part][e]
 __global__ void reduce_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1579,6 +1918,23 @@ int pick_head_group(int nH) {
 }
 
 template <int HG, bool DROP>
+int launch_fwd2(const AttnParams& p, hipStream_t stream) {
+    const LdsLayoutFwd2 L(HG);
+    auto kern = attn_fwd2_kernel<HG, DROP>;
+    static bool configured = false;
+    if (!configured) {
+        HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        configured = true;
+    }
+    const int groups = p.nH / HG;
+    const int slots = fwd_slots(p, HG);
+    const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * HG), L.total, stream, p, slots, groups);
+    HS_LAUNCH_CHECK("attn_fwd2");
+    return HS_OK;
+}
+
+template <int HG, bool DROP>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
     const LdsLayout L(HG);
     auto kern = attn_fwd_mfma_kernel<HG, DROP>;
@@ -1610,6 +1966,13 @@ int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     const bool drop = p.drop_p > 0.f;
+    static const int version = getenv("HS_ATTN_FWD_V") ? atoi(getenv("HS_ATTN_FWD_V")) : 2;  // A/B runs: 1 = the round-3 kernel
+    if (version == 2) switch (pick_head_group(p.nH)) {
+            case 4: return drop ? launch_fwd2<4, true>(p, stream) : launch_fwd2<4, false>(p, stream);
+            case 3: return drop ? launch_fwd2<3, true>(p, stream) : launch_fwd2<3, false>(p, stream);
+            case 2: return drop ? launch_fwd2<2, true>(p, stream) : launch_fwd2<2, false>(p, stream);
+            default: return drop ? launch_fwd2<1, true>(p, stream) : launch_fwd2<1, false>(p, stream);
+        }
     switch (pick_head_group(p.nH)) {
         case 4: return drop ? launch_fwd<4, true>(p, stream) : launch_fwd<4, false>(p, stream);
         case 3: return drop ? launch_fwd<3, true>(p, stream) : launch_fwd<3, false>(p, stream);
