@@ -2,25 +2,27 @@
 // production shape: window = 64 tokens (8x8 nested block), head_dim = 32, bf16 activations (gfx950 / CDNA4).
 //
 // Work decomposition
-//   workgroup = HG wavefronts = HG consecutive heads ("head group") of one window at a time; wave g owns head g.
-//   HG*64 B of every token row's q (and k, v) slice are contiguous, so the workgroup's cooperative loads and
-//   stores move whole 128-B lines (HG = 2/4) with 16 B per lane.  Workgroups are persistent: a fixed head group,
-//   grid-striding over the B*nW windows, which keeps the head's relative-position bias (64x64 fp32, pre-multiplied
-//   by log2 e) in REGISTERS for the whole launch, in exactly the accumulator layout of the score tile.
+//   forward:  workgroup = HG wavefronts = HG consecutive heads ("head group") of one window at a time; wave g owns head g.
+//   backward: workgroup = HG heads x 2 wavefronts (query half in the score phase, key tile in the dK / dV phase).
+//   HG*64 B of every token row's q (and k, v, dO) slice are contiguous, so the workgroup's cooperative loads move whole
+//   128-B lines (HG = 2/4) with 16 B per lane.  Workgroups are persistent: a fixed head group, grid-striding over the B*nW
+//   windows, which keeps the head's relative-position bias (64x64 fp32, pre-multiplied by log2 e) in REGISTERS for the whole
+//   launch, in exactly the accumulator layout of the score tile.
 //
 // Gather/scatter: window w, row i is token  idx[w*64+i]  (or (w*64+i+roll) mod N) of the UNshifted qkv tensor;
 // the output row goes back to the same token, so shift and shift_back cost nothing beyond an index load.
 //
-// Per (window, head), all on one wave:
+// Forward, per (window, head), all on one wave:
 //   S^T = K Q^T          8 x v_mfma_f32_32x32x16_bf16.  Computing the TRANSPOSED scores puts a whole query row
 //                        in one lane pair (lane l and l^32 hold the 64 keys of query l&31), so the row max / sum
 //                        are in-register reductions plus one cross-half exchange -- no LDS, no 64-lane butterflies.
 //   softmax              t = S^T * (scale*log2 e) + bias*log2 e (+ mask) -> exp2(t - max) / sum, fp32.
-//   O = P V              8 x MFMA.  The accumulator registers of S^T are, after bf16 packing, directly the A operand
-//                        (lane = query row, 8 key slots); the key order of those slots is mirrored on the V side.
-// LDS images per head: Q and K row-major [64][32] bf16 with a 16-B-chunk XOR swizzle (conflict-free ds_read_b128
-// for the MFMA A/B fragments); V TRANSPOSED [32 d][64 keys] (B fragments need 8 consecutive keys of one feature)
-// with feature rows permuted and padded so both the 2-byte transposing writes and the 8-byte reads are conflict-free.
+//   O^T = V^T P^T        8 x MFMA.  The accumulator registers of S^T are, after bf16 packing, directly the B operand
+//                        (lane = query row, 8 key slots); the result has lane = query, registers = features, and every
+//                        lane stores 16-byte pieces of its token's row straight to HBM (pack_rows_t).
+// LDS images per head: Q, K and V row-major [64][32] bf16 with a 16-B-chunk XOR swizzle (conflict-free ds_read_b128 for the
+// MFMA A/B fragments of Q and K; the fragments that need 8 consecutive TOKENS of one feature -- V in the forward, K, Q, dO
+// in the backward -- come from the same tiles through ds_read_b64_tr_b16, the hardware 4x16 transpose).
 // Cosine attention: k rows are L2-normalised while being staged; the query norm and the head's logit scale are one
 // per-lane factor applied to the fp32 scores.
 #include "window_attn.h"
@@ -34,373 +36,23 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// A/B switches of two store-placement experiments of round 3 (tools/attn_store_ab.sh builds all four combinations;
-// profiles/r03_attn_store_ab.txt).  Motivation: vmcnt counts loads AND stores here, the wait for the prefetched rows at the top
-// of an iteration is a full vmcnt(0) and therefore also waits for the stores issued just before it; a timing ablation without
-// the stores ran 9 % faster.  Neither re-ordering realised that: claiming the forward's prefetched rows in front of its stores
-// costs 12 % at stage 0 (4 spilled registers in a kernel at the 256-VGPR limit), deferring the backward's stores to the next
-// iteration is within the run-to-run noise (+-10 % at stages 2-3 between processes).  Both default OFF.
-#ifndef HS_ATTN_FWD_CLAIM
-#define HS_ATTN_FWD_CLAIM 0
-#endif
-#ifndef HS_ATTN_BWD_DEFER
-#define HS_ATTN_BWD_DEFER 0
-#endif
-
 constexpr int kWs = 64, kHd = 32;
 constexpr int kTileBytes = kWs * kHd * 2;  // 4096: [64][32] bf16, rows of 64 B = 4 chunks of 16 B
-constexpr int kVtLd = 136;                 // bytes per feature row of the transposed tile (64 keys * 2 B + 8 pad)
-constexpr int kVtStride = kHd * kVtLd + 32;  // 4384: (stride/4) % 32 == 8 spreads the heads over the banks
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNormEps = 1e-12f;
 constexpr float kMaskLog2 = -100.f * kLog2e;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-// physical row of feature d inside the transposed tile
-__device__ __forceinline__ int vt_row(int d) { return ((d & 7) << 2) + (d >> 3); }
-
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
-
-struct LdsLayout {
-    // [HG] Q tiles | [HG] K tiles | [HG] transposed V tiles | qinv[HG][64] | labels[64] | flags
-    int q, k, vt, qinv, lab, flag, total;
-    __host__ __device__ explicit LdsLayout(int hg) {
-        q = 0;
-        k = q + hg * kTileBytes;
-        vt = k + hg * kTileBytes;
-        qinv = vt + hg * kVtStride;
-        lab = qinv + hg * kWs * 4;
-        flag = lab + kWs;
-        total = flag + 16;
-    }
-};
-
-template <int HG, bool DROP>
-__global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p, int slots, int groups) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L(HG);
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;  // g: head inside the group (wave-uniform)
-    // 1-D grid -> (window slot bx, head group by), the head groups of a slot on ONE XCD (see the backward kernel)
-    const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
-    const int by = blocal % groups, bx = bxcd + 8 * (blocal / groups);
-    if (bx >= slots) return;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int h = by * HG + g;
-    const int C = p.C;
-    const int64_t N = p.N;
-    const int nW = (int)(N / kWs);
-    const int64_t total_windows = (int64_t)p.B * nW;
-    const bool cosine = (p.flags & HS_ATTN_COSINE) != 0;
-    const float hscale = p.head_scale[h];
-    const uint16_t* qkv = (const uint16_t*)p.qkv;
-    uint16_t* out = (uint16_t*)p.out;
-
-    unsigned char* q_tile = smem + L.q + g * kTileBytes;
-    unsigned char* k_tile = smem + L.k + g * kTileBytes;
-    unsigned char* vt_tile = smem + L.vt + g * kVtStride;
-    float* qinv_s = (float*)(smem + L.qinv);
-    unsigned char* lab_s = smem + L.lab;
-
-    // staging geometry: 12 steps = 3 parts (q, k, v) x 4 row blocks of 16 rows; a step moves 16 rows x HG*64 B
-    const int srow = tid / (4 * HG);   // 0..15
-    const int sc = tid % (4 * HG);     // 16-B chunk inside the row's HG*64-B segment
-    const int sg = sc >> 2, scc = sc & 3;
-    const int64_t col0 = (int64_t)by * HG * kHd + sc * 8;  // element column inside a C-wide part
-
-    // software pipeline: the q/k/v rows of window i+1 are in flight (in registers) while window i is computed, so every
-    // workgroup keeps ~HG*12 KB of HBM requests outstanding all the time instead of only during a load phase
-    int64_t tok[4], tok_next[4];
-    uint4 ld[3][4];
-    auto issue_loads = [&](int64_t wi_l) {
-        const int b_l = (int)(wi_l / nW);
-        const int64_t j_l = (wi_l - (int64_t)b_l * nW) * kWs;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) tok_next[rb] = (int64_t)b_l * N + shifted_source(p, j_l + rb * 16 + srow);
-#pragma unroll
-        for (int part = 0; part < 3; ++part)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-                ld[part][rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + (int64_t)part * C + col0);
-    };
-    if ((int64_t)bx < total_windows) issue_loads(bx);
-
-    // (loaded AFTER the first window's rows were requested: both latencies overlap)
-    // relative-position bias of this head, in the S^T accumulator layout: tile (kt, qt), register r holds
-    // query qt*32 + l31, key kt*32 + (r&3) + 8*(r>>2) + 4*half
-    // The loads are UNCONDITIONAL, eight at a time (without a bias they read this lane's bytes of the qkv tensor and the
-    // values are discarded): a per-load `p.bias ? load : 0` compiles to 16 conditional blocks, each waiting for its own
-    // load (vmcnt(0)) -- 16 serial L2 round trips in front of the first window.
-    float biasr[2][2][16];
-    {
-        const bool has_bias = p.bias != nullptr;
-        const float* bsrc = has_bias ? p.bias + ((int64_t)h * kWs + l31) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            float4 b4[2][4];
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)  // registers 4m..4m+3 are 4 consecutive keys: one 16-byte load
-                    b4[qt][m] = *(const float4*)(bsrc + (has_bias ? qt * 32 * kWs : 0) + kt * 32 + 8 * m);
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    biasr[kt][qt][4 * m] = has_bias ? b4[qt][m].x * kLog2e : 0.f;
-                    biasr[kt][qt][4 * m + 1] = has_bias ? b4[qt][m].y * kLog2e : 0.f;
-                    biasr[kt][qt][4 * m + 2] = has_bias ? b4[qt][m].z * kLog2e : 0.f;
-                    biasr[kt][qt][4 * m + 3] = has_bias ? b4[qt][m].w * kLog2e : 0.f;
-                }
-        }
-    }
-
-    for (int64_t wi = bx; wi < total_windows; wi += slots) {
-        const int b = (int)(wi / nW);
-        const int w = (int)(wi - (int64_t)b * nW);
-        const int64_t j0 = (int64_t)w * kWs;
-
-        // ------------------------------------------------------------ stage q, k, v of this window (already loaded) into LDS
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) tok[rb] = tok_next[rb];
-        if (p.labels && tid < kWs) lab_s[tid] = p.labels[j0 + tid];
-
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const int row = rb * 16 + srow;
-            // --- q: raw; its inverse norm (cosine) becomes a per-row factor of the scores
-            {
-                const uint4 v = ld[0][rb];
-                if (cosine) {
-                    const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-                    float ss = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ss += bf_lo(wd[i]) * bf_lo(wd[i]) + bf_hi(wd[i]) * bf_hi(wd[i]);
-                    ss += __shfl_xor(ss, 1, 64);
-                    ss += __shfl_xor(ss, 2, 64);
-                    if (scc == 0) qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(ss), kNormEps);
-                }
-                *(uint4*)(smem + L.q + sg * kTileBytes + swz(row, scc)) = v;
-            }
-            // --- k: L2-normalised rows for cosine attention
-            {
-                uint4 v = ld[1][rb];
-                if (cosine) {
-                    uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-                    float ss = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ss += bf_lo(wd[i]) * bf_lo(wd[i]) + bf_hi(wd[i]) * bf_hi(wd[i]);
-                    ss += __shfl_xor(ss, 1, 64);
-                    ss += __shfl_xor(ss, 2, 64);
-                    const float kinv = 1.f / fmaxf(sqrtf(ss), kNormEps);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) wd[i] = pack_bf16(bf_lo(wd[i]) * kinv, bf_hi(wd[i]) * kinv);
-                    v = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-                }
-                *(uint4*)(smem + L.k + sg * kTileBytes + swz(row, scc)) = v;
-            }
-            // --- v: transposed, feature d = scc*8 + i lands at [vt_row(d)][row]
-            {
-                const uint4 v = ld[2][rb];
-                const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-                unsigned char* base = smem + L.vt + sg * kVtStride + row * 2;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    *(uint16_t*)(base + vt_row(scc * 8 + 2 * i) * kVtLd) = (uint16_t)(wd[i] & 0xffffu);
-                    *(uint16_t*)(base + vt_row(scc * 8 + 2 * i + 1) * kVtLd) = (uint16_t)(wd[i] >> 16);
-                }
-            }
-        }
-        __syncthreads();
-        if (wi + slots < total_windows) issue_loads(wi + slots);  // prefetch: lands during the MFMAs / softmax below
-
-        bool mixed = false;  // does this window contain more than one region label?
-        if (p.labels) {
-            const uint32_t* lw = (const uint32_t*)lab_s;
-            const uint32_t first = lab_s[0] * 0x01010101u;
-            bool diff = false;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) diff |= lw[i] != first;
-            mixed = diff;  // every lane reads the same 64 bytes: wave-uniform
-        }
-
-        // ------------------------------------------------------------ S^T = K Q^T
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[kt][qt][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 kf[2], qf[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = t * 32 + l31, chunk = ks * 2 + half;
-                kf[t] = *(const bf16x8*)(k_tile + swz(row, chunk));
-                qf[t] = *(const bf16x8*)(q_tile + swz(row, chunk));
-            }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                    acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qf[qt], acc[kt][qt], 0, 0, 0);
-        }
-
-        // ------------------------------------------------------------ softmax over the keys of each query (log2 domain)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int qq = qt * 32 + l31;
-            const float fq = hscale * kLog2e * (cosine ? qinv_s[g * kWs + qq] : 1.f);
-            float m = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t = fmaf(acc[kt][qt][r], fq, biasr[kt][qt][r]);
-                    acc[kt][qt][r] = t;
-                    m = fmaxf(m, t);
-                }
-            if (mixed) {  // rare: windows cut by the shift boundary
-                const int my = lab_s[qq];
-                m = -INFINITY;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float t = acc[kt][qt][r];
-                        if (lab_s[key] != my) t += kMaskLog2;
-                        acc[kt][qt][r] = t;
-                        m = fmaxf(m, t);
-                    }
-            }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float l = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(acc[kt][qt][r] - m);
-                    acc[kt][qt][r] = e;
-                    l += e;
-                }
-            l += __shfl_xor(l, 32, 64);
-            const float linv = 1.f / l;
-            if constexpr (DROP) {  // attention dropout on the normalised probabilities (train mode only)
-                const DropRng rng(p, ((int64_t)b * p.nH + h) * N + j0 + qq);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[kt][qt][r] *= linv * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv;
-            }
-            if (p.lse && half == 0) p.lse[((int64_t)b * p.nH + h) * N + j0 + qq] = (m + __builtin_amdgcn_logf(l)) * kLn2;
-        }
-
-        // ------------------------------------------------------------ O = P V
-        f32x16 o[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qt][r] = 0.f;
-        const unsigned char* vrow = vt_tile + vt_row(l31) * kVtLd;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kt = ks >> 1, c = ks & 1;
-            const int kbase = kt * 32 + c * 16 + 4 * half;  // slots 0..3 -> keys kbase.., slots 4..7 -> kbase+8..
-            const uint2 lo = *(const uint2*)(vrow + kbase * 2);
-            const uint2 hi = *(const uint2*)(vrow + (kbase + 8) * 2);
-            const uint4 vw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                bf16x8 pf;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)acc[kt][qt][8 * c + jj];
-                o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o[qt], 0, 0, 0);
-            }
-        }
-
-        // ------------------------------------------------------------ O -> LDS (this head's q tile is free now) -> global
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                *(uint16_t*)(q_tile + qq * 64 + l31 * 2) = float_to_bf16(o[qt][r]);
-            }
-        __syncthreads();
-        // vmcnt counts loads AND stores on this target, and the two complete out of order with respect to each other: the wait
-        // for the next window's prefetched rows is a full `vmcnt(0)`.  Left to the top of the next iteration it would also wait
-        // for the stores issued right here, i.e. every iteration would pay a store's round trip to memory (timing ablation,
-        // profiles/r03_attn_bwd_ablation.txt: 9 % of the backward).  So the rows -- requested a whole iteration ago, long
-        // landed -- are claimed HERE, in front of the stores: the compiler puts its wait before this statement and has
-        // nothing to wait for at the top; the stores then drain under the next window's staging and arithmetic.
-#if HS_ATTN_FWD_CLAIM
-#pragma unroll
-        for (int part = 0; part < 3; ++part)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-                asm volatile("" : "+v"(ld[part][rb].x), "+v"(ld[part][rb].y), "+v"(ld[part][rb].z), "+v"(ld[part][rb].w));
-        asm volatile("" : "+v"(tok_next[0]), "+v"(tok_next[1]), "+v"(tok_next[2]), "+v"(tok_next[3]));
-#endif
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const int row = rb * 16 + srow;
-            const uint4 v = *(const uint4*)(smem + L.q + sg * kTileBytes + row * 64 + scc * 16);
-            *(uint4*)(out + tok[rb] * C + col0) = v;
-        }
-        __syncthreads();
-    }
-}
-
-
-// ================================================================================================ backward
-// Per (window, head), on one wave, 40 MFMAs (the minimum: S, dP, dV, dK, dQ):
-//   S^T  = K^ Q^T , dP^T = V dO^T                       (lane = query, registers = keys)
-//   P^T  = exp2(S^T*f + bias - lse) ;  dS^T = P^T o (dP^T - D) ,  D[q] = sum_k P[q][k] dP[q][k]  (= dO[q].O[q], but formed
-//                                     from the fp32 P and dP of this very pass: a query's 64 keys sit in one lane pair, so D is
-//                                     32 FMAs + one lane^32 exchange, sum_k dS[q][k] = 0 holds to fp32 rounding instead of to the
-//                                     bf16 rounding of the stored O, and the O rows are not read at all: 7 instead of 8 row
-//                                     streams per token and head)
-//   dS' = dS * f_q   (f_q = head scale [* 1/|q| for cosine])  ->  ONE bf16 matrix feeds both dK and dQ
-//   dV = P^T dO ,  dK^ = dS'^T Q      A operands = P / dS' TRANSPOSED: stored row-major [q][key] in an LDS scratch and
-//                                     read back with ds_read_b64_tr_b16 (hardware 4x16 transpose); B operands (dO, Q:
-//                                     8 consecutive tokens of one feature) come from the row-major token tiles the same way
-//   X  = dS' K^                       A operand straight from the dS' registers (as P.V in the forward), B by tr-read
-//   dq = X - q^(q^.X) , dk = (dK^ - k^(k^.dK^))/|k|     for cosine attention (plain: dq = X, dk = dK^)
-// The head's bias gradient is accumulated in registers over all windows of the launch (same layout as the bias) and
-// written once per workgroup to a partial buffer that a second tiny kernel reduces -- no atomics, deterministic.
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int kPsLd = 136;                    // bytes per query row of the P / dS' scratch (64 keys * 2 B + 8 pad)
 constexpr int kPsBytes = kWs * kPsLd;         // 8704
-
-struct LdsLayoutBwd {
-    // per head: Q | K | V | dO tiles (4096 each) | P/dS' scratch [64][64] bf16 (padded) | dq, dk, dv staging (4096 each);
-    // then per-row scalars
-    int head, scratch_off, stage_off, qinv, kinv, lab, total;
-    __host__ __device__ explicit LdsLayoutBwd(int hg) {
-        scratch_off = 4 * kTileBytes;
-        stage_off = scratch_off + kPsBytes;
-        head = stage_off + 3 * kTileBytes;  // 37376 bytes per head
-        qinv = hg * head;
-        kinv = qinv + hg * kWs * 4;
-        lab = kinv + hg * kWs * 4;
-        total = lab + kWs + 16;
-    }
-};
 
 // 4 token rows x feature column (l&31) from a swizzled row-major [64][32] bf16 tile (hardware-transposed 8-byte read)
 __device__ __forceinline__ s16x4 tr_read_tile(const unsigned char* tile, int row0, int lane) {
@@ -423,546 +75,40 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// Workgroup = HG heads x 2 waves: wave (g, qt) owns the 32 queries qt*32.. of head g (20 of the head's 40 MFMAs, half of
-// the bias / bias-gradient registers), which fits 2 waves per SIMD.  dQ rows are private to a wave; dV and dK are sums
-// over queries, so the two waves of a head exchange fp32 partials through LDS: wave 1 sends its dV half to wave 0 (into
-// the then-free V/dO tiles), wave 0 its dK half to wave 1 (into the P/dS' scratch).
-template <int HG, bool DROP, bool COS>
-__global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
-                                                                     float* __restrict__ dscale_part, int slots, int groups, int abl_arg) {
-    // abl: timing-only ablation mask of tools/attn_bwd_ablation.py (a library built with -DHS_ATTN_ABLATION reads it from
-    // HS_ATTN_BWD_ABLATE; the product build compiles the branches away): 1 no global stores, 2 no softmax / dS arithmetic, 4 no
-    // partial-sum exchange, 8 no X / dK / dV products, 16 no global loads after the first window
-#ifdef HS_ATTN_ABLATION
-    const int abl = abl_arg;
-#else
-    constexpr int abl = 0;
-#endif
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayoutBwd L(HG);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // 1-D grid -> (window slot bx, head group by): the dispatcher places block b on XCD b % 8, and the head groups of one
-    // window slot take ids 8 apart, so they run on the SAME XCD at about the same time -- their rows share 128-B lines when a
-    // head group is narrower than a line (one head = 64 B), and the second reader then hits that XCD's L2
-    const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
-    const int by = blocal % groups, bx = bxcd + 8 * (blocal / groups);
-    if (bx >= slots) return;
-    const int g = wv >> 1, qt = wv & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int h = by * HG + g;
-    const int C = p.C;
-    const int64_t N = p.N;
-    const int nW = (int)(N / kWs);
-    const int64_t total_windows = (int64_t)p.B * nW;
-    constexpr bool cosine = COS;  // compile-time: the plain variant carries none of the norm / scale-gradient arithmetic
-    const float hscale = p.head_scale[h];
-    const uint16_t* qkv = (const uint16_t*)p.qkv;
-    const uint16_t* dout = (const uint16_t*)p.dout;
-    uint16_t* dqkv = (uint16_t*)p.dqkv;
-
-    unsigned char* my = smem + g * L.head;
-    unsigned char* q_tile = my;
-    unsigned char* k_tile = my + kTileBytes;
-    unsigned char* v_tile = my + 2 * kTileBytes;
-    unsigned char* do_tile = my + 3 * kTileBytes;
-    unsigned char* scr = my + L.scratch_off;
-    unsigned char* stg = my + L.stage_off;  // [dq | dk | dv] row-major [64][32] bf16
-    float* qinv_s = (float*)(smem + L.qinv);
-    float* kinv_s = (float*)(smem + L.kinv);
-    unsigned char* lab_s = smem + L.lab;
-    const int qq = qt * 32 + l31;  // this lane's query
-
-    // bias gradient of this wave's 32 queries, accumulated over all windows of the launch.  (The bias VALUES are re-read
-    // per window from L2 right before the score MFMAs instead of being pinned in 32 more registers: the backward is at
-    // the 256-VGPR limit of 2 waves/SIMD and spilled with them resident.)
-    float dbacc[2][16];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
-    float dscale_acc = 0.f;
-
-    // Software pipeline (non-cosine variants; the cosine ones are at the register limit): the q, k, v, dO rows of window
-    // i+1 are requested into registers right after window i's MFMA phases, when the accumulators are dead, and land while
-    // window i's partial sums are exchanged and its results stored.  The workgroup barriers of that tail are RAW s_barrier
-    // instructions behind an explicit lgkmcnt(0): __syncthreads() would also wait for the loads in flight (vmcnt(0)) and
-    // undo the overlap -- PMC had the waves parked 62 % of their cycles (SQ_WAIT_ANY).
-    constexpr bool PREFETCH = !(COS && DROP);
-    uint4 ldq[2], ldk[2], ldv[2], lddo[2];
-    int64_t tok_next[2];
-    float lse_next = 0.f;
-    unsigned lab_next = 0;  // this thread's region label of the next window (threads 0..63), requested with the rows
-    // Deferred stores (PREFETCH variants): a window's dq / dk / dv rows stay in their LDS staging tiles at the end of its
-    // iteration and leave for HBM at the START of the next one, behind that iteration's input staging.  vmcnt counts loads AND
-    // stores on this target and the two complete out of order with respect to each other, so the wait for the prefetched
-    // rows at the top of an iteration is a full `vmcnt(0)`; with the stores issued right in front of it every iteration paid
-    // a store's round trip to memory (timing ablation, profiles/r03_attn_bwd_ablation.txt: 9 % of the launch).  Issued
-    // behind that wait they have a whole iteration to land, and the iteration's last barrier goes away.
-    // Only the plain instantiation (no cosine attention, no attention dropout: every BASELINE bench workload but the paper
-    // config) has the ~10 registers this costs; the others keep the immediate stores (they spill 12-24 registers with it).
-    constexpr bool DEFER = HS_ATTN_BWD_DEFER && PREFETCH && !COS && !DROP;
-    int tok_prev[2] = {0, 0};  // (token rows fit 31 bits: B * N < 2^31 is checked by the dispatcher)
-    auto issue_loads = [&](int64_t wi_l) {
-        if ((abl & 16) && wi_l != bx) return;
-        int tid_l = tid;
-        asm volatile("" : "+v"(tid_l));  // (keeps the address arithmetic out of long-lived registers, see below)
-        const int srow_l = tid_l / (4 * HG), sc_l = tid_l % (4 * HG);
-        const int64_t col_l = (int64_t)by * HG * kHd + sc_l * 8;
-        const int b_l = (int)(wi_l / nW);
-        const int64_t j_l = (wi_l - (int64_t)b_l * nW) * kWs;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            tok_next[rb] = (int64_t)b_l * N + shifted_source(p, j_l + rb * 32 + srow_l);
-            ldq[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + col_l);
-            ldk[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + C + col_l);
-            ldv[rb] = *(const uint4*)(qkv + tok_next[rb] * 3 * C + 2 * (int64_t)C + col_l);
-            lddo[rb] = *(const uint4*)(dout + tok_next[rb] * C + col_l);
-        }
-        // this lane's query row of the saved log-sum-exp (needed first thing in the P / dS' phase)
-        lse_next = p.lse[((int64_t)b_l * p.nH + h) * N + j_l + qt * 32 + (lane & 31)];
-        if (p.labels && tid < kWs) lab_next = p.labels[j_l + tid];
-    };
-    auto lds_barrier = [&]() {  // workgroup barrier that orders LDS traffic only (global loads may stay in flight)
-        if constexpr (PREFETCH) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        } else {
-            __syncthreads();
-        }
-    };
-    if (PREFETCH && (int64_t)bx < total_windows) issue_loads(bx);
-
-    for (int64_t wi = bx; wi < total_windows; wi += slots) {
-        // staging geometry: 128*HG threads move 32 rows x HG*64 B per pass, 2 passes per tile.  Derived from an opaque
-        // copy of the thread id inside the loop so that the ~40 VGPRs of per-thread addresses are not hoisted and pinned.
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
-        const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;
-        const int64_t col0 = (int64_t)by * HG * kHd + sc * 8;
-        unsigned char* st = smem + sg * L.head;
-        const int b = (int)(wi / nW);
-        const int w = (int)(wi - (int64_t)b * nW);
-        const int64_t j0 = (int64_t)w * kWs;
-        // Per-lane LDS addresses below are loop-invariant; hoisted out of this loop they would pin ~40 VGPRs for the whole
-        // kernel and spill.  An opaque copy of the lane id makes the compiler re-derive them (a few ALU ops) per window.
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
-        const int half = lane_o >> 5, l31 = lane_o & 31;
-        const int qq = qt * 32 + l31;
-        const int lane = lane_o;
-
-        // ------------------------------------------------------------ stage q, k^, v, dO; norms
-        int64_t tok[2];
-        if constexpr (!PREFETCH) issue_loads(wi);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) tok[rb] = tok_next[rb];
-        const float lse_cur = lse_next;
-        if (p.labels && tid < kWs) lab_s[tid] = (unsigned char)lab_next;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = rb * 32 + srow;
-            const uint4 vq = ldq[rb];
-            uint4 vk = ldk[rb];
-            const uint4 vv = ldv[rb];
-            const uint4 vdo = lddo[rb];
-            if (cosine) {
-                const uint32_t wq[4] = {vq.x, vq.y, vq.z, vq.w};
-                uint32_t wk[4] = {vk.x, vk.y, vk.z, vk.w};
-                float sq = 0.f, sk = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    sq += bf_lo(wq[i]) * bf_lo(wq[i]) + bf_hi(wq[i]) * bf_hi(wq[i]);
-                    sk += bf_lo(wk[i]) * bf_lo(wk[i]) + bf_hi(wk[i]) * bf_hi(wk[i]);
-                }
-                sq += __shfl_xor(sq, 1, 64);
-                sq += __shfl_xor(sq, 2, 64);
-                sk += __shfl_xor(sk, 1, 64);
-                sk += __shfl_xor(sk, 2, 64);
-                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wk[i] = pack_bf16(bf_lo(wk[i]) * kinv, bf_hi(wk[i]) * kinv);
-                vk = make_uint4(wk[0], wk[1], wk[2], wk[3]);
-                if (scc == 0) {
-                    qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(sq), kNormEps);
-                    kinv_s[sg * kWs + row] = kinv;
-                }
-            }
-            const int off = swz(row, scc);
-            *(uint4*)(st + off) = vq;
-            *(uint4*)(st + kTileBytes + off) = vk;
-            *(uint4*)(st + 2 * kTileBytes + off) = vv;
-            *(uint4*)(st + 3 * kTileBytes + off) = vdo;
-        }
-        uint4 pq0, pk0, pv0, pq1, pk1, pv1;  // the previous window's staged results (this thread's pieces)
-        const bool flush_prev = DEFER && wi != bx;
-        if (flush_prev) {
-            const unsigned char* src = st + L.stage_off + srow * 64 + scc * 16;
-            pq0 = *(const uint4*)src;
-            pk0 = *(const uint4*)(src + kTileBytes);
-            pv0 = *(const uint4*)(src + 2 * kTileBytes);
-            pq1 = *(const uint4*)(src + 32 * 64);
-            pk1 = *(const uint4*)(src + kTileBytes + 32 * 64);
-            pv1 = *(const uint4*)(src + 2 * kTileBytes + 32 * 64);
-        }
-        __syncthreads();
-        if (flush_prev && !(abl & 1)) {
-            int t0 = tok_prev[0], t1 = tok_prev[1];
-            asm volatile("" : "+v"(t0), "+v"(t1));  // (addresses formed here, not carried through the iteration)
-            uint16_t* d0 = dqkv + (int64_t)t0 * 3 * C + col0;
-            uint16_t* d1 = dqkv + (int64_t)t1 * 3 * C + col0;
-            *(uint4*)d0 = pq0;
-            *(uint4*)(d0 + C) = pk0;
-            *(uint4*)(d0 + 2 * (int64_t)C) = pv0;
-            *(uint4*)d1 = pq1;
-            *(uint4*)(d1 + C) = pk1;
-            *(uint4*)(d1 + 2 * (int64_t)C) = pv1;
-        }
-
-        bool mixed = false;
-        if (p.labels) {
-            const uint32_t* lw = (const uint32_t*)lab_s;
-            const uint32_t first = lab_s[0] * 0x01010101u;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mixed |= lw[i] != first;
-        }
-
-        // ------------------------------------------------------------ S^T = K^ Q^T and dP^T = V dO^T for this wave's 32 queries
-        // bias[h][qq][kt*32 + 8*rg + 4*half .. +3], in flight during the MFMAs below.  The eight loads are UNCONDITIONAL (without
-        // a bias they read this lane's 256 bytes of the qkv tensor and the values are discarded below): per-load
-        // `p.bias ? load : 0` ternaries compile to eight conditional blocks that each wait for their own load (vmcnt(0)) --
-        // eight serial L2 round trips per window in front of the score MFMAs -- and one branch around all of them still
-        // makes the compiler wait for them at the join.
-        float4 biasv[2][4];
-        {
-            const float* bsrc = p.bias ? p.bias + ((int64_t)h * kWs + qq) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) biasv[kt][rg] = *(const float4*)(bsrc + kt * 32 + 8 * rg);
-        }
-        f32x16 accS[2], accP[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                accS[kt][r] = 0.f;
-                accP[kt][r] = 0.f;
-            }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = ks * 2 + half;
-            const bf16x8 qf = *(const bf16x8*)(q_tile + swz(qq, chunk));
-            const bf16x8 df = *(const bf16x8*)(do_tile + swz(qq, chunk));
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int off = swz(kt * 32 + l31, chunk);
-                const bf16x8 kf = *(const bf16x8*)(k_tile + off);
-                const bf16x8 vf = *(const bf16x8*)(v_tile + off);
-                accS[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, accS[kt], 0, 0, 0);
-                accP[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df, accP[kt], 0, 0, 0);
-            }
-        }
-
-        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
-        // ------------------------------------------------------------ P, dS' (fp32); bias / scale gradients
-        if (!(abl & 2)) {
-            const bool has_bias = p.bias != nullptr;
-            const float qinv = cosine ? qinv_s[g * kWs + qq] : 1.f;
-            const float fqn = hscale * qinv;  // d s / d (q . k^)
-            const float fq2 = fqn * kLog2e;
-            const float lse2 = lse_cur * kLog2e;
-            const DropRng rng(p, ((int64_t)b * p.nH + h) * N + j0 + qq);
-            // bias (log2 domain) and, in the rare windows cut by the shift boundary, the mask: folded into one additive term
-            // under a single wave-uniform branch so that the element loops below are branch-free
-            float brow[2][16];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    brow[kt][4 * rg] = has_bias ? biasv[kt][rg].x * kLog2e : 0.f;
-                    brow[kt][4 * rg + 1] = has_bias ? biasv[kt][rg].y * kLog2e : 0.f;
-                    brow[kt][4 * rg + 2] = has_bias ? biasv[kt][rg].z * kLog2e : 0.f;
-                    brow[kt][4 * rg + 3] = has_bias ? biasv[kt][rg].w * kLog2e : 0.f;
-                }
-            if (mixed) {
-                const int mylab = lab_s[qq];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (lab_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != mylab) brow[kt][r] += kMaskLog2;
-            }
-            // pass 1: P and the (dropout-masked) dP in place; D = sum_k P dP over this lane's 32 keys.  Cosine attention also
-            // needs sum_k dS S_raw = sum_k P dP S_raw - D sum_k P S_raw for the logit-scale gradient: two more running sums
-            float dsum = 0.f, s_pds = 0.f, s_ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sraw = accS[kt][r];
-                    const float t = fmaf(sraw, fq2, brow[kt][r]);
-                    const float pr = __builtin_amdgcn_exp2f(t - lse2);
-                    float dpv = accP[kt][r];
-                    if constexpr (DROP)  // the forward multiplied V by P o mask/(1-p): regenerate the same mask
-                        dpv *= rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-                    dsum = fmaf(pr, dpv, dsum);
-                    if constexpr (COS) {
-                        const float ps = pr * sraw;
-                        s_ps += ps;
-                        s_pds = fmaf(ps, dpv, s_pds);
-                    }
-                    accS[kt][r] = pr;
-                    accP[kt][r] = dpv;
-                    // (cosine: S_raw is needed again after the exp2; unfenced, the scheduler issues all 32 exp2 first and keeps
-                    // 32 extra values alive, which spills at the 256-VGPR limit of two waves per SIMD)
-                    if constexpr (COS)
-                        if ((r & 7) == 7) asm volatile("" : "+v"(dsum), "+v"(s_ps), "+v"(s_pds));
-                }
-            dsum += __shfl_xor(dsum, 32, 64);  // the other 32 keys of this query
-            if constexpr (COS) dscale_acc = fmaf(qinv, s_pds - dsum * s_ps, dscale_acc);  // this lane's share of sum_k dS S_raw / |q|
-            // pass 2: dS = P o (dP - D); bias gradient; the operands of the three products
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pr = accS[kt][r];
-                    const float dsv = pr * (accP[kt][r] - dsum);
-                    dbacc[kt][r] += dsv;
-                    if constexpr (DROP)
-                        accP[kt][r] = pr * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);  // dropped P, the operand of dV
-                    else
-                        accP[kt][r] = pr;
-                    accS[kt][r] = dsv * fqn;  // dS'
-                }
-        }
-
-        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
-        // Order chosen for register pressure: X first (its A operand is the dS' registers), then dS' -> scratch -> dK^,
-        // then P -> scratch -> dV; each accumulator set dies before the next one is born.
-        // ------------------------------------------------------------ X = dS' K^ for this wave's 32 query rows
-        if (!(abl & 8)) {
-            f32x16 dq;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int kt = ks >> 1, c = ks & 1;
-                const int kbase = kt * 32 + c * 16 + 4 * half;
-                const bf16x8 bk = join(tr_read_tile(k_tile, kbase, lane), tr_read_tile(k_tile, kbase + 8, lane));
-                bf16x8 af;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) af[jj] = (__bf16)accS[kt][8 * c + jj];
-                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bk, dq, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {  // dq rows are private to this wave: straight to the staging tile
-                const int rr = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                *(uint16_t*)(stg + rr * 64 + l31 * 2) = float_to_bf16(dq[r]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
-        // ------------------------------------------------------------ dK^_partial = dS'^T Q over this wave's queries
-        unsigned char* myrow = scr + qq * kPsLd + 4 * half * 2;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                *(uint2*)(myrow + (kt * 32 + 8 * rg) * 2) =
-                    make_uint2(pack_bf16(accS[kt][4 * rg], accS[kt][4 * rg + 1]), pack_bf16(accS[kt][4 * rg + 2], accS[kt][4 * rg + 3]));
-        f32x16 dv[2], dk[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dk[0][r] = 0.f;
-            dk[1][r] = 0.f;
-        }
-        if (!(abl & 8))
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {  // 16 of this wave's queries per step: half 0 -> +0..7, half 1 -> +8..15
-            const int qrow = qt * 32 + ks * 16 + 8 * half;
-            const bf16x8 bq = join(tr_read_tile(q_tile, qrow, lane), tr_read_tile(q_tile, qrow + 4, lane));
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 a = join(tr_read_scratch(scr, qrow, kt, lane), tr_read_scratch(scr, qrow + 4, kt, lane));
-                dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, dk[kt], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
-        // ------------------------------------------------------------ dV_partial = P^T dO (same scratch rows, program order)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                *(uint2*)(myrow + (kt * 32 + 8 * rg) * 2) =
-                    make_uint2(pack_bf16(accP[kt][4 * rg], accP[kt][4 * rg + 1]), pack_bf16(accP[kt][4 * rg + 2], accP[kt][4 * rg + 3]));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dv[0][r] = 0.f;
-            dv[1][r] = 0.f;
-        }
-        if (!(abl & 8))
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int qrow = qt * 32 + ks * 16 + 8 * half;
-            const bf16x8 bo = join(tr_read_tile(do_tile, qrow, lane), tr_read_tile(do_tile, qrow + 4, lane));
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 a = join(tr_read_scratch(scr, qrow, kt, lane), tr_read_scratch(scr, qrow + 4, kt, lane));
-                dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bo, dv[kt], 0, 0, 0);
-            }
-        }
-
-        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: cross-phase hoisting of LDS reads costs registers
-        // ------------------------------------------------------------ exchange the query-sum partials between the head's waves
-        lds_barrier();  // every wave is done with the V / dO tiles and with the scratch
-        if (PREFETCH && wi + slots < total_windows) issue_loads(wi + slots);  // in flight during the exchange and the stores
-        float4* xch_v = (float4*)v_tile;  // 8 KB = V + dO tiles: wave 1 -> wave 0, [kt][r / 4][lane] x 4 floats (b128 accesses)
-        float4* xch_k = (float4*)scr;     // 8 KB of the scratch:  wave 0 -> wave 1
-        if (abl & 4) {
-        } else if (qt == 1) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    xch_v[(kt * 4 + rg) * 64 + lane] = make_float4(dv[kt][4 * rg], dv[kt][4 * rg + 1], dv[kt][4 * rg + 2], dv[kt][4 * rg + 3]);
-        } else {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    xch_k[(kt * 4 + rg) * 64 + lane] = make_float4(dk[kt][4 * rg], dk[kt][4 * rg + 1], dk[kt][4 * rg + 2], dk[kt][4 * rg + 3]);
-        }
-        lds_barrier();
-        if (abl & 4) {
-        } else if (qt == 0) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float4 o = xch_v[(kt * 4 + rg) * 64 + lane];
-                    const float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int rr = kt * 32 + i + 8 * rg + 4 * half;
-                        *(uint16_t*)(stg + 2 * kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dv[kt][4 * rg + i] + ov[i]);
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float4 o = xch_k[(kt * 4 + rg) * 64 + lane];
-                    const float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int rr = kt * 32 + i + 8 * rg + 4 * half;
-                        *(uint16_t*)(stg + kTileBytes + rr * 64 + l31 * 2) = float_to_bf16(dk[kt][4 * rg + i] + ov[i]);
-                    }
-                }
-        }
-        lds_barrier();
-
-        // ------------------------------------------------------------ staged results: cosine normalisation Jacobian; -> global
-        // The DEFER variant leaves the rows in LDS (each thread reads back only its own pieces at the next staging, so no
-        // barrier is needed behind this block); the other variants store them now.
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = rb * 32 + srow;
-            unsigned char* sp = st + L.stage_off + row * 64 + scc * 16;
-            uint4 xq, xk;
-            if constexpr (!DEFER) {
-                xq = *(const uint4*)sp;
-                xk = *(const uint4*)(sp + kTileBytes);
-            }
-            if (cosine) {  // remove the component along q^ / k^ (gradient through x / |x|)
-                const uint4 rq = *(const uint4*)(st + swz(row, scc));
-                const uint4 rk = *(const uint4*)(st + kTileBytes + swz(row, scc));
-                const float qinv = qinv_s[sg * kWs + row], kinv = kinv_s[sg * kWs + row];
-                uint32_t a[4] = {xq.x, xq.y, xq.z, xq.w}, bq[4] = {rq.x, rq.y, rq.z, rq.w};
-                uint32_t c2[4] = {xk.x, xk.y, xk.z, xk.w}, bk[4] = {rk.x, rk.y, rk.z, rk.w};
-                float pq = 0.f, pk = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    pq += bf_lo(a[i]) * bf_lo(bq[i]) + bf_hi(a[i]) * bf_hi(bq[i]);
-                    pk += bf_lo(c2[i]) * bf_lo(bk[i]) + bf_hi(c2[i]) * bf_hi(bk[i]);
-                }
-                pq += __shfl_xor(pq, 1, 64);
-                pq += __shfl_xor(pq, 2, 64);
-                pk += __shfl_xor(pk, 1, 64);
-                pk += __shfl_xor(pk, 2, 64);
-                pq *= qinv * qinv;  // q^ = q*qinv on both sides of  X - q^ (q^ . X)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] = pack_bf16(bf_lo(a[i]) - bf_lo(bq[i]) * pq, bf_hi(a[i]) - bf_hi(bq[i]) * pq);
-                    c2[i] = pack_bf16((bf_lo(c2[i]) - bf_lo(bk[i]) * pk) * kinv, (bf_hi(c2[i]) - bf_hi(bk[i]) * pk) * kinv);
-                }
-                xq = make_uint4(a[0], a[1], a[2], a[3]);
-                xk = make_uint4(c2[0], c2[1], c2[2], c2[3]);
-            }
-            if constexpr (!DEFER) {
-                const uint4 xv = *(const uint4*)(sp + 2 * kTileBytes);
-                uint16_t* dst = dqkv + tok[rb] * 3 * C + col0;
-                if (!(abl & 1)) {
-                    *(uint4*)dst = xq;
-                    *(uint4*)(dst + C) = xk;
-                    *(uint4*)(dst + 2 * (int64_t)C) = xv;
-                }
-            }
-            if constexpr (DEFER) tok_prev[rb] = (int)tok[rb];
-        }
-        if constexpr (!DEFER) lds_barrier();
-    }
-    if (DEFER && (int64_t)bx < total_windows && !(abl & 1)) {  // the last window's rows (this thread's own pieces)
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
-        const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;
-        const int64_t col0 = (int64_t)by * HG * kHd + sc * 8;
-        const unsigned char* src = smem + sg * L.head + L.stage_off + srow * 64 + scc * 16;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            uint16_t* dst = dqkv + (int64_t)tok_prev[rb] * 3 * C + col0;
-            *(uint4*)dst = *(const uint4*)(src + rb * 32 * 64);
-            *(uint4*)(dst + C) = *(const uint4*)(src + kTileBytes + rb * 32 * 64);
-            *(uint4*)(dst + 2 * (int64_t)C) = *(const uint4*)(src + 2 * kTileBytes + rb * 32 * 64);
-        }
-    }
-
-    // ------------------------------------------------------------ per-workgroup partial parameter gradients
-    if (dbias_part) {
-        float* dst = dbias_part + ((int64_t)bx * p.nH + h) * kWs * kWs + (int64_t)qq * kWs;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                *(float4*)(dst + kt * 32 + 8 * rg + 4 * half) =
-                    make_float4(dbacc[kt][4 * rg], dbacc[kt][4 * rg + 1], dbacc[kt][4 * rg + 2], dbacc[kt][4 * rg + 3]);
-    }
-    if (dscale_part) {  // two waves per head: [slot][head][qt]
-        const float tot = wave_sum(dscale_acc);
-        if (lane == 0) dscale_part[((int64_t)bx * p.nH + h) * 2 + qt] = tot;
-    }
-}
-
-// ================================================================================================ backward, second form (round 4)
-// Same 40 MFMAs per (window, head), re-arranged around three observations of profiles/r03_attn_bwd_ablation.txt (the kernel is
-// issue / barrier bound: 34.5 VALU instructions per MFMA, 5 barriers per window, 72 % of its time left with all global traffic
-// removed):
+// ================================================================================================ backward
+// Per (window, head) 40 MFMAs (the minimum: S, dP, dV, dK, dQ), on the head's two waves:
+//   S^T  = K^ Q^T , dP^T = V dO^T                       (lane = query, registers = keys; wave t: queries t*32..)
+//   P^T  = exp2(S^T*f + bias - lse) ;  dS^T = P^T o (dP^T - D) ,  D[q] = sum_k P[q][k] dP[q][k]  (= dO[q].O[q], but formed
+//                                     from the fp32 P and dP of this very pass: a query's 64 keys sit in one lane pair, so D is
+//                                     32 FMAs + one lane^32 exchange, sum_k dS[q][k] = 0 holds to fp32 rounding instead of to the
+//                                     bf16 rounding of the stored O, and the O rows are not read at all: 7 instead of 8 row
+//                                     streams per token and head)
+//   dS' = dS * f_q   (f_q = head scale [* 1/|q| for cosine])  ->  ONE bf16 matrix feeds both dK and dQ
+//   dq = X - q^(q^.X) , dk = (dK^ - k^(k^.dK^))/|k|     for cosine attention (plain: dq = X, dk = dK^), X = dS' K^
+// The head's bias gradient is accumulated in registers over all windows of the launch (same layout as the bias) and
+// written once per workgroup to a partial buffer that a second tiny kernel reduces -- no atomics, deterministic.
+//
+// Arrangement (round 4; the round-3 kernel was issue / barrier bound -- profiles/r03_attn_bwd_ablation.txt: 34.5 VALU
+// instructions per MFMA, 5 barriers per window, 72 % of its time left with all global traffic removed; this one: 23.0, 3
+// barriers, stage 0 of HEAL-SWIN-B 680 -> 555-570 us, profiles/r04_attn_v2_ab.txt, r04_attn_pmc_*.json):
 //  * TRANSPOSED output products.  dQ^T = K^^T dS'^T, dK^^T = Q^T dS', dV^T = dO^T P are the same MFMAs with the A and B operands
 //    exchanged; the accumulator then has lane = token, registers = 4 consecutive features x 4 groups.  bf16 packing gives 8-byte
 //    pieces, one v_permlane32_swap per dword pairs them into 16 contiguous bytes, and each lane stores its token's row piece
-//    straight to HBM: no 2-byte LDS writes, no staging tiles, no read-back pass, no barrier around it.
+//    straight to HBM: no 2-byte LDS writes, no staging tiles, no read-back pass, no barrier around it (PMC: HBM traffic stays
+//    1.02 x algorithmic -- the 32-byte pieces of a line merge in L2).
 //  * dK / dV split by KEY tile instead of by query half.  Wave t of a head writes the P / dS' rows of its 32 queries to two LDS
-//    scratches; after one barrier wave t forms dK^T and dV^T of key tile t over ALL 64 queries (4 + 4 MFMAs, as before).  The
-//    fp32 partial-sum exchange (8 KB per wave and window, two barriers) is gone.
+//    scratches (row-major [q][key]); after one barrier wave t forms dK^T and dV^T of key tile t over ALL 64 queries (4 + 4
+//    MFMAs, B operands by ds_read_b64_tr_b16 from the scratches, A operands the same way from the Q / dO tiles).  No fp32
+//    partial-sum exchange.
 //  * 32-bit addressing through per-image buffer descriptors, window counters advanced without 64-bit divisions, the
 //    relative-position bias kept in registers (pre-multiplied by log2 e) for the whole launch, the label scan done once per
-//    workgroup by a ballot.  Three barriers per window.
+//    workgroup by a ballot.
 // Loads of window i+1 are requested right after window i's staging barrier and claimed (s_waitcnt) in front of window i's last
 // stores, so no wait ever covers a store's round trip.
-struct LdsLayoutBwd2 {
+struct LdsLayoutBwd {
     // per head: Q | K^ | V | dO tiles (4096 each) | dS' scratch | P scratch ([64 q][64 key] bf16, padded rows); then per-row scalars
     int scr_s, scr_p, head, qinv, kinv, lab, flag, total;
-    __host__ __device__ explicit LdsLayoutBwd2(int hg) {
+    __host__ __device__ explicit LdsLayoutBwd(int hg) {
         scr_s = 4 * kTileBytes;
         scr_p = scr_s + kPsBytes;
         head = scr_p + kPsBytes;  // 33792 bytes per head
@@ -997,10 +143,10 @@ __device__ __forceinline__ void pack_rows_t(const float (&v)[16], u32x4& p0, u32
 }
 
 template <int HG, bool DROP, bool COS>
-__global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, float* __restrict__ dbias_part,
+__global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
                                                                  float* __restrict__ dscale_part, int slots, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayoutBwd2 L(HG);
+    const LdsLayoutBwd L(HG);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
@@ -1017,8 +163,9 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
     // register budget (256 at two waves per SIMD): the plain instantiation keeps the bias in registers for the whole launch and
     // requests the next rows right behind the staging barrier; the cosine / dropout ones re-read the bias per window from L2
     // and request the rows once the score accumulators are dead
-    // (cosine + dropout: only behind the dQ stores, when the P / dS' operands are dead as well)
-    constexpr bool BIASREG = !COS && !DROP, EARLY = !COS && !DROP, LATEST = COS && DROP;
+    // (cosine + dropout, the instantiation with the most live state: no pipelining, the rows are requested at the top of their
+    // own window -- as in the round-3 kernel)
+    constexpr bool BIASREG = !COS && !DROP, EARLY = !COS && !DROP, NOPIPE = COS && DROP;
     const float hscale = p.head_scale[h];
     const bool has_idx = p.idx != nullptr;
     const int roll = (int)p.roll;
@@ -1129,10 +276,12 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
             request_tokens(w_cur);
             asm volatile("" : "+v"(tok_ld2[0]), "+v"(tok_ld2[1]), "+v"(tok_st2));
         }
-        issue_loads(b_cur, w_cur);
-        int b_n = b_cur, w_n = w_cur;
-        advance(b_n, w_n);
-        if (has_idx && b_n < p.B) request_tokens(w_n);
+        if constexpr (!NOPIPE) {
+            issue_loads(b_cur, w_cur);
+            int b_n = b_cur, w_n = w_cur;
+            advance(b_n, w_n);
+            if (has_idx && b_n < p.B) request_tokens(w_n);
+        }
     }
     const bool has_bias = p.bias != nullptr;
     const float* bsrc = has_bias ? p.bias + ((int64_t)h * kWs + qq) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
@@ -1162,14 +311,21 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
     for (int wi = bx; wi < total_windows; wi += slots) {
         const int b = b_cur, w = w_cur;
         const int j0 = w * kWs;
+        if constexpr (NOPIPE) {
+            issue_loads(b, w);
+            int b_n = b, w_n = w;
+            advance(b_n, w_n);
+            if (has_idx && b_n < p.B) request_tokens(w_n);  // (table mode: the NEXT window's token rows still travel one window ahead)
+            claim();
+        }
+        const int tok_store = tok_st;  // this lane's token row of the current window
+        const float lse_cur = lse_next;
         HS_STAGE_GEOMETRY
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));  // (per-lane LDS addresses are re-derived per window instead of pinned in ~40 registers)
         const int half = lane_o >> 5, l31 = lane_o & 31;
         const int qq = t * 32 + l31;
         const int lane = lane_o;
-        const int tok_store = tok_st;  // this lane's token row of the current window
-        const float lse_cur = lse_next;
 
         // ------------------------------------------------------------ stage q, k^, v, dO; norms; label scan
         if (p.labels && wv == 0) {
@@ -1278,6 +434,12 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
                 }
         }
         float dsum = 0.f, s_pds = 0.f, s_ps = 0.f;
+        uint32_t pS[2][8], pP[2][8];
+        {
+        // (Measured, not kept: the same arithmetic on register PAIRS with v_pk_fma / v_pk_mul / v_pk_add -- 17 instead of 23 VALU
+        // instructions per MFMA -- is 4-5 % SLOWER at every stage (stage 0: 584-591 us against 555-570, stage 2: 171 against
+        // 163-166; profiles/r04_attn_v2_ab.txt): a packed fp32 op occupies the SIMD for two passes, so it frees issue slots but no
+        // ALU time, and it lengthens every dependent chain.)
         // pass 1: P and the (dropout-masked) dP in place; D = sum_k P dP over this lane's 32 keys
         auto pass1 = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
@@ -1312,8 +474,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
             pass1(std::false_type{});
         dsum += __shfl_xor(dsum, 32, 64);  // the other 32 keys of this query
         if constexpr (COS) dscale_acc = fmaf(qinv, s_pds - dsum * s_ps, dscale_acc);
-        // pass 2: dS = P o (dP - D); bias gradient; bf16 operands  pS = dS' = dS * f_q,  pP = (dropped) P
-        uint32_t pS[2][8], pP[2][8];
+        // pass 2: dS = P o (dP - D); bias gradient; bf16 operands  pS = dS' = dS * f_q,  pP = dropped P
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -1326,14 +487,12 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
                     const float dsv = pr * (accP[kt][r] - dsum);
                     dbacc[kt][r] += dsv;
                     ds2[e] = dsv * fqn;
-                    if constexpr (DROP)
-                        pp2[e] = pr * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-                    else
-                        pp2[e] = pr;
+                    pp2[e] = DROP ? pr * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) : pr;
                 }
                 pS[kt][i] = pack_bf16x2(ds2[0], ds2[1]);
                 pP[kt][i] = pack_bf16x2(pp2[0], pp2[1]);
             }
+        }
         // rows of this lane's query in the two scratches: keys kt*32 + 8*rg + 4*half .. +3 are registers 4rg..4rg+3
         {
             unsigned char* rs = scr_s + qq * kPsLd + 8 * half;
@@ -1347,7 +506,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!EARLY && !LATEST) prefetch();
+        if constexpr (!EARLY && !NOPIPE) prefetch();
 
         const __amdgpu_buffer_rsrc_t rdq = image_rsrc(p.dqkv, img_qkv, b);
         const uint32_t vst = (uint32_t)tok_store * c3b + (uint32_t)(h * kHd) * 2u + 16u * half;
@@ -1391,7 +550,6 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
             __builtin_amdgcn_raw_buffer_store_b128(p1, rdq, vst + 32u, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LATEST) prefetch();
         lds_barrier();  // B: both scratches complete
 
         // ------------------------------------------------------------ dK^^T = Q^T dS' and dV^T = dO^T P for key tile t, all 64 queries
@@ -1442,7 +600,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
         // The prefetched rows (requested a whole window ago, long landed) are claimed HERE, in front of the last stores: vmcnt
         // counts loads and stores together and the two complete out of order, so a wait for the rows at the top of the next
         // window would also wait for these stores' round trip.
-        claim();
+        if constexpr (!NOPIPE) claim();
         __builtin_amdgcn_raw_buffer_store_b128(k0, rdq, vst, cb, 0);
         __builtin_amdgcn_raw_buffer_store_b128(k1, rdq, vst + 32u, cb, 0);
         __builtin_amdgcn_raw_buffer_store_b128(v0, rdq, vst, 2 * cb, 0);
@@ -1467,14 +625,14 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd2_kernel(AttnParams p, fl
 }
 #undef HS_STAGE_GEOMETRY
 
-// ================================================================================================ forward, second form (round 4)
-// The forward with the output product transposed like the backward's (O^T = V^T P^T: lane = query, registers = features, each
+// ================================================================================================ forward
+// The output product is transposed like the backward's (O^T = V^T P^T: lane = query, registers = features, each
 // lane stores two 16-byte pieces of its token's head slice per query tile): no 2-byte LDS writes of O, no read-back pass, no
 // barrier around it; V is staged ROW-major like Q and K (one 16-byte LDS write instead of eight 2-byte transposing ones) and its
 // B fragments come from ds_read_b64_tr_b16.  32-bit addressing through per-image buffer descriptors; two barriers per window.
-struct LdsLayoutFwd2 {
+struct LdsLayoutFwd {
     int head, qinv, lab, flag, total;  // per head: Q | K^ | V tiles (4096 each)
-    __host__ __device__ explicit LdsLayoutFwd2(int hg) {
+    __host__ __device__ explicit LdsLayoutFwd(int hg) {
         head = 3 * kTileBytes;
         qinv = hg * head;
         lab = qinv + hg * kWs * 4;
@@ -1484,9 +642,9 @@ struct LdsLayoutFwd2 {
 };
 
 template <int HG, bool DROP>
-__global__ void __launch_bounds__(64 * HG, 2) attn_fwd2_kernel(AttnParams p, int slots, int groups) {
+__global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p, int slots, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayoutFwd2 L(HG);
+    const LdsLayoutFwd L(HG);
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // head inside the group
     const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
@@ -1806,14 +964,37 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd2_kernel(AttnParams p, int
 }
 #undef HS_STAGE_GEOMETRY
 
-// dst[e] += sum over parts of src[part][e]
-__global__ void reduce_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, int64_t n) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < parts; ++s) acc += src[(int64_t)s * n + e];  // unrolled: 8 independent loads in flight, same order
-    dst[e] += acc;
+// dst[e] += sum over parts of src[part][e].  A block of 16 waves owns 256 consecutive elements (one float4 per lane); wave w sums
+// the parts p = w, w + 16, ... with all of its loads in flight at once, the 16 partial rows are combined through LDS in a fixed
+// order (deterministic).  (Round 3 gave one thread one element and all `parts` loads in sequence: 64 blocks and 17.8 us at
+// stage 0 of HEAL-SWIN-B, where the table is smallest and the number of parts largest.)
+__global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, int64_t n) {
+    __shared__ float4 part_s[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4;  // n is a multiple of 256 (nH * 64 * 64)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int s = w; s < parts; s += 16) {
+        const float4 v = *(const float4*)(src + (int64_t)s * n + e);
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+    }
+    part_s[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        float4 t = *(const float4*)(dst + e);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 v = part_s[k][lane];
+            t.x += v.x;
+            t.y += v.y;
+            t.z += v.z;
+            t.w += v.w;
+        }
+        *(float4*)(dst + e) = t;
+    }
 }
 
 // dhead_scale[h] += sum over slots and the head's two waves of part[slot][h][qt]
@@ -1847,7 +1028,7 @@ int fwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / h
 int pick_head_group_bwd(int nH) {
     static const int forced = getenv("HS_ATTN_BWD_HG") ? atoi(getenv("HS_ATTN_BWD_HG")) : 0;  // A/B runs
     if (forced == 1 || (forced == 2 && nH % 2 == 0)) return forced;
-    // 37 KB of LDS per head: pairs (128-B segments) where the head count allows; a 3-head group would need 112 KB and
+    // 33 KB of LDS per head: pairs (128-B segments) where the head count allows; a 3-head group would need 100 KB and
     // leave one workgroup per CU, so odd head counts (nH = 3 at stage 0 of the T model) run one head per workgroup and
     // let the neighbouring workgroup's half of each 128-B line come from L2
     return nH % 2 == 0 ? 2 : 1;
@@ -1866,39 +1047,11 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     float* dbias_part = p.dbias ? workspace : nullptr;
     float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
     const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
-    static const int abl = getenv("HS_ATTN_BWD_ABLATE") ? atoi(getenv("HS_ATTN_BWD_ABLATE")) : 0;  // timing experiments only
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part, slots, groups, abl);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part, slots, groups);
     HS_LAUNCH_CHECK("attn_bwd_mfma");
     if (dbias_part) {
         const int64_t n = (int64_t)p.nH * kWs * kWs;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dbias_part, p.dbias, slots, n);
-        HS_LAUNCH_CHECK("reduce dbias partials");
-    }
-    if (dscale_part) {
-        hipLaunchKernelGGL(reduce_scale_partials_kernel, dim3(1), dim3(256), 0, stream, dscale_part, p.dhead_scale, slots, p.nH);
-        HS_LAUNCH_CHECK("reduce dscale partials");
-    }
-    return HS_OK;
-}
-
-template <int HG, bool DROP, bool COS>
-int launch_bwd2(const AttnParams& p, float* workspace, hipStream_t stream) {
-    const LdsLayoutBwd2 L(HG);
-    auto kern = attn_bwd2_kernel<HG, DROP, COS>;
-    static bool configured = false;
-    if (!configured) {
-        HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-        configured = true;
-    }
-    const int groups = p.nH / HG, slots = bwd_slots(p, HG);
-    float* dbias_part = p.dbias ? workspace : nullptr;
-    float* dscale_part = p.dhead_scale ? workspace + (int64_t)slots * p.nH * kWs * kWs : nullptr;
-    const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, dbias_part, dscale_part, slots, groups);
-    HS_LAUNCH_CHECK("attn_bwd2");
-    if (dbias_part) {
-        const int64_t n = (int64_t)p.nH * kWs * kWs;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dbias_part, p.dbias, slots, n);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(n / 256)), dim3(1024), 0, stream, dbias_part, p.dbias, slots, n);
         HS_LAUNCH_CHECK("reduce dbias partials");
     }
     if (dscale_part) {
@@ -1918,27 +1071,10 @@ int pick_head_group(int nH) {
 }
 
 template <int HG, bool DROP>
-int launch_fwd2(const AttnParams& p, hipStream_t stream) {
-    const LdsLayoutFwd2 L(HG);
-    auto kern = attn_fwd2_kernel<HG, DROP>;
-    static bool configured = false;
-    if (!configured) {
-        HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-        configured = true;
-    }
-    const int groups = p.nH / HG;
-    const int slots = fwd_slots(p, HG);
-    const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * HG), L.total, stream, p, slots, groups);
-    HS_LAUNCH_CHECK("attn_fwd2");
-    return HS_OK;
-}
-
-template <int HG, bool DROP>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
-    const LdsLayout L(HG);
+    const LdsLayoutFwd L(HG);
     auto kern = attn_fwd_mfma_kernel<HG, DROP>;
-    static bool configured = false;  // per instantiation; the attribute is a property of the function, set once
+    static bool configured = false;
     if (!configured) {
         HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
         configured = true;
@@ -1966,13 +1102,6 @@ int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     const bool drop = p.drop_p > 0.f;
-    static const int version = getenv("HS_ATTN_FWD_V") ? atoi(getenv("HS_ATTN_FWD_V")) : 2;  // A/B runs: 1 = the round-3 kernel
-    if (version == 2) switch (pick_head_group(p.nH)) {
-            case 4: return drop ? launch_fwd2<4, true>(p, stream) : launch_fwd2<4, false>(p, stream);
-            case 3: return drop ? launch_fwd2<3, true>(p, stream) : launch_fwd2<3, false>(p, stream);
-            case 2: return drop ? launch_fwd2<2, true>(p, stream) : launch_fwd2<2, false>(p, stream);
-            default: return drop ? launch_fwd2<1, true>(p, stream) : launch_fwd2<1, false>(p, stream);
-        }
     switch (pick_head_group(p.nH)) {
         case 4: return drop ? launch_fwd<4, true>(p, stream) : launch_fwd<4, false>(p, stream);
         case 3: return drop ? launch_fwd<3, true>(p, stream) : launch_fwd<3, false>(p, stream);
@@ -1984,15 +1113,6 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
 int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream) {
     if (!workspace) return fail(HS_ERR_INVALID_ARG, "the MFMA backward needs a workspace (hs_window_attn_bwd_workspace)");
     const bool drop = p.drop_p > 0.f, cos = (p.flags & HS_ATTN_COSINE) != 0;
-    static const int version = getenv("HS_ATTN_BWD_V") ? atoi(getenv("HS_ATTN_BWD_V")) : 2;  // A/B runs: 1 = the round-3 kernel
-    if (version == 2) {
-        if (pick_head_group_bwd(p.nH) == 2) {
-            if (cos) return drop ? launch_bwd2<2, true, true>(p, workspace, stream) : launch_bwd2<2, false, true>(p, workspace, stream);
-            return drop ? launch_bwd2<2, true, false>(p, workspace, stream) : launch_bwd2<2, false, false>(p, workspace, stream);
-        }
-        if (cos) return drop ? launch_bwd2<1, true, true>(p, workspace, stream) : launch_bwd2<1, false, true>(p, workspace, stream);
-        return drop ? launch_bwd2<1, true, false>(p, workspace, stream) : launch_bwd2<1, false, false>(p, workspace, stream);
-    }
     if (pick_head_group_bwd(p.nH) == 2) {
         if (cos) return drop ? launch_bwd<2, true, true>(p, workspace, stream) : launch_bwd<2, false, true>(p, workspace, stream);
         return drop ? launch_bwd<2, true, false>(p, workspace, stream) : launch_bwd<2, false, false>(p, workspace, stream);

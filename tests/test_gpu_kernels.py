@@ -473,6 +473,29 @@ def test_gelu_vs_oracle(n, dtype):
     assert_close(xd.grad, xr.grad, 1e-5 if dtype == torch.float32 else GRAD_TOL[dtype], "gelu'")
 
 
+def test_gelu_matches_erf_gelu():
+    """The division-free GELU of csrc/hs_gelu.h (Phi(-|x|) = exp2(degree-5 polynomial)) against the exact erf form in float64 on a
+    dense grid that covers the tail, the origin and large arguments: ABSOLUTE error of GELU and GELU' <= 2e-6 (analysis: 8.3e-7 /
+    9.6e-7 in fp32 arithmetic), far inside the 1e-4 a bf16 result can resolve.  nn.GELU is the reference op (ref :31)."""
+    ops, _, _ = _mods()
+    x = torch.cat([torch.linspace(-40, 40, 2_000_001), torch.linspace(-1e-3, 1e-3, 20001), torch.tensor([0.0, -0.0, 1e4, -1e4, 3e38, -3e38])])
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.gelu_dropout(xd)
+    y.backward(torch.ones_like(y))
+    x64 = x.double()
+    phi = 0.5 * (1 + torch.erf(x64 / 2 ** 0.5))
+    ref = torch.where(x64.abs() > 1e30, x64.clamp_min(0), x64 * phi)
+    dref = phi + x64 * torch.exp(-x64.clamp(-1e3, 1e3) ** 2 / 2) / (2 * torch.pi) ** 0.5
+    e = (y.detach().cpu().double() - ref).abs()
+    e = torch.where(ref.abs() > 1e3, e / ref.abs().clamp_min(1), e)  # relative for the huge arguments
+    de = (xd.grad.cpu().double() - dref).abs()
+    assert torch.isfinite(y).all() and torch.isfinite(xd.grad).all()
+    assert float(e.max()) <= 2e-6, float(e.max())
+    assert float(de.max()) <= 2e-6, float(de.max())
+    from conftest import NOTES
+    NOTES.append(f"GELU (exp2-polynomial tail) vs erf form, fp32 kernels, |x| <= 40 dense: max abs err {float(e.max()):.2e}, GELU' {float(de.max()):.2e}")
+
+
 def test_gelu_dropout_mask_consistency():
     ops, _, _ = _mods()
     n, p = 1 << 20, 0.1

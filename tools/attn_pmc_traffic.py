@@ -27,9 +27,9 @@ def attn_sequence(vals, names):
     seq = []
     for d in sorted(vals):
         n = names[d]
-        if "attn_fwd_mfma" in n:
+        if "attn_fwd_mfma" in n or "attn_fwd2" in n:
             seq.append(("hs_window_attn_fwd", vals[d], d))
-        elif "attn_bwd_mfma" in n:
+        elif "attn_bwd_mfma" in n or "attn_bwd2" in n:
             seq.append(("hs_window_attn_bwd", vals[d], d))
     return seq
 
