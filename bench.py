@@ -55,6 +55,9 @@ WORKLOADS = {
 }
 
 
+COMPANION_WORKLOADS = ("T128", "T256")  # the reference's own model (BASELINE configs[1] and the paper config): companion lines
+
+
 def full_cfg(cfg):
     base = dict(patch_size=4, window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", embed_dim=96,
                 depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], mlp_ratio=4.0, qkv_bias=True, qk_scale=None, use_cos_attn=False,
@@ -79,28 +82,73 @@ def build_model(wl, nside=None):
     return model, cfg, spec
 
 
-def pmc_traffic_per_launch(attn_agg):
-    """HBM bytes per launch from the committed PMC passes (profiles/r03_attn_pmc_hbm_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, KiB units, FETCH x2 gfx950 correction), averaged over this run's launch
-    mix by matching each launch's algorithmic byte count; None if a launch shape was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r03_attn_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r02_attn_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
+def _traffic_table(records):
     table = {}
-    for r in json.load(open(path))["records"]:
+    for r in records:
         tag = r["kernel"].replace("hs_", "")
         table.setdefault((tag, int(r["algorithmic_bytes"])), []).append(r["hbm_bytes_corrected"])
+    return table
+
+
+def measure_pmc_traffic(workload, batch, timeout_s=240):
+    """HBM bytes of the attention launches MEASURED on this box: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE -- separate
+    runs, only --kernel-trace beside --pmc, as MI355X_MICROARCH.md prescribes) over tools/bench_attn.py at this workload's stage
+    shapes, reduced by tools/attn_pmc_traffic.py (KiB units, FETCH_SIZE x 2 for wide coalesced reads on gfx950).  Returns the
+    records, or None when rocprofv3 is not on PATH / a pass fails (the caller then falls back to the committed profile)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import attn_pmc_traffic as APT
+    except Exception:  # noqa: BLE001
+        return None
+    work = tempfile.mkdtemp(prefix="hs_bench_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, c), "-o", "t", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "bench_attn.py"), "--iters", "2", "--workload", workload, "--batch", str(batch)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+        f = glob.glob(os.path.join(work, "FETCH_SIZE", "**", "*counter_collection.csv"), recursive=True)
+        w = glob.glob(os.path.join(work, "WRITE_SIZE", "**", "*counter_collection.csv"), recursive=True)
+        k = glob.glob(os.path.join(work, "FETCH_SIZE", "**", "*kernel_trace.csv"), recursive=True)
+        if not (f and w and k):
+            return None
+        return APT.records(f[0], w[0], k[0], WORKLOADS[workload], batch)
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def pmc_traffic_per_launch(attn_agg, records=None):
+    """HBM bytes per launch, averaged over this run's launch mix by matching each launch's algorithmic byte count against
+    `records` (measured in this run, measure_pmc_traffic) or, without them, against the committed passes of the same kernels
+    and shapes (profiles/r04_attn_pmc_hbm_traffic.json); (None, source) if a launch shape is not covered."""
+    source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_attn.py at the same stage shapes (after the timed region)"
+    if records is None:
+        path = os.path.join(ROOT, "profiles", "r04_attn_pmc_hbm_traffic.json")
+        if not os.path.exists(path):
+            return None, None
+        records = json.load(open(path))["records"]
+        source = "profiles/r04_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc passes of the same kernels and shapes; looked up: rocprofv3 unavailable or failed in this run)"
+    table = _traffic_table(records)
     tot, n = 0.0, 0
     for tag, a in attn_agg.items():
         for nbytes, cnt in a[4].items():
             vals = table.get((tag, int(nbytes)))
             if not vals:
-                return None
+                return None, None
             tot += cnt * sum(vals) / len(vals)
             n += cnt
-    return tot / n if n else None
+    return (tot / n if n else None), source
 
 
 def usable_cores():
@@ -268,6 +316,9 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="print the per-shape table of the event-timed launches to stderr")
     ap.add_argument("--no-fp32-companion", action="store_true", help="skip the fp32 run of the same workload (N = 1 only)")
     ap.add_argument("--no-graph-companion", action="store_true", help="skip the HIP-graph replay of the same workload (N = 1 only)")
+    ap.add_argument("--no-companions", action="store_true", help="skip the HEAL-SWIN-T companion workloads (T128, T256; N = 1 only)")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 counter passes after the timed region (N = 1 only); look it up in profiles/ instead")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd + loss + bwd + Adam) in one HIP graph and replay it (single GPU, no "
                          "dropout); removes host launch latency, which dominates the small workloads")
@@ -320,6 +371,13 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         # diagnosability of the first real multi-GPU run: what every rank sees, on stderr (the JSON line stays alone on stdout)
         env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "MASTER_"))}
+        # a mis-bound exchange must fail loudly BEFORE anything is timed: five all-reduces of ones have to give the world size
+        for _ in range(5):
+            probe = torch.ones(1 << 16, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize(dev)
+            if not bool((probe == float(world)).all()):
+                raise SystemExit(f"[bench rank {rank}] warm exchange check failed: all_reduce(ones) gave {float(probe[0])}, expected {world}")
         print(f"[bench rank {rank}/{world}] device {dev_index}: {torch.cuda.get_device_name(dev_index)}, backend "
               f"{dist.get_backend()}, init {time.perf_counter() - t_init:.2f}s, env {env}", file=sys.stderr, flush=True)
 
@@ -327,6 +385,7 @@ def main():
     # tuned once on an MI355X with PyTorch TunableOp (tuning itself stays OFF here; a validator mismatch -- other ROCm,
     # other GPU -- makes PyTorch ignore the file and fall back to the library heuristic).
     tuned = os.path.join(ROOT, "heal_swin_amd", "tuning", f"tunableop_gfx950_{args.workload}_bs{args.batch}_{args.dtype}.csv")
+    gemm_selection = "TunableOp tuning run" if args.tune_gemm else "default heuristic"
     if args.tune_gemm:
         os.makedirs(os.path.dirname(os.path.abspath(args.tune_gemm)), exist_ok=True)
         torch.cuda.tunable.enable(True)
@@ -342,6 +401,7 @@ def main():
         # fp32 re-run of the same workload, the fp32 depth-head config), merged into a scratch file
         extra = [os.path.join(os.path.dirname(tuned), f"tunableop_gfx950_{args.workload}_bs{args.batch}_fp32.csv"),
                  os.path.join(os.path.dirname(tuned), "tunableop_gfx950_D256_bs2_fp32.csv")]
+        extra += [os.path.join(os.path.dirname(tuned), f"tunableop_gfx950_{w}_bs{args.batch}_bf16.csv") for w in COMPANION_WORKLOADS]
         merged = tuned
         have = [f for f in extra if os.path.exists(f) and f != tuned]
         if have and args.dtype == "bf16":
@@ -355,7 +415,16 @@ def main():
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
         torch.cuda.tunable.set_filename(merged, insert_device_ordinal=False)
-        torch.cuda.tunable.read_file(merged)
+        ok = torch.cuda.tunable.read_file(merged)
+        # PyTorch ignores a results file whose Validator lines (ROCm / hipBLASLt / GPU identification) do not match this process:
+        # say what was actually loaded, not that a file exists
+        want = sum(1 for ln in open(merged).read().splitlines() if ln and not ln.startswith("Validator"))
+        try:
+            loaded = len(torch.cuda.tunable.get_results())
+        except Exception:  # noqa: BLE001
+            loaded = 0
+        gemm_selection = (f"TunableOp results file: {loaded} of {want} entries loaded" if (ok and loaded) else
+                          "default heuristic (TunableOp results file present but rejected: validator mismatch)")
 
     wl = WORKLOADS[args.workload]
     if args.paper_drop_rates:
@@ -376,7 +445,7 @@ def main():
                        "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
                        "launch": "hip graph replay" if args.graph else "eager",
                        "params_M": res.params_m, "final_loss": res.loss,
-                       "library_gemm_selection": "TunableOp tuning run" if args.tune_gemm else ("TunableOp results file" if (os.path.exists(tuned) and not args.no_tuned_gemm) else "default heuristic")},
+                       "library_gemm_selection": gemm_selection},
         }
         # whole-step model FLOPs (analytic forward count == FlopCounterMode; backward = 2x) against the dense bf16 peak
         if wl.get("fwd_gflop_per_image"):
@@ -395,10 +464,10 @@ def main():
     # the reference trains in fp32 (training/train_config.py:95 `precision: int = 32`): same workload, same batch, fp32
     # activations, a few steps -- so the reference's own precision is measured next to the bf16 headline
     if world == 1 and args.dtype == "bf16" and not args.no_fp32_companion and not args.graph and not args.tune_gemm:
-        k = max(2, min(args.steps, 3))
-        r32 = run_workload(ctx, "fp32", k, 1, timing=False)
+        k = max(2, min(args.steps, 8))
+        r32 = run_workload(ctx, "fp32", k, 2, timing=False)
         out["fp32"] = {"value": args.batch * k / r32.elapsed, "unit": "images/s", "ms_per_step": 1e3 * r32.elapsed / k, "steps": k,
-                       "warmup": 1, "batch_per_gpu": args.batch, "workload": wl["name"], "final_loss": r32.loss,
+                       "warmup": 2, "batch_per_gpu": args.batch, "workload": wl["name"], "final_loss": r32.loss,
                        "note": "fp32 activations and MFMA-f32 kernels; fp32 library GEMMs with " + (
                            "TunableOp picks" if os.path.exists(tuned.replace("_bf16.csv", "_fp32.csv")) and not args.no_tuned_gemm else "the default heuristic")}
     # BASELINE configs[4] at its stated size next to it: HEAL-SWIN-T, nside 256, 8 base pixels, depth head (f_out = 1), fp32, masked
@@ -421,6 +490,40 @@ def main():
                                "eager_over_graph": (elapsed / args.steps) / (rg.elapsed / kg),
                                "note": "whole step (zero_grad, fwd, CE, bwd, Adam) captured once and replayed; the headline `value` stays the "
                                        "eager step because the roofline brackets need per-launch HIP events"}
+    # the reference's own model next to the headline: BASELINE configs[1] (T @ nside 128) and the paper config (T @ nside 256,
+    # ring_shift + cosine attention + v2 norms), bf16, same batch, eager AND replayed from one HIP graph (these steps are short
+    # enough for host launch latency to matter: the faster of the two is the value, `launch` says which)
+    if world == 1 and args.dtype == "bf16" and args.workload == "B256" and not args.no_companions and not args.graph and not args.tune_gemm:
+        out["companions"] = {}
+        for key in COMPANION_WORKLOADS:
+            w = WORKLOADS[key]
+            cctx = types.SimpleNamespace(**{**vars(ctx), "wl": w})
+            re_ = run_workload(cctx, "bf16", 8, 2, timing=True)
+            gctx = types.SimpleNamespace(**{**vars(cctx), "args": argparse.Namespace(**{**vars(args), "graph": True})})
+            rg_ = run_workload(gctx, "bf16", 8, 2, timing=False)
+            best = min(re_.elapsed, rg_.elapsed)
+            tf = 3 * w["fwd_gflop_per_image"] * args.batch * 8 / best / 1e3
+            rl = roofline_of(re_.timings, re_.elapsed)
+            out["companions"][key] = {
+                "workload": w["name"], "value": args.batch * 8 / best, "unit": "images/s", "batch_per_gpu": args.batch, "steps": 8, "warmup": 2,
+                "launch": "hip graph replay" if rg_.elapsed < re_.elapsed else "eager",
+                "ms_per_step_eager": 1e3 * re_.elapsed / 8, "ms_per_step_graph": 1e3 * rg_.elapsed / 8, "final_loss": re_.loss,
+                "achieved_TFLOPs": tf, "frac_of_dense_bf16_peak": tf / MFMA_PEAK_TFLOPS,
+                "attention_roofline": {"bound": "hbm", "achieved": rl["achieved"], "peak": rl["peak"], "unit": "GB/s", "frac": rl["frac"],
+                                       "avg_launch_us": rl["avg_launch_us"], "launches": rl["launches"], "measured_in": "the eager run"}}
+    if rank == 0 and res.timings and world == 1 and not args.no_kernel_timing:
+        # the WindowAttention MODULE (qkv Linear + fused core + proj Linear, forward + input gradients + weight gradients) at the
+        # step's shapes: north_star's ">= 40 % MFMA utilisation in windowed attention" is a statement about this unit, not about
+        # the 32-flop/B core kernels the `roofline` object above brackets
+        try:
+            out["roofline"]["module"] = module_roofline(ctx)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["module"] = {"error": repr(e)}
+        if not args.no_pmc_traffic:
+            recs = measure_pmc_traffic(args.workload, args.batch)
+            if recs is not None:
+                out["roofline"] = {**roofline_of(res.timings, elapsed, detail=args.kernel_table, traffic_records=recs),
+                                   "module": out["roofline"]["module"]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
@@ -429,7 +532,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_of(timings, elapsed, detail=False):
+def roofline_of(timings, elapsed, detail=False, traffic_records=None):
     """attention roofline = attention flops of the timed launches (fwd + bwd) / their measured time against the
     dense bf16 MFMA peak; the HBM view of the same launches (algorithmic bytes / time against 8 TB/s) is kept beside it
     because a core-only attention kernel (32 flop/B) is bandwidth-bound by construction."""
@@ -454,15 +557,15 @@ def roofline_of(timings, elapsed, detail=False):
     fwd_n = sum(a[3] for t, a in attn.items() if t.endswith("_fwd"))
     bwd_n = sum(a[3] for t, a in attn.items() if t.endswith("_bwd"))
     tf_8d = (fwd_f + 2.0 * fwd_f * (bwd_n / fwd_n if fwd_n else 0.0)) / tot_t / 1e12
-    traffic = pmc_traffic_per_launch({t: a for t, a in attn.items() if t in ("window_attn_fwd", "window_attn_bwd")})
+    traffic, traffic_source = pmc_traffic_per_launch({t: a for t, a in attn.items() if t in ("window_attn_fwd", "window_attn_bwd")},
+                                                     traffic_records)
     return {
         "kernel": " + ".join(sorted(attn)) + " (fused shift / window partition / attention / reverse)",
         # a core-only attention kernel is 32 flop/B: HBM is the bound that applies; the MFMA fraction is the
         # north_star's target metric and is carried beside it
         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
         "traffic": traffic,
-        "traffic_source": "profiles/r03_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same "
-                          "kernels and shapes; looked up, not measured in this run)" if traffic is not None else None,
+        "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": tot_b / launches,
         # what a pure read stream reaches on this chip (tools/microbench/fill_rate.hip, 1 GB working set, every CU
         # streaming: profiles/r02_microbench_fill_rate.txt) -- the vendor figure above is the contract's denominator
@@ -476,6 +579,55 @@ def roofline_of(timings, elapsed, detail=False):
                              "TFLOP/s": a[2] / a[0] / 1e12, "share_of_step": a[0] / elapsed}
                        for tag, a in (agg if detail else fold_gemm_tags(agg)).items()},
     }
+
+
+def module_roofline(ctx, reps=3):
+    """Event-timed forward + backward of every distinct WindowAttention module of the workload (the block's attention branch:
+    qkv Linear -> fused shift / window / attention core -> proj Linear, with their input- and weight-gradient kernels) on random
+    bf16 activations of the step's shapes, weighted by the number of blocks of that shape per step.  Standalone launches on the
+    idle GPU after the timed region (inside the step these kernels are interleaved with the norms and the MLP)."""
+    from heal_swin_amd.models_torch.swin_hp_transformer import SwinTransformerBlock
+
+    wl, dev, batch = ctx.wl, ctx.dev, getattr(ctx, "batch", None) or ctx.args.batch
+    model, cfg, spec = build_model(wl)
+    model = model.to(dev).train()
+    model.compute_dtype = torch.bfloat16
+    groups = {}
+    for m in model.modules():
+        if isinstance(m, SwinTransformerBlock):
+            groups.setdefault((m.dim, m.input_resolution, m._shifted), []).append(m)
+    tot_s, tot_flop, per = 0.0, 0.0, []
+    for (C, N, shifted), blks in sorted(groups.items()):
+        blk = blks[0]
+        x = torch.randn(batch, N, C, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        dy = torch.randn(batch, N, C, device=dev, dtype=torch.bfloat16)
+        ts = []
+        for it in range(reps + 1):
+            for p_ in blk.parameters():
+                p_.grad = None
+            x.grad = None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            blk._attention_branch(x).backward(dy)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            if it:
+                ts.append(e0.elapsed_time(e1) * 1e-3)
+        t = min(ts)
+        fwd_flop = batch * (8.0 * N * C * C + 4.0 * N * blk.window_size * C)  # qkv 6NC^2 + proj 2NC^2 + QK^T and PV
+        tot_s += t * len(blks)
+        tot_flop += 3.0 * fwd_flop * len(blks)
+        per.append({"C": C, "tokens": N, "shifted": bool(shifted), "blocks": len(blks), "ms_fwd_bwd": 1e3 * t,
+                    "TFLOP/s": 3.0 * fwd_flop / t / 1e12})
+        del x, dy
+    del model
+    torch.cuda.empty_cache()
+    tf = tot_flop / tot_s / 1e12
+    return {"kernel": "WindowAttention module: qkv Linear + window_attn core + proj Linear, fwd + dgrad + wgrad", "bound": "mfma",
+            "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+            "module_fwd_GFLOP_per_image": tot_flop / 3.0 / batch / 1e9, "ms_per_step": 1e3 * tot_s,
+            "flop_count": "3 x forward (8 N C^2 + 4 N Ws C per block), SURVEY 8d",
+            "measured": f"standalone, HIP events, min of {reps} after 1 warm-up per distinct (C, tokens, shifted)", "per_shape": per}
 
 
 def fold_gemm_tags(agg):

@@ -629,6 +629,11 @@ def _cast_param(p, dtype):
 OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice below; "0": library GEMMs only; "1": own kernel wherever legal
 
 
+# Set by parallel.GradBucketAllReduce while compute units are reserved for a co-resident gradient exchange (world > 1): every
+# bf16 Linear product then runs on hs_gemm_nt, whose persistent grids honour hs_set_reserved_cus.  The library GEMMs fill all
+# 256 CUs and cannot be masked: with 8 foreign workgroups resident they lose 64 % (256 -> 420 us, profiles/r03_cu_contention.json).
+# Costs ~3 ms per step on an idle chip (HS_OWN_GEMM=1 measurement of round 3), saves ~27 ms under contention (r04_cu_contention.json).
+PREFER_OWN_GEMM = False
 OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "4096"))
 OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "1024"))
 OWN_BIAS_MAX_K = int(os.environ.get("HS_OWN_BIAS_MAX_K", "0"))  # A/B: > 0 sends every bias / residual product with k <= this to hs_gemm_nt
@@ -646,7 +651,7 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     two thresholds for A/B runs."""
     if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 16:
         return False  # (n % 8: whole-row-segment stores; the model pads the 12-class head to 16 rows)
-    if OWN_GEMM == "1":
+    if OWN_GEMM == "1" or PREFER_OWN_GEMM:
         return True
     kk = k + k2
     if epi == _lib.HS_EPI_DGELU:

@@ -64,12 +64,17 @@ class GradBucketAllReduce:
         self._direct = False
         on_gpu = bool(self.params) and self.params[0].is_cuda
         self._reserved_prev = None
+        self._prefer_prev = None
         if on_gpu:
             from . import _lib
             want = (16 if (self._exchange and self.world > 1) else 0) if reserved_cus == "auto" else int(reserved_cus)
             self._reserved_prev = int(_lib.lib.hs_get_reserved_cus())
             if want != self._reserved_prev:
                 _lib.check(_lib.lib.hs_set_reserved_cus(want), "hs_set_reserved_cus")
+            if want > 0:  # CUs are reserved for the exchange: keep every GEMM on the kernels that honour the reservation
+                from . import ops as _ops
+                self._prefer_prev = _ops.PREFER_OWN_GEMM
+                _ops.PREFER_OWN_GEMM = True
         if (direct_wgrad or async_wgrad) and on_gpu:
             # kernels accumulate Linear / LayerNorm parameter gradients straight into the bucket views of the parameters
             # REGISTERED HERE (ops asks grad_buffer(p) per parameter; other models in the process are unaffected)
@@ -281,6 +286,10 @@ class GradBucketAllReduce:
             from . import _lib
             _lib.lib.hs_set_reserved_cus(self._reserved_prev)
             self._reserved_prev = None
+        if self._prefer_prev is not None:
+            from . import ops as _ops
+            _ops.PREFER_OWN_GEMM = self._prefer_prev
+            self._prefer_prev = None
         if not self._direct and self.async_wgrad is None:
             return
         from . import ops

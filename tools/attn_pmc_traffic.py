@@ -34,31 +34,43 @@ def attn_sequence(vals, names):
     return seq
 
 
-def main():
-    fetch, fn = per_dispatch(sys.argv[1], "FETCH_SIZE")
-    write, wn = per_dispatch(sys.argv[2], "WRITE_SIZE")
+def records(fetch_csv, write_csv, trace_csv, wl=None, batch=8):
+    """wl: a bench.py WORKLOADS entry (default: HEAL-SWIN-B @ nside 256, 12 base pixels)."""
+    fetch, fn = per_dispatch(fetch_csv, "FETCH_SIZE")
+    write, wn = per_dispatch(write_csv, "WRITE_SIZE")
     dur = {}
-    for r in csv.DictReader(open(sys.argv[3])):
+    for r in csv.DictReader(open(trace_csv)):
         dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     fs, ws = attn_sequence(fetch, fn), attn_sequence(write, wn)
     assert len(fs) == len(ws) and len(fs) % 12 == 0, (len(fs), len(ws))
-    B, N0, C0 = 8, 196608, 128
-    records = []
+    if wl is None:
+        N0, C0, nstage = 196608, 128, 4
+    else:
+        N0, C0 = wl["base_pix"] * wl["nside"] ** 2 // 4, wl["cfg"]["embed_dim"]
+        nstage = len(wl["cfg"]["depths"])
+    shapes = [(N0 // 4 ** s, C0 * 2 ** s) for s in range(nstage) if N0 // 4 ** s >= 64]
+    out = []
     for cfg in range(len(fs) // 12):
         stage, shifted = cfg // 2, cfg % 2
-        E = B * (N0 // 4 ** stage) * (C0 * 2 ** stage) * 2  # bytes of one [B, N, C] bf16 tensor
+        N, C = shapes[stage]
+        E = batch * N * C * 2  # bytes of one [B, N, C] bf16 tensor
         for kern, mult in (("hs_window_attn_fwd", 4), ("hs_window_attn_bwd", 7)):  # bwd: q, k, v, dO in, dq, dk, dv out (no O read since round 3)
             f = [v for k, v, _ in fs[cfg * 12:(cfg + 1) * 12] if k == kern]
             w = [v for k, v, _ in ws[cfg * 12:(cfg + 1) * 12] if k == kern]
             t = [dur[d] for k, _, d in fs[cfg * 12:(cfg + 1) * 12] if k == kern and d in dur]
             fk, wk = sum(f) / len(f), sum(w) / len(w)
             hbm = (2 * fk + wk) * 1024
-            records.append({"stage": stage, "shifted": shifted, "kernel": kern, "launches": len(f), "FETCH_SIZE_KiB": fk,
-                            "WRITE_SIZE_KiB": wk, "hbm_bytes_corrected": hbm, "algorithmic_bytes": mult * E,
-                            "traffic_over_algorithmic": hbm / (mult * E), "avg_us_under_pmc": sum(t) / max(1, len(t))})
+            out.append({"stage": stage, "shifted": shifted, "kernel": kern, "launches": len(f), "FETCH_SIZE_KiB": fk,
+                        "WRITE_SIZE_KiB": wk, "hbm_bytes_corrected": hbm, "algorithmic_bytes": mult * E,
+                        "traffic_over_algorithmic": hbm / (mult * E), "avg_us_under_pmc": sum(t) / max(1, len(t))})
+    return out
+
+
+def main():
+    recs = records(sys.argv[1], sys.argv[2], sys.argv[3])
     print(json.dumps({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/bench_attn.py --iters 2 "
                               "(HEAL-SWIN-B stage shapes, batch 8, bf16); corrected per MI355X_MICROARCH.md HBM section: KiB units, "
-                              "FETCH_SIZE x2 on gfx950 for wide coalesced reads (tools/attn_pmc_traffic.py)", "records": records}, indent=1))
+                              "FETCH_SIZE x2 on gfx950 for wide coalesced reads (tools/attn_pmc_traffic.py)", "records": recs}, indent=1))
 
 
 if __name__ == "__main__":

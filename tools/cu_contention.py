@@ -5,7 +5,8 @@ to exactly one resident round of all 256 CUs, and what does hs_set_reserved_cus(
 
 A stand-in (`hs_debug_occupy_cus`: k workgroups of 256 threads, 128 VGPRs, 16 KB LDS, resident for the whole measurement on a side
 stream) plays the communication kernels.  Measured: (1) the chip-filling kernels one by one at the HEAL-SWIN-B stage-2 shapes,
-(2) the whole B / nside 256 / batch 8 training step.  Writes JSON to stdout (-> profiles/r03_cu_contention.json)."""
+(2) the whole B / nside 256 / batch 8 training step.  Round 4: a duty-cycled occupier shaped like the real exchange beside the always-resident one, and the step with every GEMM on
+hs_gemm_nt (ops.PREFER_OWN_GEMM).  Writes JSON to stdout (-> profiles/r04_cu_contention.json)."""
 import json
 import os
 import sys
@@ -100,29 +101,69 @@ def step_case():
     return step, dp
 
 
+def timed_duty(fn, iters, k, step_ms, bursts=10, burst_us=400.0):
+    """the same with a DUTY-CYCLED occupier shaped like the real exchange of a data-parallel step: `bursts` launches of k
+    workgroups x `burst_us` per step, evenly spaced, issued from a second host thread onto the side stream"""
+    import threading
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    stop = threading.Event()
+
+    def pulse():
+        gap = step_ms * 1e-3 / bursts
+        while not stop.is_set():
+            occupy(k, burst_us)
+            time.sleep(gap)
+
+    th = threading.Thread(target=pulse, daemon=True)
+    th.start()
+    time.sleep(0.005)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    stop.set()
+    th.join()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    torch.cuda.synchronize()
+    return us
+
+
 def main():
-    out = {"device": torch.cuda.get_device_name(0), "occupier": "k workgroups x 256 threads, 128 VGPRs, 16 KB LDS, resident on a side stream",
-           "kernels": [], "step": []}
+    out = {"device": torch.cuda.get_device_name(0), "occupier": "k workgroups x 256 threads, 128 VGPRs, 16 KB LDS on a side stream: "
+           "`resident` for the whole measurement, or `duty` = 10 bursts x 0.4 ms per step (the shape of the real gradient exchange: "
+           "596 MB of fp32 buckets per 160 ms step)", "kernels": [], "step": []}
     cases = kernel_cases()
-    for reserved in (0, 16, 32):
+    for reserved in (0, 16):
         check(lib.hs_set_reserved_cus(reserved), "hs_set_reserved_cus")
         for name, fn, est in cases:
             row = {"kernel": name, "reserved_cus": reserved, "us": {}}
-            for k in (0, 8, 16, 32):
+            for k in (0, 8, 16):
                 row["us"][str(k)] = round(timed(fn, 10, k, est), 1)
             out["kernels"].append(row)
             print(row, file=sys.stderr, flush=True)
     del cases
     torch.cuda.empty_cache()
-    for reserved in (0, 16, 32):
+    # whole step: library GEMMs where the per-shape policy picks them (idle-chip default) vs every bf16 Linear on hs_gemm_nt
+    # (what GradBucketAllReduce switches on when CUs are reserved, ops.PREFER_OWN_GEMM)
+    for reserved, own in ((0, False), (16, False), (16, True)):
         check(lib.hs_set_reserved_cus(reserved), "hs_set_reserved_cus")
         step, dp = step_case()
-        row = {"workload": "HEAL-SWIN-B nside 256 batch 8 bf16 train step", "reserved_cus": reserved, "ms": {}}
-        for k in (0, 8, 16, 32):
-            row["ms"][str(k)] = round(timed(step, 5, k, 170000) / 1e3, 2)
+        ops.PREFER_OWN_GEMM = own
+        row = {"workload": "HEAL-SWIN-B nside 256 batch 8 bf16 train step", "reserved_cus": reserved,
+               "gemms": "all bf16 Linear products on hs_gemm_nt" if own else "per-shape policy (hipBLASLt for the MFMA-bound products)", "ms": {}}
+        row["ms"]["idle"] = round(timed(step, 5, 0, 170000) / 1e3, 2)
+        for k in (8, 16):
+            row["ms"][f"resident k={k}"] = round(timed(step, 5, k, 170000) / 1e3, 2)
+        for k in (8, 16):
+            row["ms"][f"duty k={k}"] = round(timed_duty(step, 5, k, row["ms"]["idle"]) / 1e3, 2)
         out["step"].append(row)
         print(row, file=sys.stderr, flush=True)
         dp.remove()
+        ops.PREFER_OWN_GEMM = False
         del step, dp
         torch.cuda.empty_cache()
     check(lib.hs_set_reserved_cus(0), "hs_set_reserved_cus")
