@@ -316,6 +316,8 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="print the per-shape table of the event-timed launches to stderr")
     ap.add_argument("--no-fp32-companion", action="store_true", help="skip the fp32 run of the same workload (N = 1 only)")
     ap.add_argument("--no-graph-companion", action="store_true", help="skip the HIP-graph replay of the same workload (N = 1 only)")
+    ap.add_argument("--unfused-loss", action="store_true",
+                    help="call the model and losses.seg_loss separately (logits materialised) instead of model.forward_seg_loss")
     ap.add_argument("--no-companions", action="store_true", help="skip the HEAL-SWIN-T companion workloads (T128, T256; N = 1 only)")
     ap.add_argument("--no-pmc-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 counter passes after the timed region (N = 1 only); look it up in profiles/ instead")
@@ -442,7 +444,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "step": "fwd + CE loss + bwd + grad all-reduce + Adam",
+                       "parallelism": f"dp{world}",
+                       "step": "fwd + CE loss + bwd + grad all-reduce + Adam" + ("" if args.unfused_loss else " (loss fused into the decoder tail: model.forward_seg_loss)"),
                        "launch": "hip graph replay" if args.graph else "eager",
                        "params_M": res.params_m, "final_loss": res.loss,
                        "library_gemm_selection": gemm_selection},
@@ -674,10 +677,15 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
         labels = torch.randint(0, spec["f_out"], (batch, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
         loss_fn = seg_loss
 
+    fused_loss = wl.get("task") != "depth" and not args.unfused_loss
+
     def step():
         dp.zero_grad()
-        logits = model(imgs.float())  # the caller's `.float()` (model_lightning_swin_hp.py:61)
-        loss = loss_fn(logits, labels)
+        if fused_loss:  # model + the caller's CrossEntropyLoss in one call: the loss rides on the decoder tail's kernels
+            loss = model.forward_seg_loss(imgs.float(), labels)
+        else:
+            logits = model(imgs.float())  # the caller's `.float()` (model_lightning_swin_hp.py:61)
+            loss = loss_fn(logits, labels)
         loss.backward()
         dp.finish()
         opt.step()

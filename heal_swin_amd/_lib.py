@@ -43,6 +43,9 @@ _SIGNATURES = {
     "hs_ln_head_supported": [c_int, c_int, c_int],
     "hs_expand_ln_head_supported": [c_int, c_int, c_int, c_int],
     "hs_expand_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
+    "hs_expand_ln_head_ce_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int,
+                                 c_int, c_ptr],
+    "hs_ln_head_ce_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
     "hs_ln_head_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_ln_head_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_sample_bilinear_u8": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
@@ -93,6 +96,7 @@ _OTHER = {
     "hs_layernorm_bwd_workspace": ([c_i64, c_int], c_i64),
     "hs_seg_ce_partials": ([c_i64, c_i64], c_i64),
     "hs_ln_head_partials": ([c_i64], c_i64),
+    "hs_expand_ln_head_blocks": ([c_i64], c_i64),
     "hs_linear_wgrad_workspace": ([c_i64, c_int, c_int], c_i64),
     "hs_window_attn_bwd_workspace": ([c_int, c_i64, c_int, c_int, c_int, c_int], c_i64),
     "hs_patch_merge_bwd_workspace": ([c_i64, c_int, c_int], c_i64),

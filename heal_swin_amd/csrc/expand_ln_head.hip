@@ -38,13 +38,23 @@ __device__ __forceinline__ uint4 pack8f(const float* f) {
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// Optional fused loss (the caller's CrossEntropyLoss(weight), models_lightning/segmentation/model_lightning_swin_hp.py:
+// 39-45, 104-111): the 16 logits of a pixel row sit in one lane pair, so log-sum-exp, the label's logit and the row's weighted
+// term are eight registers + one lane^32 exchange away; with `logits == nullptr` the [rows, 16] fp32 tensor is never written.
+struct TailCe {
+    const uint8_t* labels;  // [rows] class ids in pixel order (rows = (token, child)); ids >= n_classes are ignored (weight 0)
+    const float* class_w;   // [n_classes] or null (all ones)
+    float* loss_part;       // [4 * gridDim.x][2]: per-wave sums of w (lse - logit_y) and of w
+    int n_classes;
+};
+
 template <int NB>
 __global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ xn_lo,
                                                                     const uint16_t* __restrict__ wexp,
                                                                     const uint16_t* __restrict__ wfold, const float* __restrict__ bvec,
                                                                     uint16_t* __restrict__ y, float* __restrict__ logits,
                                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                                    int64_t tokens) {
+                                                                    int64_t tokens, TailCe ce) {
     constexpr int C = 32 * NB, KS = 2 * NB, NCH = C / 8;  // channels (= input width), 16-deep k-steps, 16-byte chunks per row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;                                  // [kP * C][kRowB], 16-byte chunk ^ (row & 15)
@@ -78,6 +88,7 @@ __global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16
 
     const int sx = l31 & 15;
     const float inv_c = 1.f / (float)C;
+    float ce_num = 0.f, ce_den = 0.f;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (tid >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t tok0 = wave * 32; tok0 < tokens; tok0 += nwaves * 32) {
         const int64_t tok = tok0 + l31;
@@ -190,15 +201,50 @@ __global__ void __launch_bounds__(256, 1) expand_ln_head_fwd_kernel(const uint16
                     lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfa[ct][j], __builtin_bit_cast(bf16x8, pack8f(lo)), lg, 0, 0, 0);
                     lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfl[ct][j], __builtin_bit_cast(bf16x8, hb), lg, 0, 0, 0);
                 }
+            if (ce.labels) {  // weighted cross-entropy of the row, from the fp32 logits in registers
+                constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+                float v[8];
+                float m = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    v[r] = lg[r] + bk[r];
+                    if (4 * half + (r & 3) + 8 * (r >> 2) < ce.n_classes) m = fmaxf(m, v[r]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const int yl = live ? (int)ce.labels[orow] : 255;
+                float ssum = 0.f, pick = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int cls = 4 * half + (r & 3) + 8 * (r >> 2);
+                    if (cls < ce.n_classes) ssum += __builtin_amdgcn_exp2f((v[r] - m) * kLog2e);
+                    pick = cls == yl ? v[r] : pick;
+                }
+                ssum += __shfl_xor(ssum, 32, 64);
+                pick += __shfl_xor(pick, 32, 64);  // (the other half holds 0)
+                const float wy = yl < ce.n_classes ? (ce.class_w ? ce.class_w[yl] : 1.f) : 0.f;
+                if (half == 0) {
+                    ce_num = fmaf(wy, m + __builtin_amdgcn_logf(ssum) * kLn2 - pick, ce_num);
+                    ce_den += wy;
+                }
+            }
             if (live) {
                 // accumulator register r = class 4 half + (r & 3) + 8 (r >> 2) of this lane's row: classes 0..15 are r = 0..7
-                *(float4*)(logits + orow * kKP + 4 * half) = make_float4(lg[0] + bk[0], lg[1] + bk[1], lg[2] + bk[2], lg[3] + bk[3]);
-                *(float4*)(logits + orow * kKP + 8 + 4 * half) = make_float4(lg[4] + bk[4], lg[5] + bk[5], lg[6] + bk[6], lg[7] + bk[7]);
+                if (logits) {
+                    *(float4*)(logits + orow * kKP + 4 * half) = make_float4(lg[0] + bk[0], lg[1] + bk[1], lg[2] + bk[2], lg[3] + bk[3]);
+                    *(float4*)(logits + orow * kKP + 8 + 4 * half) = make_float4(lg[4] + bk[4], lg[5] + bk[5], lg[6] + bk[6], lg[7] + bk[7]);
+                }
                 if (half == 0 && mean_out) {
                     mean_out[orow] = mean;
                     rstd_out[orow] = rstd;
                 }
             }
+        }
+    }
+    if (ce.labels) {  // every wave writes its pair (zeros if it owned no rows): the host sums the array
+        const float n = wave_sum(ce_num), d = wave_sum(ce_den);
+        if (lane == 0) {
+            ce.loss_part[2 * wave] = n;
+            ce.loss_part[2 * wave + 1] = d;
         }
     }
 }
@@ -212,22 +258,21 @@ int hs_expand_ln_head_supported(int width, int children, int n_classes, int dtyp
     return dtype == HS_BF16 && children == hs::kP && width % 32 == 0 && width >= 64 && width <= 128 && n_classes >= 1 && n_classes <= 16;
 }
 
-int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits,
-                          float* mean, float* rstd, int64_t tokens, int width, int children, int dtype, void* stream) {
+namespace {
+int launch_expand_ln_head(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits,
+                          float* mean, float* rstd, int64_t tokens, int width, int children, int dtype, void* stream, hs::TailCe ce,
+                          const char* who) {
     using namespace hs;
-    HS_CHECK_ARG(xn && wexp && wfold && bvec && logits, "hs_expand_ln_head_fwd: null pointer");
-    HS_CHECK_ARG(tokens > 0, "hs_expand_ln_head_fwd: bad shape");
+    HS_CHECK_ARG(xn && wexp && wfold && bvec, "%s: null pointer", who);
+    HS_CHECK_ARG(tokens > 0, "%s: bad shape", who);
     HS_CHECK_ARG((y == nullptr) == (mean == nullptr) && (mean == nullptr) == (rstd == nullptr),
-                 "hs_expand_ln_head_fwd: y, mean and rstd (what the backward needs) go together");
+                 "%s: y, mean and rstd (what the backward needs) go together", who);
     if (!hs_expand_ln_head_supported(width, children, 1, dtype))
-        return fail(HS_ERR_UNSUPPORTED, "hs_expand_ln_head_fwd: bf16, 4 children, C in {64, 96, 128} (got C = %d, children %d): the expand "
-                    "weight must fit the LDS", width, children);
+        return fail(HS_ERR_UNSUPPORTED, "%s: bf16, 4 children, C in {64, 96, 128} (got C = %d, children %d): the expand "
+                    "weight must fit the LDS", who, width, children);
     const int nb = width / 32;
     const size_t smem = (size_t)kP * width * kRowB + 4 * 32 * kPatchRow;
-    int64_t blocks = (tokens + 127) / 128;  // 4 waves x 32 tokens per workgroup and step
-    const int cus = usable_cus();
-    if (blocks > cus) blocks = cus;
-    const dim3 grid((unsigned)blocks), block(256);
+    const dim3 grid((unsigned)hs_expand_ln_head_blocks(tokens)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define HS_ELH(NB)                                                                                                                  \
     case NB: {                                                                                                                      \
@@ -238,7 +283,7 @@ int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, c
             configured = true;                                                                                                      \
         }                                                                                                                           \
         hipLaunchKernelGGL(kern, grid, block, smem, s, (const uint16_t*)xn, (const uint16_t*)xn_lo, (const uint16_t*)wexp, (const uint16_t*)wfold, bvec, \
-                           (uint16_t*)y, logits, mean, rstd, tokens);                                                              \
+                           (uint16_t*)y, logits, mean, rstd, tokens, ce);                                                          \
     } break;
     switch (nb) {
         HS_ELH(2) HS_ELH(3) HS_ELH(4)
@@ -246,6 +291,30 @@ int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, c
 #undef HS_ELH
     HS_LAUNCH_CHECK("expand_ln_head_fwd");
     return HS_OK;
+}
+}  // namespace
+
+int64_t hs_expand_ln_head_blocks(int64_t tokens) {
+    int64_t blocks = (tokens + 127) / 128;  // 4 waves x 32 tokens per workgroup and step
+    const int cus = hs::usable_cus();
+    if (blocks > cus) blocks = cus;
+    return blocks < 1 ? 1 : blocks;
+}
+
+int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits,
+                          float* mean, float* rstd, int64_t tokens, int width, int children, int dtype, void* stream) {
+    HS_CHECK_ARG(logits, "hs_expand_ln_head_fwd: null pointer");
+    return launch_expand_ln_head(xn, xn_lo, wexp, wfold, bvec, y, logits, mean, rstd, tokens, width, children, dtype, stream,
+                                 hs::TailCe{nullptr, nullptr, nullptr, 0}, "hs_expand_ln_head_fwd");
+}
+
+int hs_expand_ln_head_ce_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, const uint8_t* labels,
+                             const float* class_weights, int n_classes, void* y, float* logits, float* mean, float* rstd,
+                             float* loss_partials, int64_t tokens, int width, int children, int dtype, void* stream) {
+    HS_CHECK_ARG(labels && loss_partials, "hs_expand_ln_head_ce_fwd: null pointer");
+    HS_CHECK_ARG(n_classes >= 1 && n_classes <= 16, "hs_expand_ln_head_ce_fwd: 1..16 classes");
+    return launch_expand_ln_head(xn, xn_lo, wexp, wfold, bvec, y, logits, mean, rstd, tokens, width, children, dtype, stream,
+                                 hs::TailCe{labels, class_weights, loss_partials, n_classes}, "hs_expand_ln_head_ce_fwd");
 }
 
 }  // extern "C"

@@ -229,6 +229,154 @@ __global__ void __launch_bounds__(256) ln_head_bwd_kernel(const uint16_t* __rest
     }
 }
 
+// The backward with the loss fused in: instead of reading a [rows, 16] dlogits tensor the kernel recomputes the row's
+// logits from the saved expanded rows (xhat = (y - mean) rstd as hi + lo through the folded head weight, 3 MFMAs per 16 channels
+// in an HBM-bound kernel), takes softmax and the weighted cross-entropy gradient
+//     dlogits[row, k] = scale w[y] (softmax_k - [k == y]),   scale = dloss / sum_rows w[y]
+// in registers, and continues exactly as ln_head_bwd_kernel.  The rows of the folded weight arrive PERMUTED (blocks 4..7 and
+// 8..11 exchanged, ops._fold_head_ce) so that accumulator register r < 8 of lane half h is class 8 h + r: the 8 contiguous
+// classes of a lane are then directly the B operand of the g = dlogits (gamma W) product and the 16 bytes of D'.
+template <int NB>
+__global__ void __launch_bounds__(256) ln_head_ce_bwd_kernel(const uint16_t* __restrict__ y, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, const uint8_t* __restrict__ labels,
+                                                             const float* __restrict__ class_w, const float* __restrict__ scale_ptr,
+                                                             int n_classes, const uint16_t* __restrict__ wfold,
+                                                             const float* __restrict__ bvec, const uint16_t* __restrict__ afold,
+                                                             uint16_t* __restrict__ dy, uint16_t* __restrict__ dprime,
+                                                             float* __restrict__ part, int64_t rows) {
+    constexpr int C = NB * 32, NS = NB * 2;
+    constexpr float kLog2e = 1.4426950408889634f;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    bf16x8 wa[NS], wl[NS];  // folded head weight, hi and lo, rows permuted (see above)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        wa[s] = *(const bf16x8*)(wfold + l31 * C + 16 * s + 8 * half);
+        wl[s] = *(const bf16x8*)(wfold + (32 + l31) * C + 16 * s + 8 * half);
+    }
+    float bk[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bk[r] = bvec[4 * half + (r & 3) + 8 * (r >> 2)];
+    bf16x8 aa[NB];
+    {
+        const int hh = (l31 >> 2) & 1, j4 = l31 & 3, q = l31 >> 3;
+        const int c_in = 16 * (q >> 1) + 8 * hh + j4 + 4 * (q & 1);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) aa[i] = *(const bf16x8*)(afold + (32 * i + c_in) * kKP + 8 * half);
+    }
+    const float scale = scale_ptr[0];
+    float uacc[8], tacc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) uacc[j] = tacc[j] = 0.f;
+    const float inv_c = 1.f / (float)C;
+    for (int64_t row0 = wave * 32; row0 < rows; row0 += nwaves * 32) {
+        const int64_t row = row0 + l31;
+        const bool live = row < rows;
+        const float mean = live ? mean_in[row] : 0.f, rstd = live ? rstd_in[row] : 0.f;
+        const int yl = live ? (int)labels[row] : 255;
+        uint4 v[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = live ? *(const uint4*)(y + row * C + 16 * s + 8 * half) : make_uint4(0, 0, 0, 0);
+        // ---- the row's logits again: xhat (hi + lo) through the folded head weight (hi + lo)
+        float xh[NS][8];
+        f32x16 lg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lg[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            unpack8(v[s], xh[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xh[s][j] = (xh[s][j] - mean) * rstd;
+            const uint4 hb = pack8(xh[s]);
+            float hi[8], lo[8];
+            unpack8(hb, hi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = xh[s][j] - hi[j];
+            lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], __builtin_bit_cast(bf16x8, hb), lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], __builtin_bit_cast(bf16x8, pack8(lo)), lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s], __builtin_bit_cast(bf16x8, hb), lg, 0, 0, 0);
+        }
+        // ---- softmax and the cross-entropy gradient on this lane's classes 8 half .. 8 half + 7
+        float d[8];
+        {
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                d[r] = lg[r] + bk[r];
+                if (8 * half + r < n_classes) m = fmaxf(m, d[r]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float ssum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                d[r] = 8 * half + r < n_classes ? __builtin_amdgcn_exp2f((d[r] - m) * kLog2e) : 0.f;
+                ssum += d[r];
+            }
+            ssum += __shfl_xor(ssum, 32, 64);
+            const float wy = yl < n_classes ? (class_w ? class_w[yl] : 1.f) : 0.f;
+            const float coef = scale * wy, pinv = 1.f / ssum;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) d[r] = coef * (d[r] * pinv - (8 * half + r == yl ? 1.f : 0.f));
+        }
+        const uint4 dl = pack8(d);
+        f32x16 g[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[i][r] = 0.f;
+            g[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[i], __builtin_bit_cast(bf16x8, dl), g[i], 0, 0, 0);
+        }
+        {
+            float dp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dp[j] = d[j] * rstd;
+            const uint4 pk = pack8(dp);
+            float dr[8];
+            unpack8(pk, dr);  // the rounded values, as the weight-gradient kernel will read them
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uacc[j] += d[j];
+                tacc[j] = fmaf(dr[j], mean, tacc[j]);
+            }
+            if (live) *(uint4*)(dprime + row * kKP + 8 * half) = pk;
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gv = g[s >> 1][8 * (s & 1) + j];
+                s1 += gv;
+                s2 = fmaf(gv, xh[s][j], s2);
+            }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float m1 = s1 * inv_c, m2 = s2 * inv_c;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rstd * (g[s >> 1][8 * (s & 1) + j] - m1 - xh[s][j] * m2);
+            if (live) *(uint4*)(dy + row * C + 16 * s + 8 * half) = pack8(o);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            uacc[j] += __shfl_xor(uacc[j], off, 64);
+            tacc[j] += __shfl_xor(tacc[j], off, 64);
+        }
+    }
+    if (l31 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            part[wave * 32 + 8 * half + j] = uacc[j];
+            part[wave * 32 + 16 + 8 * half + j] = tacc[j];
+        }
+    }
+}
+
 int grid_for(int64_t rows) {
     int64_t b = (rows + 127) / 128;  // 4 waves x 32 rows per workgroup and step
     if (b > 256 * 8) b = 256 * 8;
@@ -291,6 +439,30 @@ int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const vo
     }
 #undef HS_LNH_BWD
     HS_LAUNCH_CHECK("ln_head_bwd");
+    return HS_OK;
+}
+
+int hs_ln_head_ce_bwd(const void* y, const float* mean, const float* rstd, const uint8_t* labels, const float* class_weights,
+                      const float* scale, int n_classes, const void* wfold, const float* bvec, const void* afold, void* dy, void* dprime,
+                      float* partials, int64_t rows, int width, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(y && mean && rstd && labels && scale && wfold && bvec && afold && dy && dprime && partials, "null pointer");
+    HS_CHECK_ARG(rows > 0, "bad shape");
+    HS_CHECK_ARG(n_classes >= 1 && n_classes <= 16, "hs_ln_head_ce_bwd: 1..16 classes");
+    if (!hs_ln_head_supported(width, n_classes, dtype) || width > 128)
+        return fail(HS_ERR_UNSUPPORTED, "hs_ln_head_ce_bwd: bf16 rows of 64..128 (multiple of 32) columns only");
+    const dim3 grid(grid_for(rows)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define HS_LNH_CE(NB)                                                                                                                   \
+    case NB:                                                                                                                            \
+        hipLaunchKernelGGL((ln_head_ce_bwd_kernel<NB>), grid, block, 0, s, (const uint16_t*)y, mean, rstd, labels, class_weights, scale, \
+                           n_classes, (const uint16_t*)wfold, bvec, (const uint16_t*)afold, (uint16_t*)dy, (uint16_t*)dprime, partials, rows); \
+        break;
+    switch (width / 32) {
+        HS_LNH_CE(2) HS_LNH_CE(3) HS_LNH_CE(4)
+    }
+#undef HS_LNH_CE
+    HS_LAUNCH_CHECK("ln_head_ce_bwd");
     return HS_OK;
 }
 

@@ -568,7 +568,9 @@ class UnetDecoder(nn.Module):
         self.output = nn.Conv1d(in_channels=config.embed_dim, out_channels=data_spec.f_out, kernel_size=1, bias=False)
         self.norm_up = _make_norm(config.norm_layer, config.embed_dim)
 
-    def forward(self, x, x_downsample):
+    def forward(self, x, x_downsample, ce=None):
+        """ce = (labels u8 [B, Npix], class weights or None): return the weighted cross-entropy of the logits instead of the logits
+        (SwinHPTransformerSys.forward_seg_loss); fused into the tail kernels where they apply."""
         dbg = self.config.dev_mode
         for inx, layer_up in enumerate(self.layers_up):
             if inx > 0:
@@ -590,15 +592,19 @@ class UnetDecoder(nn.Module):
             else:
                 xn = self.norm_up(x)
             B, N0, _ = xn.shape
+            if ce is not None and ce[0].dtype == torch.uint8 and torch.is_grad_enabled():
+                # training: expand -> LayerNorm -> head -> weighted CE in one forward kernel; the logits are never written
+                return ops.expand_ln_head_ce(xn.reshape(B * N0, up.dim), up.expand.weight, up.norm.weight, up.norm.bias, w,
+                                             ce[0].contiguous(), ce[1], xn_lo)
             lg = ops.expand_ln_head(xn.reshape(B * N0, up.dim), up.expand.weight, up.norm.weight, up.norm.bias, w, xn_lo)
-            return ops.pad_slice(lg.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2)  # B, f_out, Npix (fp32)
+            return self._maybe_loss(ops.pad_slice(lg.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2), ce)  # B, f_out, Npix (fp32)
         if isinstance(up.norm, HSLayerNorm) and ops.ln_head_ok(x, up.dim, f_out):
             # the tail's LayerNorm and the class head in one pass over the expanded rows (hs_ln_head_*): the normalised
             # [B, Npix, C] tensor is neither written nor kept for the backward
             x = up.expand(self.norm_up(x))  # B, N0, p * C: row (b, n) holds the p children of token n back to back
             B, N0, _ = x.shape
             x = ops.ln_head(x.reshape(B * N0 * up.patch_size, up.dim), up.norm.weight, up.norm.bias, w)
-            return ops.pad_slice(x.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2)  # B, f_out, Npix (fp32)
+            return self._maybe_loss(ops.pad_slice(x.view(B, N0 * up.patch_size, -1), f_out).transpose(1, 2), ce)  # B, f_out, Npix (fp32)
         x = up(self.norm_up(x))  # B, Npix, C
         if x.dtype == torch.bfloat16 and f_out % 8 and f_out > 8:
             # 12 classes: rows padded to 16 so that the input gradient (K = 12 -> 16) runs in hs_gemm_nt: 0.33 ms instead of the
@@ -606,7 +612,14 @@ class UnetDecoder(nn.Module):
             x = ops.pad_slice(ops.linear(x, F.pad(w.reshape(f_out, -1), (0, 0, 0, (-f_out) % 8))), f_out)
         else:
             x = ops.linear(x, w)
-        return x.float().transpose(1, 2)  # B, f_out, Npix; logits leave the model in fp32 whatever the compute dtype (see ops.LnHeadFn)
+        return self._maybe_loss(x.float().transpose(1, 2), ce)  # B, f_out, Npix; logits leave the model in fp32 whatever the compute dtype (see ops.LnHeadFn)
+
+    @staticmethod
+    def _maybe_loss(logits, ce):
+        if ce is None:
+            return logits
+        from ..losses import seg_loss
+        return seg_loss(logits, ce[0], ce[1])
 
 
 @dataclass
@@ -725,6 +738,27 @@ class SwinHPTransformerSys(nn.Module):
             with torch.autocast(device_type="cuda", enabled=False):
                 x, x_downsample = self.forward_features(x.to(dt))
                 return self.decoder(x, x_downsample)
+        finally:
+            ops.CAST_CACHE = prev
+
+    def forward_seg_loss(self, x, labels, class_weights=None):
+        """nn.CrossEntropyLoss(weight=class_weights)(self(x), labels.long()) -- the segmentation caller's training step
+        (models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111) -- as ONE call, so that the loss rides on the
+        decoder tail's kernels: in bf16 training the [B, f_out, Npix] logits and their gradient are never written (SURVEY 8f N2;
+        csrc/expand_ln_head.hip, csrc/ln_head.hip).  Where the fused tail does not apply (fp32, other widths, no gradient) this is
+        exactly losses.seg_loss(self(x), labels, class_weights).  labels: [B, Npix] integer class ids."""
+        if not x.is_cuda:
+            raise RuntimeError("SwinHPTransformerSys (heal_swin_amd) runs only on an MI355X (HIP) device; there is no CPU path")
+        if labels.dtype != torch.uint8 and self.data_spec.f_out <= 255:
+            labels = labels.to(torch.uint8)
+        w = None if class_weights is None else class_weights.to(device=x.device, dtype=torch.float32).contiguous()
+        dt = self._activation_dtype(x)
+        prev, ops.CAST_CACHE = ops.CAST_CACHE, self._param_casts(dt)
+        ops.LAST_CAST_CACHE = ops.CAST_CACHE
+        try:
+            with torch.autocast(device_type="cuda", enabled=False):
+                x, x_downsample = self.forward_features(x.to(dt))
+                return self.decoder(x, x_downsample, ce=(labels, w))
         finally:
             ops.CAST_CACHE = prev
 

@@ -913,8 +913,10 @@ class LnHeadFn(torch.autograd.Function):
         return (dy if ctx.needs_input_grad[0] else None), dgamma, dbeta, dw
 
 
-def _ln_head_backward(y2, mean, rstd, gamma, beta, weight, dlogits, want_params):
-    """(dy, dgamma, dbeta, dWhead) of logits = head(LayerNorm(y2)) by `hs_ln_head_bwd` + one weight-gradient product (LnHeadFn)."""
+def _ln_head_backward(y2, mean, rstd, gamma, beta, weight, dlogits, want_params, ce=None):
+    """(dy, dgamma, dbeta, dWhead) of logits = head(LayerNorm(y2)) by `hs_ln_head_bwd` + one weight-gradient product (LnHeadFn).
+    ce = (labels u8 [rows], class weights or None, scale f32[1]): the logits' gradient is that of the weighted cross-entropy and is
+    formed inside the kernel (`hs_ln_head_ce_bwd`) instead of being read."""
     rows, C = y2.shape
     f_out, KP = weight.shape[0], LnHeadFn.KP
     dev = y2.device
@@ -922,13 +924,21 @@ def _ln_head_backward(y2, mean, rstd, gamma, beta, weight, dlogits, want_params)
     g32, b32 = gamma.detach().float(), beta.detach().float()
     afold = torch.zeros((C, KP), dtype=torch.bfloat16, device=dev)
     afold[:, :f_out] = (w * g32).t().to(torch.bfloat16)
-    dlogits = dlogits.to(torch.float32).contiguous()
     dy = torch.empty_like(y2)
     dprime = torch.empty((rows, KP), dtype=torch.bfloat16, device=dev)
     part = torch.empty((int(lib.hs_ln_head_partials(rows)), 32), dtype=torch.float32, device=dev)
-    with _timed("ln_head_bwd", dev, rows * (4 * C + 6 * KP) + 8 * rows, 2 * rows * C * KP):
-        check(lib.hs_ln_head_bwd(ptr(y2), ptr(mean), ptr(rstd), ptr(dlogits), ptr(afold), ptr(dy), ptr(dprime), ptr(part), rows, C,
-                                 _lib.HS_BF16, _lib.HS_F32, stream_ptr(dev)), "hs_ln_head_bwd")
+    if ce is not None:
+        labels, class_w, scale = ce
+        wfold, bvec = _fold_head_ce(gamma, beta, weight, C, dev)
+        with _timed("ln_head_ce_bwd", dev, rows * (4 * C + 2 * KP + 1) + 8 * rows, 2 * rows * C * (KP + 96)):
+            check(lib.hs_ln_head_ce_bwd(ptr(y2), ptr(mean), ptr(rstd), ptr(labels), ptr(class_w), ptr(scale), f_out, ptr(wfold), ptr(bvec),
+                                        ptr(afold), ptr(dy), ptr(dprime), ptr(part), rows, C, _lib.HS_BF16, stream_ptr(dev)),
+                  "hs_ln_head_ce_bwd")
+    else:
+        dlogits = dlogits.to(torch.float32).contiguous()
+        with _timed("ln_head_bwd", dev, rows * (4 * C + 6 * KP) + 8 * rows, 2 * rows * C * KP):
+            check(lib.hs_ln_head_bwd(ptr(y2), ptr(mean), ptr(rstd), ptr(dlogits), ptr(afold), ptr(dy), ptr(dprime), ptr(part), rows, C,
+                                     _lib.HS_BF16, _lib.HS_F32, stream_ptr(dev)), "hs_ln_head_bwd")
     dgamma = dbeta = dw = None
     if want_params:
         ut = part.sum(0)
@@ -1005,6 +1015,72 @@ class ExpandLnHeadFn(torch.autograd.Function):
         ctx.w_cast = ctx.cast_cache = None
         dwexp, _ = _param_grads(dy2, xn2, wexp, None, ctx.needs_input_grad[1], False)
         return dxn, dwexp, dgamma, dbeta, dw, None
+
+
+def _fold_head_ce(gamma, beta, weight, C, device):
+    """The folded head weight for `hs_ln_head_ce_bwd`: as _fold_head, but with row blocks 4..7 and 8..11 exchanged, so that the
+    kernel's accumulator register r < 8 of lane half h is class 8 h + r (csrc/ln_head.hip:ln_head_ce_bwd_kernel)."""
+    wfold, bvec = _fold_head(gamma, beta, weight, C, device)
+    perm = torch.arange(32, device=device)
+    perm[4:8], perm[8:12] = torch.arange(8, 12, device=device), torch.arange(4, 8, device=device)
+    perm64 = torch.cat([perm, perm + 32])
+    return wfold[perm64].contiguous(), bvec[perm].contiguous()
+
+
+class ExpandLnHeadCeFn(torch.autograd.Function):
+    """The decoder tail AND the segmentation caller's weighted cross-entropy (reference swin_hp_transformer.py:442-452, :785-788 and
+    models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111) as one forward and one backward kernel
+    (`hs_expand_ln_head_ce_fwd`, `hs_ln_head_ce_bwd`): the [B, Npix, 16] fp32 logits and their gradient never exist in
+    HBM.  xn2 [tokens, C] bf16, labels u8 [4 tokens] in pixel order -> scalar loss (fp32)."""
+
+    @staticmethod
+    def forward(ctx, xn2, wexp, gamma, beta, weight, labels, class_w, xn_lo):
+        _require_gpu(xn2, wexp, gamma, beta, weight, labels, class_w, xn_lo)
+        tokens, C = xn2.shape
+        xn2 = xn2.contiguous()
+        xn_lo = None if xn_lo is None else xn_lo.reshape(tokens, C).contiguous()
+        P = wexp.shape[0] // C
+        f_out = weight.shape[0]
+        wq = _cast_param(wexp, torch.bfloat16).contiguous()
+        wfold, bvec = _fold_head(gamma, beta, weight, C, xn2.device)
+        need = any(ctx.needs_input_grad[:5])
+        rows = tokens * P
+        labels = labels.reshape(-1)
+        assert labels.dtype == torch.uint8 and labels.numel() == rows and labels.is_contiguous(), "labels: contiguous uint8, one per pixel row"
+        y = torch.empty((rows, C), dtype=torch.bfloat16, device=xn2.device) if need else None
+        mean = torch.empty(rows, dtype=torch.float32, device=xn2.device) if need else None
+        rstd = torch.empty_like(mean) if need else None
+        parts = torch.empty((4 * int(lib.hs_expand_ln_head_blocks(tokens)), 2), dtype=torch.float32, device=xn2.device)
+        # algorithmic traffic: xn in, labels in (+ the expanded rows once in training); no logits
+        with _timed("expand_ln_head_ce_fwd", xn2.device, 2 * tokens * C + rows * (1 + (2 * C + 8 if need else 0)),
+                    2 * rows * C * C + 4 * rows * C * 32):
+            check(lib.hs_expand_ln_head_ce_fwd(ptr(xn2), ptr(xn_lo), ptr(wq), ptr(wfold), ptr(bvec), ptr(labels), ptr(class_w), f_out,
+                                               ptr(y), None, ptr(mean), ptr(rstd), ptr(parts), tokens, C, P, _lib.HS_BF16,
+                                               stream_ptr(xn2.device)), "hs_expand_ln_head_ce_fwd")
+        tot = parts.sum(0)
+        ctx.save_for_backward(xn2, y, mean, rstd, gamma, beta, weight, wexp, labels, class_w, tot)
+        ctx.w_cast = wq if wq.dtype != wexp.dtype else None
+        ctx.cast_cache = CAST_CACHE
+        return tot[0] / tot[1]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        xn2, y, mean, rstd, gamma, beta, weight, wexp, labels, class_w, tot = ctx.saved_tensors
+        tokens, C = xn2.shape
+        scale = (dloss.to(torch.float32) / tot[1]).reshape(1)
+        dy, dgamma, dbeta, dw = _ln_head_backward(y, mean, rstd, gamma, beta, weight, None, any(ctx.needs_input_grad[2:5]),
+                                                  ce=(labels, class_w, scale))
+        dy2 = dy.view(tokens, wexp.shape[0])
+        dxn = _input_grad(dy2, wexp, ctx.w_cast, None, ctx.cast_cache) if ctx.needs_input_grad[0] else None
+        ctx.w_cast = ctx.cast_cache = None
+        dwexp, _ = _param_grads(dy2, xn2, wexp, None, ctx.needs_input_grad[1], False)
+        return dxn, dwexp, dgamma, dbeta, dw, None, None, None
+
+
+def expand_ln_head_ce(xn2, wexp, gamma, beta, weight, labels, class_weights=None, xn_lo=None):
+    """Weighted cross-entropy of head(LayerNorm(expand(xn2 [+ xn_lo]) viewed per child)) against uint8 pixel labels, without the
+    logits (ExpandLnHeadCeFn)."""
+    return ExpandLnHeadCeFn.apply(xn2, wexp, gamma, beta, weight, labels, class_weights, xn_lo)
 
 
 def expand_ln_head(xn2, wexp, gamma, beta, weight, xn_lo=None):

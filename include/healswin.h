@@ -410,6 +410,27 @@ int hs_expand_ln_head_supported(int width, int children, int n_classes, int dtyp
 int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, void* y, float* logits,
                           float* mean, float* rstd, int64_t tokens, int width, int children, int dtype, void* stream);
 
+/* The tail WITH the segmentation caller's loss (nn.CrossEntropyLoss(weight=...)(logits, masks.long()),
+ * models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111): the forward kernel above additionally takes the pixel
+ * labels, forms the weighted cross-entropy of every row from the fp32 logits it holds in registers and writes per-wavefront partial
+ * sums; with logits == NULL the [4 tokens, 16] fp32 logits tensor is never written (training: 403 MB at nside 256, batch 8, plus the
+ * loss kernels' 3 passes over it).  The backward recomputes the row's logits from the saved expanded rows y, forms
+ * dlogits = scale w[label] (softmax - onehot) in registers and continues as hs_ln_head_bwd (same outputs).
+ *   labels [dev] u8[4 tokens] in pixel order (row = 4 token + child); ids >= n_classes carry weight 0;
+ *   class_weights [dev] f32[n_classes] or NULL (all ones);
+ *   loss_partials [dev] f32[4 * hs_expand_ln_head_blocks(tokens), 2]: sums of w (lse - logit_label) and of w per wavefront:
+ *                 loss = sum(col 0) / sum(col 1)  (the reference's weighted mean);
+ *   backward: scale [dev] f32[1] = dloss / sum(col 1); wfold [dev] bf16[64, C] and bvec [dev] f32[32] as for the forward but with row
+ *             blocks 4..7 and 8..11 EXCHANGED (heal_swin_amd/ops.py:_fold_head_ce; csrc/ln_head.hip says why); afold, dy, dprime,
+ *             partials as for hs_ln_head_bwd.  bf16, C in {64, 96, 128}. */
+int64_t hs_expand_ln_head_blocks(int64_t tokens);
+int hs_expand_ln_head_ce_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, const uint8_t* labels,
+                             const float* class_weights, int n_classes, void* y, float* logits, float* mean, float* rstd,
+                             float* loss_partials, int64_t tokens, int width, int children, int dtype, void* stream);
+int hs_ln_head_ce_bwd(const void* y, const float* mean, const float* rstd, const uint8_t* labels, const float* class_weights,
+                      const float* scale, int n_classes, const void* wfold, const float* bvec, const void* afold, void* dy, void* dprime,
+                      float* partials, int64_t rows, int width, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * PatchMerging / PatchExpand / FinalPatchExpand_X4 as one operator call per module and direction (SURVEY 8b's proposed
  * hs_patch_merge_* / hs_patch_expand_*).  In nested HEALPix order the reference's data movement is a free view -- the four

@@ -162,3 +162,90 @@ def test_tail_with_hi_lo_norm_up_output():
     import conftest
     conftest.NOTES.append(f"fused tail logits vs fp32 composition on the exact norm_up output: {e_lo:.2e} with xn_lo, {e_hi:.2e} without")
     assert e_lo <= 1e-3 and e_lo < 0.6 * e_hi
+
+
+def reference_tail_ce(xn, wexp, gamma, beta, w, labels, class_w, P=4):
+    """fp32 composition of FinalPatchExpand_X4 + head + nn.CrossEntropyLoss(weight) (the segmentation caller's loss,
+    models_lightning/segmentation/model_lightning_swin_hp.py:39-45, :104-111), on bf16-exact inputs."""
+    xn = xn.float().detach().requires_grad_(True)
+    wexp, gamma, beta, w = (t.detach().clone().requires_grad_(True) for t in (wexp, gamma, beta, w))
+    C = xn.shape[-1]
+    yv = F.linear(xn, wexp).reshape(-1, C)
+    logits = F.linear(F.layer_norm(yv, (C,), gamma, beta, 1e-5), w)
+    loss = F.cross_entropy(logits, labels.long(), weight=class_w)
+    loss.backward()
+    return loss.detach(), xn.grad, wexp.grad, gamma.grad, beta.grad, w.grad
+
+
+@pytest.mark.parametrize("tokens,C,f_out,weighted", [(4096, 128, 12, True), (1000, 96, 12, False), (33, 64, 5, True), (70000, 128, 16, True),
+                                                     (5000, 128, 1, False)])
+def test_expand_ln_head_ce_matches_the_composition(tokens, C, f_out, weighted):
+    """`hs_expand_ln_head_ce_fwd` + `hs_ln_head_ce_bwd` (the decoder tail with the caller's weighted cross-entropy fused in: no
+    logits tensor) against the fp32 composition of the reference modules + nn.CrossEntropyLoss: the loss to 1e-3
+    (north_star's fp32 bound: the kernel keeps fp32 from the expand product to the loss), every gradient to the bf16 bound."""
+    from heal_swin_amd import ops
+
+    torch.manual_seed(tokens + C + f_out)
+    dev = "cuda"
+    xn = (torch.randn(tokens, C, device=dev) * 1.3 + 0.2).to(torch.bfloat16)
+    wexp = (torch.randn(4 * C, C, device=dev) * C ** -0.5).to(torch.bfloat16).float().requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, device=dev)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, device=dev)).requires_grad_(True)
+    w = (torch.randn(f_out, C, 1, device=dev) * 2.0 * C ** -0.5).requires_grad_(True)
+    labels = torch.randint(0, f_out, (4 * tokens,), device=dev, dtype=torch.uint8)
+    cw = (0.2 + torch.rand(f_out, device=dev)) if weighted else None
+    xq = xn.clone().requires_grad_(True)
+    loss = ops.expand_ln_head_ce(xq, wexp, gamma, beta, w, labels, cw)
+    assert loss.dtype == torch.float32 and loss.dim() == 0
+    (loss * 3.0).backward()  # (a non-trivial incoming gradient)
+    ref_loss, ref_dx, ref_dwe, ref_dg, ref_db, ref_dw = reference_tail_ce(xn, wexp, gamma, beta, w.reshape(f_out, C), labels, cw)
+    tag = f"expand_ln_head_ce[{tokens}x{C}->{f_out}]"
+    if f_out > 1:
+        assert abs(float(loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    else:
+        assert abs(float(loss)) <= 1e-6  # one class: the loss is identically zero
+    floor = 1e-7 if f_out == 1 else 0.0  # (one class: every gradient is exactly zero)
+    assert_close(xq.grad, 3.0 * ref_dx, GRAD_TOL[torch.bfloat16], tag + " dxn", floor=floor)
+    assert_close(wexp.grad, 3.0 * ref_dwe, GRAD_TOL[torch.bfloat16], tag + " dWexpand", floor=floor)
+    assert_close(gamma.grad, 3.0 * ref_dg, GRAD_TOL[torch.bfloat16], tag + " dgamma", floor=floor)
+    assert_close(beta.grad, 3.0 * ref_db, GRAD_TOL[torch.bfloat16], tag + " dbeta", floor=floor)
+    assert_close(w.grad.reshape(f_out, C), 3.0 * ref_dw, GRAD_TOL[torch.bfloat16], tag + " dWhead", floor=floor)
+    import conftest
+    conftest.NOTES.append(f"{tag}: fused-CE loss {float(loss):.6f} vs fp32 composition {float(ref_loss):.6f}")
+
+
+def test_forward_seg_loss_equals_model_plus_seg_loss_and_the_oracle():
+    """model.forward_seg_loss(x, labels, w) (loss fused into the tail kernels, no logits) against losses.seg_loss(model(x), labels, w)
+    on the same weights -- loss and every parameter gradient -- and the loss against the CPU oracle of the reference."""
+    import types
+
+    import bench
+    from heal_swin_amd.losses import seg_loss
+    from oracle import model as OM
+
+    wl = bench.WORKLOADS["T128"]
+    model, cfg, spec = bench.build_model(wl, nside=64)
+    sd = {k: v.clone() for k, v in model.state_dict().items() if not k.endswith("attn_mask")}
+    model = model.cuda().train()
+    model.compute_dtype = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randint(0, 256, (2, 3, spec["dim_in"]), generator=g, device="cuda", dtype=torch.uint8)
+    labels = torch.randint(0, 12, (2, spec["dim_in"]), generator=g, device="cuda", dtype=torch.uint8)
+    cw = 0.3 + torch.rand(12, generator=g, device="cuda")
+    res = {}
+    for fused in (True, False):
+        model.zero_grad(set_to_none=True)
+        loss = model.forward_seg_loss(x.float(), labels, cw) if fused else seg_loss(model(x.float()), labels, cw)
+        loss.backward()
+        res[fused] = (float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) <= 2e-4 * abs(res[False][0]), (res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1])
+    for n, gr in res[False][1].items():
+        tol = 8e-2 if n.endswith(("relative_position_bias_table", "logit_scale")) else 5e-2
+        assert_close(res[True][1][n], gr, tol, f"forward_seg_loss grad {n} vs model + seg_loss")
+    ref = OM.seg_loss(OM.forward(sd, types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec), x.cpu().float()), labels.cpu(), cw.cpu())
+    assert abs(res[True][0] - float(ref)) <= 5e-3 * abs(float(ref)), (res[True][0], float(ref))
+    # long / int labels and the no-grad call take the composed route and agree
+    with torch.no_grad():
+        l2 = model.forward_seg_loss(x.float(), labels.long(), cw)
+    assert abs(float(l2) - res[True][0]) <= 2e-3 * abs(res[True][0])
