@@ -293,12 +293,15 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
         const float mean = live ? mean_in[row] : 0.f, rstd = live ? rstd_in[row] : 0.f;
         const float rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
         float xh[ITERS][VEC], g[ITERS][VEC];
+        float d2[ITERS][VEC];  // gradient arriving through the residual path of the fused add: requested WITH x and dy (it
+                               // depends on nothing; loaded behind the row reductions it was a second serial round trip per row)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
                 float dyv[VEC];
+                if (dres_in) vec_io<T, VEC>::load(dres_in, base + (int64_t)c * VEC, d2[it]);
                 // (a software prefetch of the next rows' chunks, as in the forward kernel, was measured to change nothing here:
                 // two loads per lane are in flight already, 4.7-5.1 TB/s)
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, xh[it]);
@@ -326,11 +329,9 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
                 float o[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = rstd * (g[it][k] - m1 - xh[it][k] * m2);
-                if (dres_in) {  // gradient arriving through the residual path of the fused add
-                    float d2[VEC];
-                    vec_io<T, VEC>::load(dres_in, base + (int64_t)c * VEC, d2);
+                if (dres_in) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) o[k] += d2[k];
+                    for (int k = 0; k < VEC; ++k) o[k] += d2[it][k];
                 }
                 if (v1_mode) {
                     vec_io<T, VEC>::store(dx, base + (int64_t)c * VEC, o);

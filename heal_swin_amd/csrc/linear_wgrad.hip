@@ -269,7 +269,10 @@ __device__ __forceinline__ s16x8 tr_frag_asm(uint32_t a, int ks) {
 template <int NB, int TK>
 __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                            float* __restrict__ part_w, float* __restrict__ part_b,
-                                                           int64_t rows, int n_out, int k_in, Geometry g) {
+                                                           int64_t rows, int n_out, int k_in, Geometry g, int ldy, int ldx, int yc0, int xc0) {
+    // ldy / ldx: row strides of dY / X in elements; yc0 / xc0: first column of the operand inside its row (the operands may be
+    // column blocks of wider matrices -- the hi / lo parts of a bf16x3 split, ops.split3).  The descriptors cover whole rows of the
+    // WIDE matrices, so a tile that overhangs the operand's columns reads its neighbours (never stored), not unmapped memory
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource / LDS-DMA builtins exist in the device pass only
     constexpr int TN = 64 * NB;
     constexpr int WK = TK / 64, NW = 2 * WK, NT = 64 * NW;  // waves along k, waves, threads: waves in 2 x WK, each (32*NB) x 64
@@ -297,21 +300,21 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
     const bool do_bias = part_b != nullptr && tk == 0;
 
     // descriptors over [m_begin, m_end) x the full row; raw (stride 0) buffers return 0 past num_records
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + m_begin * n_out), 0, m_len * n_out * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + m_begin * k_in), 0, m_len * k_in * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + m_begin * ldy), 0, m_len * ldy * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + m_begin * ldx), 0, m_len * ldx * 2, 0x00020000);
     // DMA instruction q of a tile fills LDS bytes [q KB, q KB + 1 KB): position p = 64 q + lane -> (row, physical chunk)
     int voff_y[YI], voff_x[XI];
 #pragma unroll
     for (int j = 0; j < YI; ++j) {
         const int p = (wave * YI + j) * 64 + lane, row = p / YCH, pc = p % YCH;
-        voff_y[j] = row * n_out * 2 + n0 * 2 + ((pc ^ ((row & 3) << 2)) << 4);
+        voff_y[j] = row * ldy * 2 + (yc0 + n0) * 2 + ((pc ^ ((row & 3) << 2)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
         const int p = (wave * XI + j) * 64 + lane, row = p / XCH, pc = p % XCH;
-        voff_x[j] = row * k_in * 2 + k0 * 2 + ((pc ^ ((row & 3) << 2)) << 4);
+        voff_x[j] = row * ldx * 2 + (xc0 + k0) * 2 + ((pc ^ ((row & 3) << 2)) << 4);
     }
-    const int ystep = kTok * n_out * 2, xstep = kTok * k_in * 2;
+    const int ystep = kTok * ldy * 2, xstep = kTok * ldx * 2;
     auto issue = [&](int b) {
         unsigned char* base = smem + b * STAGE;
 #pragma unroll
@@ -733,8 +736,28 @@ int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in) {
     return (a > b ? a : b) * ((int64_t)n_out * k_in + n_out);
 }
 
+namespace {
+int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out, int k_in,
+                      int accumulate, int dtype, void* stream, int ldy, int ldx, int yc0, int xc0);
+}
+
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out,
                     int k_in, int accumulate, int dtype, void* stream) {
+    return linear_wgrad_impl(dy, x, dw, dbias, workspace, rows, n_out, k_in, accumulate, dtype, stream, n_out, k_in, 0, 0);
+}
+
+int hs_linear_wgrad_ld(const void* dy, int64_t ldy, int64_t ycol0, const void* x, int64_t ldx, int64_t xcol0, float* dw, float* dbias,
+                       float* workspace, int64_t rows, int n_out, int k_in, int accumulate, void* stream) {
+    HS_CHECK_ARG(ycol0 >= 0 && xcol0 >= 0 && ycol0 + n_out <= ldy && xcol0 + k_in <= ldx && ldy % 8 == 0 && ldx % 8 == 0 &&
+                 ycol0 % 8 == 0 && xcol0 % 8 == 0 && ldy < (1 << 20) && ldx < (1 << 20),
+                 "hs_linear_wgrad_ld: column blocks must lie inside the rows; strides and offsets are multiples of 8 elements");
+    return linear_wgrad_impl(dy, x, dw, dbias, workspace, rows, n_out, k_in, accumulate, HS_BF16, stream, (int)ldy, (int)ldx, (int)ycol0,
+                             (int)xcol0);
+}
+
+namespace {
+int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out, int k_in,
+                      int accumulate, int dtype, void* stream, int ldy, int ldx, int yc0, int xc0) {
     using namespace hs;
     HS_CHECK_ARG(dy && x && dw && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && n_out > 0 && k_in > 0, "bad shape");
@@ -745,7 +768,12 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     if (dtype == HS_BF16 && (n_out % 4 || k_in % 8))
         return fail(HS_ERR_UNSUPPORTED, "bf16: n_out must be a multiple of 4 and k_in a multiple of 8");
     if (dtype == HS_F32 && (n_out % 4 || k_in % 4)) return fail(HS_ERR_UNSUPPORTED, "fp32: n_out and k_in must be multiples of 4");
-    const Geometry g = dtype == HS_F32 ? make_geometry_f32(rows, n_out, k_in) : make_geometry(rows, n_out, k_in);
+    Geometry g = dtype == HS_F32 ? make_geometry_f32(rows, n_out, k_in) : make_geometry(rows, n_out, k_in);
+    const bool strided = ldy != n_out || ldx != k_in || yc0 || xc0;
+    if (strided) {  // column blocks of wider matrices: LDS-DMA kernels only, 32-bit offsets inside a token slice
+        if (!g.dma || g.rows_per_slice * (int64_t)(ldy > ldx ? ldy : ldx) * 2 >= ((int64_t)1 << 31))
+            return fail(HS_ERR_UNSUPPORTED, "hs_linear_wgrad_ld: a token slice exceeds the 2 GiB buffer-offset range");
+    }
     if (dtype == HS_BF16 && n_out % 8 && !g.dma) return fail(HS_ERR_UNSUPPORTED, "n_out must be a multiple of 8 for slices beyond 2 GiB");
     if (dtype == HS_F32 && !g.dma) return fail(HS_ERR_UNSUPPORTED, "fp32: a token slice exceeds the 2 GiB buffer-offset range");
     const int64_t n = (int64_t)n_out * k_in, rec = n + n_out;
@@ -760,11 +788,11 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
         hipLaunchKernelGGL(wgrad_dma_f32_kernel, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, part_w, part_b, rows, n_out,
                            k_in, g);
     else if (g.dma && g.tile_k == 256)
-        hipLaunchKernelGGL((wgrad_dma_kernel<4, 256>), grid, dim3(512), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
+        hipLaunchKernelGGL((wgrad_dma_kernel<4, 256>), grid, dim3(512), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g, ldy, ldx, yc0, xc0);
     else if (g.dma && g.tile_n == 256)
-        hipLaunchKernelGGL((wgrad_dma_kernel<4, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
+        hipLaunchKernelGGL((wgrad_dma_kernel<4, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g, ldy, ldx, yc0, xc0);
     else if (g.dma)
-        hipLaunchKernelGGL((wgrad_dma_kernel<2, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
+        hipLaunchKernelGGL((wgrad_dma_kernel<2, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g, ldy, ldx, yc0, xc0);
     else if (g.tile_n == 256)
         hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
     else
@@ -785,5 +813,6 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
     HS_LAUNCH_CHECK("linear_wgrad reduce");
     return HS_OK;
 }
+}  // namespace
 
 }  // extern "C"

@@ -687,14 +687,66 @@ def _lib_tag(kind, m, n, k):
     return f"lib {kind} m={m} n={n} k={k}"
 
 
+# fp32 activations (the reference's precision): "bf16x3" forms every Linear product as ONE bf16 GEMM of three-fold depth over
+# hi / lo splits of both operands with fp32 accumulation (csrc/split3.hip: a_hi b_hi + a_hi b_lo + a_lo b_hi, ~1e-5 relative to the
+# fp32 product, 3/16 of the fp32-MFMA time); "strict" keeps exact-fp32 GEMMs (library fp32 GEMM, v_mfma_f32_32x32x2_f32 weight
+# gradients) -- the reference form, used by the finite-difference tests.
+FP32_GEMM = os.environ.get("HS_FP32_GEMM", "bf16x3")
+_SPLIT_MEMO = []  # the last few splits (key, tensor): dy is split once for the input- and the weight-gradient product
+_MM_OUT_DTYPE = [None]  # whether torch.mm(..., out_dtype=) is available in this build (probed on first use)
+
+
+def _bf16x3_ok(x):
+    return FP32_GEMM == "bf16x3" and x.dtype == torch.float32 and x.is_cuda and x.shape[-1] % 8 == 0
+
+
+def split3(x2d, mode):
+    """bf16 [rows, 3 k] = [hi | hi | lo] (mode 0) or [hi | lo | hi] (mode 1) of fp32 x2d [rows, k] (`hs_split_bf16x3`)."""
+    x2d = x2d.contiguous()
+    key = (x2d.data_ptr(), tuple(x2d.shape), x2d._version, mode)
+    for kk, _, t in _SPLIT_MEMO:
+        if kk == key:
+            return t
+    rows, k = x2d.shape
+    out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=x2d.device)
+    check(lib.hs_split_bf16x3(ptr(x2d), ptr(out), rows, k, mode, stream_ptr(x2d.device)), "hs_split_bf16x3")
+    if mode == 0:
+        # (the entry keeps the SOURCE alive: its address cannot be recycled for another tensor while the key is in the memo)
+        _SPLIT_MEMO.append((key, x2d, out))
+        del _SPLIT_MEMO[:-2]
+    return out
+
+
+def _mm_f32(a3, b3t, bias=None):
+    """fp32 result of the bf16 product a3 @ b3t (+ bias): hipBLASLt with an fp32 output (`out_dtype`)."""
+    if _MM_OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a3[:8], b3t, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+        except Exception:  # noqa: BLE001  (a build without mm.dtype)
+            _MM_OUT_DTYPE[0] = False
+    if not _MM_OUT_DTYPE[0]:
+        raise RuntimeError("HS_FP32_GEMM=bf16x3 needs torch.mm(..., out_dtype=torch.float32); set HS_FP32_GEMM=strict")
+    y = torch.mm(a3, b3t, out_dtype=torch.float32)
+    return y if bias is None else y.add_(bias)
+
+
 def _lib_linear(x2, w, b):
     m, k = x2.shape[0] if x2.dim() == 2 else x2.numel() // x2.shape[-1], x2.shape[-1]
+    if _bf16x3_ok(x2) and w.dtype == torch.float32 and w.shape[0] % 8 == 0:
+        with _timed(_lib_tag("fwd bf16x3", m, w.shape[0], 3 * k), x2.device, 4 * (m * k + m * w.shape[0]), 6 * m * k * w.shape[0]):
+            y = _mm_f32(split3(x2.reshape(m, k), 0), split3(w.reshape(w.shape[0], k), 1).t(), b)
+        return y.view(x2.shape[:-1] + (w.shape[0],))
     with _timed(_lib_tag("fwd", m, w.shape[0], k), x2.device, 2 * (m * k + m * w.shape[0]), 2 * m * k * w.shape[0]):
         return torch.nn.functional.linear(x2, w, b)
 
 
 def _lib_matmul(dy2, w, res=None):
     m, n = dy2.shape
+    if _bf16x3_ok(dy2) and w.dtype == torch.float32 and w.shape[1] % 8 == 0:
+        with _timed(_lib_tag("dgrad bf16x3", m, w.shape[1], 3 * n), dy2.device, 4 * (m * n + m * w.shape[1]), 6 * m * n * w.shape[1]):
+            dx = _mm_f32(split3(dy2, 0), split3(w.t().contiguous(), 1).t())
+        return dx if res is None else dx.add_(res)
     with _timed(_lib_tag("dgrad", m, w.shape[1], n), dy2.device, 2 * (m * n + m * w.shape[1]), 2 * m * n * w.shape[1]):
         return dy2 @ w if res is None else torch.addmm(res, dy2, w)
 
@@ -791,6 +843,16 @@ class LinearFn(torch.autograd.Function):
         if want_b:
             db32 = db_out if db_out is not None else torch.empty(n_out, dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=dev)
+        if _bf16x3_ok(x2) and n_out % 8 == 0 and x2.dtype == dy2.dtype:
+            # dW = dY^T X as three bf16 weight-gradient products over the hi / lo column blocks of the [hi | hi | lo] splits
+            # (the split of dY is shared with the input-gradient product): hi^T hi + hi^T lo + lo^T hi; the bias gradient takes
+            # the column sums of dY_hi and dY_lo
+            dy3, x3 = split3(dy2, 0), split3(x2, 0)
+            with _timed("linear_wgrad bf16x3", dev, 3 * 2 * rows * (n_out + k_in), 6 * rows * n_out * k_in):
+                for i, (yo, xo, dbp) in enumerate(((0, 0, db32), (0, 2 * k_in, None), (2 * n_out, 0, db32))):
+                    check(lib.hs_linear_wgrad_ld(ptr(dy3), 3 * n_out, yo, ptr(x3), 3 * k_in, xo, ptr(dw32), ptr(dbp), ptr(ws), rows,
+                                                 n_out, k_in, 1 if (accumulate or i) else 0, stream_ptr(dev)), "hs_linear_wgrad_ld")
+            return dw32, db32
         with _timed("linear_wgrad", dev, x2.element_size() * rows * (n_out + k_in), 2 * rows * n_out * k_in):
             check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate,
                                       _lib.dtype_code(x2.dtype), stream_ptr(dev)), "hs_linear_wgrad")

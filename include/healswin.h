@@ -396,6 +396,18 @@ int hs_ln_head_fwd(const void* y, const void* wfold, const float* bvec, void* lo
 int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const void* dlogits, const void* afold, void* dy,
                    void* dprime, float* partials, int64_t rows, int width, int dtype, int logits_dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 x 3 products for fp32 activations (the reference trains in fp32, training/train_config.py:95).  hs_split_bf16x3 writes, for
+ * fp32 x [rows, k], the bf16 matrix [rows, 3 k] = [hi | hi | lo] (mode 0: activation side) or [hi | lo | hi] (mode 1: weight side),
+ * hi = bf16(x), lo = bf16(x - hi): a bf16 GEMM of depth 3 k over a mode-0 and a mode-1 operand with fp32 accumulation equals
+ * a_hi b_hi + a_hi b_lo + a_lo b_hi, i.e. the fp32 product to ~1e-5 relative, at 3/16 of the fp32-MFMA time (csrc/split3.hip).
+ * hs_linear_wgrad_ld is hs_linear_wgrad (bf16) on the column blocks [ycol0, ycol0 + n_out) / [xcol0, xcol0 + k_in) of matrices with row
+ * strides ldy / ldx (elements, multiples of 8; dy / x point to the matrices' first elements): the hi / lo blocks of two mode-0 matrices feed the three weight-gradient products (accumulate = 1 on the second and third).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_split_bf16x3(const float* x, void* out, int64_t rows, int k, int mode, void* stream);
+int hs_linear_wgrad_ld(const void* dy, int64_t ldy, int64_t ycol0, const void* x, int64_t ldx, int64_t xcol0, float* dw, float* dbias,
+                       float* workspace, int64_t rows, int n_out, int k_in, int accumulate, void* stream);
+
 /* The whole decoder tail forward in one launch: FinalPatchExpand_X4's Linear(C -> 4 C) (models_torch/swin_hp_transformer.py:442-447),
  * the 'b n (p c) -> b (n p) c' view (:449), its LayerNorm(C) (:450-452) and the 1x1 class head (:785-788).  LayerNorm reads the fp32
  * accumulators of the expand product, xhat enters the head as hi + lo, the logits leave in fp32: of the tail's four bf16 roundings
