@@ -471,8 +471,19 @@ def main():
         r32 = run_workload(ctx, "fp32", k, 2, timing=False)
         out["fp32"] = {"value": args.batch * k / r32.elapsed, "unit": "images/s", "ms_per_step": 1e3 * r32.elapsed / k, "steps": k,
                        "warmup": 2, "batch_per_gpu": args.batch, "workload": wl["name"], "final_loss": r32.loss,
-                       "note": "fp32 activations and MFMA-f32 kernels; fp32 library GEMMs with " + (
+                       "gemm": "bf16x3: every Linear product as one bf16 GEMM of three-fold depth over hi / lo splits, fp32 accumulation "
+                               "(ops.FP32_GEMM, csrc/split3.hip; logits 7e-6 of the oracle at this size, tests/test_gpu_baseline_configs.py)",
+                       "note": "fp32 activations and MFMA-f32 attention kernels; library GEMMs with " + (
                            "TunableOp picks" if os.path.exists(tuned.replace("_bf16.csv", "_fp32.csv")) and not args.no_tuned_gemm else "the default heuristic")}
+        # the exact-fp32 form of the same step (library fp32 GEMMs, v_mfma_f32 weight gradients): the reference for the line above
+        from heal_swin_amd import ops as _ops
+        prev_mode, _ops.FP32_GEMM = _ops.FP32_GEMM, "strict"
+        try:
+            rs = run_workload(ctx, "fp32", 3, 1, timing=False)
+        finally:
+            _ops.FP32_GEMM = prev_mode
+        out["fp32"]["strict_fp32_gemm"] = {"value": args.batch * 3 / rs.elapsed, "unit": "images/s", "ms_per_step": 1e3 * rs.elapsed / 3, "steps": 3,
+                                           "warmup": 1, "final_loss": rs.loss, "note": "HS_FP32_GEMM=strict"}
     # BASELINE configs[4] at its stated size next to it: HEAL-SWIN-T, nside 256, 8 base pixels, depth head (f_out = 1), fp32, masked
     # L1 loss; batch 2 per GPU as in the reference's run configs (run_configs/*/..._train_run_config.py: batch_size 2)
     if world == 1 and args.dtype == "bf16" and args.workload == "B256" and not args.no_fp32_companion and not args.graph and not args.tune_gemm:
