@@ -727,8 +727,18 @@ def _mm_f32(a3, b3t, bias=None):
             _MM_OUT_DTYPE[0] = False
     if not _MM_OUT_DTYPE[0]:
         raise RuntimeError("HS_FP32_GEMM=bf16x3 needs torch.mm(..., out_dtype=torch.float32); set HS_FP32_GEMM=strict")
-    y = torch.mm(a3, b3t, out_dtype=torch.float32)
-    return y if bias is None else y.add_(bias)
+    if bias is None:
+        return torch.mm(a3, b3t, out_dtype=torch.float32)
+    if _MM_OUT_DTYPE[0] is True:  # addend (bias vector or residual matrix, fp32) in the GEMM's epilogue where the build has addmm.dtype
+        try:
+            y = torch.addmm(bias, a3, b3t, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = "addmm"
+            return y
+        except Exception:  # noqa: BLE001
+            _MM_OUT_DTYPE[0] = "mm"
+    if _MM_OUT_DTYPE[0] == "addmm":
+        return torch.addmm(bias, a3, b3t, out_dtype=torch.float32)
+    return torch.mm(a3, b3t, out_dtype=torch.float32).add_(bias)
 
 
 def _lib_linear(x2, w, b):
@@ -745,8 +755,8 @@ def _lib_matmul(dy2, w, res=None):
     m, n = dy2.shape
     if _bf16x3_ok(dy2) and w.dtype == torch.float32 and w.shape[1] % 8 == 0:
         with _timed(_lib_tag("dgrad bf16x3", m, w.shape[1], 3 * n), dy2.device, 4 * (m * n + m * w.shape[1]), 6 * m * n * w.shape[1]):
-            dx = _mm_f32(split3(dy2, 0), split3(w.t().contiguous(), 1).t())
-        return dx if res is None else dx.add_(res)
+            dx = _mm_f32(split3(dy2, 0), split3(w.t().contiguous(), 1).t(), res)
+        return dx
     with _timed(_lib_tag("dgrad", m, w.shape[1], n), dy2.device, 2 * (m * n + m * w.shape[1]), 2 * m * n * w.shape[1]):
         return dy2 @ w if res is None else torch.addmm(res, dy2, w)
 
