@@ -46,7 +46,9 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=self.inputs.device)
         side.wait_stream(torch.cuda.current_stream(self.inputs.device))
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
+            # at least TWO eager steps: the second one builds the device-side job table of the batched weight transposes
+            # (ops.ParamCastCache), a pageable host-to-device copy that must not happen inside the capture
+            for _ in range(max(2, warmup)):
                 self._eager()
         torch.cuda.current_stream(self.inputs.device).wait_stream(side)
         torch.cuda.synchronize(self.inputs.device)

@@ -127,7 +127,10 @@ def depth_mean_log_var_loss(pred, target, mask_background=False):
     """mean of log_var/2 + (mean - target)^2 exp(-log_var)/2 over non-inf targets, channel 0 = mean, channel 1 = log variance
     (loss_depth_regression.py:23-38)."""
     keep, tgt, n = _finite(target)
-    means, log_var = pred[:, 0].float(), pred[:, 1].float()
+    # (the INPUTS are sanitised at the background pixels, not only the result: the reference's boolean indexing never touches
+    # those pixels, while where()'s backward would multiply a 0 gradient with an overflowed exp(-log_var) there: 0 * inf = NaN)
+    zero = torch.zeros((), dtype=torch.float32, device=pred.device)
+    means, log_var = torch.where(keep, pred[:, 0].float(), zero), torch.where(keep, pred[:, 1].float(), zero)
     return _masked_mean(0.5 * log_var + (means - tgt) ** 2 * (0.5 * torch.exp(-log_var)), keep, n)
 
 

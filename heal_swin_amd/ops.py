@@ -587,6 +587,8 @@ class ParamCastCache:
         if ent is None:
             t = self.shadows[i].t().contiguous()
             self.transposed[i] = ent = [t, self.versions]
+            if self._jobs is not None:  # a captured hs_transpose_many_16 node may still read the old table: never free it
+                self.__dict__.setdefault("_retired_jobs", []).append(self._jobs)
             self._jobs = None  # the job table is rebuilt with this entry
         elif ent[1] is not self.versions:
             self._retranspose_all()

@@ -124,8 +124,19 @@ class GradBucketAllReduce:
         self._pass_task = None               # autograd graph-task id of the backward() that opened this pass
 
     # ------------------------------------------------------------------ step protocol
+    def reset(self):
+        """Forget an unfinished backward pass (e.g. after an exception inside backward()): in-flight exchanges are waited for and
+        dropped, the next gradient event opens a fresh pass.  zero_grad() does the same."""
+        for _, w in self._works:
+            w.wait()
+        self._reset_pass()
+
     def zero_grad(self):
-        """Zero the buckets in place and (re-)attach every .grad view."""
+        """Zero the buckets in place and (re-)attach every .grad view.  Also closes a pass left open by an aborted backward()
+        (see reset()); restrictions by design: ONE backward() per pass -- nested / re-entrant backwards (reentrant activation
+        checkpointing) and `loss1.backward(retain_graph=True); loss2.backward()` need finish() in between or no_sync()."""
+        for _, w in getattr(self, "_works", []):
+            w.wait()
         for flat in self.buckets:
             flat.zero_()
         for p, view in self._views.items():
