@@ -14,6 +14,7 @@ HS_F32, HS_BF16 = 0, 1
 HS_ATTN_COSINE = 1
 HS_ATTN_FORCE_VALU = 2
 HS_ATTN_RESIDUAL = 4
+HS_ATTN_OVERWRITE_GRADS = 8
 HS_EPI_BIAS, HS_EPI_GELU, HS_EPI_DGELU, HS_EPI_RESID = 0, 1, 2, 3
 
 c_i64 = ctypes.c_int64

@@ -964,314 +964,12 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
 }
 #undef HS_STAGE_GEOMETRY
 
-// The same forward with TWO waves per head (32 queries each, as the backward's score phase): half the score / bias registers per
-// wave, four waves per SIMD instead of two (A/B: HS_ATTN_FWD_QS=2).
-template <int HG, bool DROP>
-__global__ void __launch_bounds__(128 * HG, 4) attn_fwd_mfma_q2_kernel(AttnParams p, int slots, int groups) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayoutFwd L(HG);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wv >> 1, t = wv & 1;  // head inside the group; this wave's query tile (32 queries)
-    const int bxcd = blockIdx.x & 7, blocal = blockIdx.x >> 3;
-    const int by = blocal % groups, bx = bxcd + 8 * (blocal / groups);
-    if (bx >= slots) return;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int h = by * HG + g;
-    const int C = p.C, nH = p.nH;
-    const int N = (int)p.N;
-    const int nW = N / kWs;
-    const int total_windows = p.B * nW;
-    const bool cosine = (p.flags & HS_ATTN_COSINE) != 0;
-    const float hscale = p.head_scale[h];
-    const bool has_idx = p.idx != nullptr;
-    const int roll = (int)p.roll;
-    const uint32_t c3b = 3u * (uint32_t)C * 2u, cb = (uint32_t)C * 2u;
-    const uint32_t img_qkv = (uint32_t)N * c3b, img_out = (uint32_t)N * cb;
-
-    unsigned char* q_tile = smem + g * L.head;
-    unsigned char* k_tile = q_tile + kTileBytes;
-    unsigned char* v_tile = q_tile + 2 * kTileBytes;
-    float* qinv_s = (float*)(smem + L.qinv);
-    unsigned char* lab_s = smem + L.lab;
-    uint32_t* flag_s = (uint32_t*)(smem + L.flag);
-
-    // staging geometry: 6 steps = 3 parts (q, k, v) x 2 row blocks of 32 rows; a step moves 32 rows x HG*64 B.  (Re-derived
-    // from an opaque copy of the thread id wherever it is used instead of being pinned in registers for the whole kernel.)
-#define HS_STAGE_GEOMETRY                                                                          \
-    int tid_o = tid;                                                                               \
-    asm volatile("" : "+v"(tid_o));                                                                \
-    const int srow = tid_o / (4 * HG), sc = tid_o % (4 * HG), sg = sc >> 2, scc = sc & 3;          \
-    const uint32_t colb = (uint32_t)(by * HG * kHd + sc * 8) * 2u;                                 \
-    unsigned char* st = smem + sg * L.head;                                                        \
-    const int l31 = tid_o & 31;                                                                    \
-    (void)scc;                                                                                     \
-    (void)st;                                                                                      \
-    (void)colb;                                                                                    \
-    (void)l31;
-
-    auto image_rsrc = [&](const void* base, uint32_t bytes_per_image, int b_l) {
-        const uint64_t a = (uint64_t)base + (uint64_t)b_l * bytes_per_image;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)bytes_per_image, 0x00020000);
-    };
-    auto rolled = [&](int j) {
-        const int s = j + roll;
-        return s >= N ? s - N : s;
-    };
-
-    u32x4 ld[3][2];
-    int tok_ld[2] = {0, 0}, tok_st[1] = {0};
-    int tok_ld2[2] = {0, 0}, tok_st2[1] = {0};  // table mode: token rows of the window after the one in flight
-    unsigned lab_next = 0;
-    int b_cur = bx / nW, w_cur = bx - b_cur * nW;
-    auto advance = [&](int& b_l, int& w_l) {
-        w_l += slots;
-        while (w_l >= nW) {
-            w_l -= nW;
-            ++b_l;
-        }
-    };
-    auto request_tokens = [&](int w_l) {
-        HS_STAGE_GEOMETRY
-        const int j_l = w_l * kWs;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) tok_ld2[rb] = p.idx[j_l + rb * 32 + srow];
-        tok_st2[0] = p.idx[j_l + 32 * t + l31];
-    };
-    auto issue_loads = [&](int b_l, int w_l) {
-        HS_STAGE_GEOMETRY
-        const int j_l = w_l * kWs;
-        if (has_idx) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) tok_ld[rb] = tok_ld2[rb];
-            tok_st[0] = tok_st2[0];
-        } else {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) tok_ld[rb] = rolled(j_l + rb * 32 + srow);
-            tok_st[0] = rolled(j_l + 32 * t + l31);
-        }
-        const __amdgpu_buffer_rsrc_t rq = image_rsrc(p.qkv, img_qkv, b_l);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const uint32_t vo = (uint32_t)tok_ld[rb] * c3b + colb;
-            ld[0][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, 0);
-            ld[1][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, cb, 0);
-            ld[2][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 2 * cb, 0);
-        }
-        if (p.labels && wv == 0) lab_next = p.labels[j_l + lane];
-    };
-    auto claim = [&]() {
-#pragma unroll
-        for (int part = 0; part < 3; ++part)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(ld[part][rb]));
-        asm volatile("" : "+v"(lab_next), "+v"(tok_ld2[0]), "+v"(tok_ld2[1]), "+v"(tok_st2[0]));
-    };
-    auto lds_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-
-    if (bx < total_windows) {
-        if (has_idx) {
-            request_tokens(w_cur);
-            asm volatile("" : "+v"(tok_ld2[0]), "+v"(tok_ld2[1]), "+v"(tok_st2[0]));
-        }
-        issue_loads(b_cur, w_cur);
-        int b_n = b_cur, w_n = w_cur;
-        advance(b_n, w_n);
-        if (has_idx && b_n < p.B) request_tokens(w_n);
-    }
-
-    // relative-position bias of this head (x log2 e), in the S^T accumulator layout: tile (kt, qt), register r holds query
-    // qt*32 + l31, key kt*32 + (r&3) + 8*(r>>2) + 4*half.  Unconditional loads (without a bias they read qkv bytes, zeroed below).
-    float biasr[2][16];
-    {
-        const bool has_bias = p.bias != nullptr;
-        const float* bsrc = has_bias ? p.bias + ((int64_t)h * kWs + 32 * t + l31) * kWs + 4 * half : (const float*)p.qkv + 4 * half;
-        const float bs = has_bias ? kLog2e : 0.f;
-        float4 b4[2][4];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) b4[kt][m] = *(const float4*)(bsrc + kt * 32 + 8 * m);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                biasr[kt][4 * m] = b4[kt][m].x * bs;
-                biasr[kt][4 * m + 1] = b4[kt][m].y * bs;
-                biasr[kt][4 * m + 2] = b4[kt][m].z * bs;
-                biasr[kt][4 * m + 3] = b4[kt][m].w * bs;
-            }
-    }
-    claim();
-
-    for (int wi = bx; wi < total_windows; wi += slots) {
-        const int b = b_cur, w = w_cur;
-        const int j0 = w * kWs;
-        const int tq0 = tok_st[0];
-        HS_STAGE_GEOMETRY
-        const int half = tid_o >> 5 & 1;
-        const int lane = tid_o & 63;
-
-        // ------------------------------------------------------------ stage q, k^, v (row-major, swizzled); norms; label scan
-        if (p.labels && wv == 0) {
-            lab_s[lane] = (unsigned char)lab_next;
-            const unsigned first = __builtin_amdgcn_readfirstlane(lab_next);
-            const bool any = __ballot(lab_next != first) != 0ull;
-            if (lane == 0) flag_s[0] = any ? 1u : 0u;
-        }
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = rb * 32 + srow;
-            const u32x4 vq = ld[0][rb];
-            u32x4 vk = ld[1][rb];
-            if (cosine) {
-                float sq = 0.f, sk = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    sq += bf_lo(vq[i]) * bf_lo(vq[i]) + bf_hi(vq[i]) * bf_hi(vq[i]);
-                    sk += bf_lo(vk[i]) * bf_lo(vk[i]) + bf_hi(vk[i]) * bf_hi(vk[i]);
-                }
-                sq += __shfl_xor(sq, 1, 64);
-                sq += __shfl_xor(sq, 2, 64);
-                sk += __shfl_xor(sk, 1, 64);
-                sk += __shfl_xor(sk, 2, 64);
-                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vk[i] = pack_bf16(bf_lo(vk[i]) * kinv, bf_hi(vk[i]) * kinv);
-                if (scc == 0) qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(sq), kNormEps);
-            }
-            const int off = swz(row, scc);
-            *(u32x4*)(st + off) = vq;
-            *(u32x4*)(st + kTileBytes + off) = vk;
-            *(u32x4*)(st + 2 * kTileBytes + off) = ld[2][rb];
-        }
-        lds_barrier();  // A
-
-        int b_n = b_cur, w_n = w_cur;
-        advance(b_n, w_n);
-        auto prefetch = [&]() {
-            if (wi + slots < total_windows) {
-                issue_loads(b_n, w_n);
-                if (has_idx) {
-                    int b_nn = b_n, w_nn = w_n;
-                    advance(b_nn, w_nn);
-                    if (b_nn < p.B) request_tokens(w_nn);
-                }
-            }
-        };
-        // (the dropout instantiation is at the register limit during the softmax: it requests the rows behind it)
-        // (four waves per SIMD = 128 registers: the rows are requested behind the softmax, when the score registers are packed)
-        b_cur = b_n;
-        w_cur = w_n;
-        const bool mixed = p.labels ? (flag_s[0] != 0u) : false;
-
-        // ------------------------------------------------------------ S^T = K^ Q^T for this wave's 32 queries
-        f32x16 acc[2];
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int qq = 32 * t + l31;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = ks * 2 + half;
-            const bf16x8 qf = *(const bf16x8*)(q_tile + swz(qq, chunk));
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 kf = *(const bf16x8*)(k_tile + swz(kt * 32 + l31, chunk));
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, ks == 0 ? zero16 : acc[kt], 0, 0, 0);
-            }
-        }
-
-        // ------------------------------------------------------------ softmax over the keys of each query (log2 domain)
-        {
-            const float fq = hscale * kLog2e * (cosine ? qinv_s[g * kWs + qq] : 1.f);
-            float m = -INFINITY;
-            if (!mixed) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float tv = fmaf(acc[kt][r], fq, biasr[kt][r]);
-                        acc[kt][r] = tv;
-                        m = fmaxf(m, tv);
-                    }
-            } else {  // rare: windows cut by the shift boundary
-                const int my = lab_s[qq];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float tv = fmaf(acc[kt][r], fq, biasr[kt][r]);
-                        if (lab_s[key] != my) tv += kMaskLog2;
-                        acc[kt][r] = tv;
-                        m = fmaxf(m, tv);
-                    }
-            }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float l = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(acc[kt][r] - m);
-                    acc[kt][r] = e;
-                    l += e;
-                }
-            l += __shfl_xor(l, 32, 64);
-            const float linv = 1.f / l;
-            if constexpr (DROP) {
-                const DropRng rng(p, ((int64_t)b * nH + h) * N + j0 + qq);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[kt][r] *= linv * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[kt][r] *= linv;
-            }
-            if (p.lse && half == 0) p.lse[((int64_t)b * nH + h) * N + j0 + qq] = (m + __builtin_amdgcn_logf(l)) * kLn2;
-        }
-
-        prefetch();
-        // ------------------------------------------------------------ O^T = V^T P^T (lane = query, registers = features)
-        f32x16 o;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kt = ks >> 1, c = ks & 1;
-            const int kbase = kt * 32 + c * 16 + 4 * half;  // slots 0..3 -> keys kbase.., slots 4..7 -> kbase+8..
-            const bf16x8 vf = join(tr_read_tile(v_tile, kbase, lane), tr_read_tile(v_tile, kbase + 8, lane));
-            bf16x8 pf;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)acc[kt][8 * c + jj];
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ks == 0 ? zero16 : o, 0, 0, 0);
-        }
-        u32x4 o00, o01;
-        {
-            float x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = o[r];
-            pack_rows_t(x, o00, o01);
-        }
-        claim();
-        const __amdgpu_buffer_rsrc_t ro = image_rsrc(p.out, img_out, b);
-        const uint32_t hb = (uint32_t)(h * kHd) * 2u + 16u * half;
-        __builtin_amdgcn_raw_buffer_store_b128(o00, ro, (uint32_t)tq0 * cb + hb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o01, ro, (uint32_t)tq0 * cb + hb + 32u, 0, 0);
-        lds_barrier();  // B: every wave is done with the tiles
-    }
-}
-#undef HS_STAGE_GEOMETRY
-
 // dst[e] += sum over parts of src[part][e].  A block of 16 waves owns 256 consecutive elements (one float4 per lane); wave w sums
 // the parts p = w, w + 16, ... with all of its loads in flight at once, the 16 partial rows are combined through LDS in a fixed
 // order (deterministic).  (Round 3 gave one thread one element and all `parts` loads in sequence: 64 blocks and 17.8 us at
 // stage 0 of HEAL-SWIN-B, where the table is smallest and the number of parts largest.)
-__global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, int64_t n) {
+__global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int parts, int64_t n,
+                                                                int overwrite) {
     __shared__ float4 part_s[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4;  // n is a multiple of 256 (nH * 64 * 64)
@@ -1287,7 +985,7 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __re
     part_s[w][lane] = acc;
     __syncthreads();
     if (w == 0) {
-        float4 t = *(const float4*)(dst + e);
+        float4 t = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(dst + e);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const float4 v = part_s[k][lane];
@@ -1301,12 +999,12 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __re
 }
 
 // dhead_scale[h] += sum over slots and the head's two waves of part[slot][h][qt]
-__global__ void reduce_scale_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int slots, int nH) {
+__global__ void reduce_scale_partials_kernel(const float* __restrict__ src, float* __restrict__ dst, int slots, int nH, int overwrite) {
     const int h = threadIdx.x;
     if (h >= nH) return;
     float acc = 0.f;
     for (int s2 = 0; s2 < slots; ++s2) acc += src[((int64_t)s2 * nH + h) * 2] + src[((int64_t)s2 * nH + h) * 2 + 1];
-    dst[h] += acc;
+    dst[h] = overwrite ? acc : dst[h] + acc;
 }
 
 // Persistent grid = resident workgroups, counted PER XCD: the kernels map the head groups of a window slot onto one XCD
@@ -1354,30 +1052,13 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     HS_LAUNCH_CHECK("attn_bwd_mfma");
     if (dbias_part) {
         const int64_t n = (int64_t)p.nH * kWs * kWs;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(n / 256)), dim3(1024), 0, stream, dbias_part, p.dbias, slots, n);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(n / 256)), dim3(1024), 0, stream, dbias_part, p.dbias, slots, n, (p.flags & HS_ATTN_OVERWRITE_GRADS) ? 1 : 0);
         HS_LAUNCH_CHECK("reduce dbias partials");
     }
     if (dscale_part) {
-        hipLaunchKernelGGL(reduce_scale_partials_kernel, dim3(1), dim3(256), 0, stream, dscale_part, p.dhead_scale, slots, p.nH);
+        hipLaunchKernelGGL(reduce_scale_partials_kernel, dim3(1), dim3(256), 0, stream, dscale_part, p.dhead_scale, slots, p.nH, (p.flags & HS_ATTN_OVERWRITE_GRADS) ? 1 : 0);
         HS_LAUNCH_CHECK("reduce dscale partials");
     }
-    return HS_OK;
-}
-
-template <int HG, bool DROP>
-int launch_fwd_q2(const AttnParams& p, hipStream_t stream) {
-    const LdsLayoutFwd L(HG);
-    auto kern = attn_fwd_mfma_q2_kernel<HG, DROP>;
-    static bool configured = false;
-    if (!configured) {
-        HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-        configured = true;
-    }
-    const int groups = p.nH / HG;
-    const int slots = persistent_slots(p, groups, HG);  // 2 HG waves per workgroup at four waves per SIMD: as many workgroups per CU as the one-wave form
-    const unsigned grid = 8u * (unsigned)((slots + 7) / 8) * (unsigned)groups;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * HG), L.total, stream, p, slots, groups);
-    HS_LAUNCH_CHECK("attn_fwd_mfma_q2");
     return HS_OK;
 }
 
@@ -1422,13 +1103,6 @@ int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     const bool drop = p.drop_p > 0.f;
-    static const int qs = getenv("HS_ATTN_FWD_QS") ? atoi(getenv("HS_ATTN_FWD_QS")) : 1;  // A/B: 2 = two waves per head
-    if (qs == 2) switch (pick_head_group(p.nH)) {
-            case 4: return drop ? launch_fwd_q2<4, true>(p, stream) : launch_fwd_q2<4, false>(p, stream);
-            case 3: return drop ? launch_fwd_q2<3, true>(p, stream) : launch_fwd_q2<3, false>(p, stream);
-            case 2: return drop ? launch_fwd_q2<2, true>(p, stream) : launch_fwd_q2<2, false>(p, stream);
-            default: return drop ? launch_fwd_q2<1, true>(p, stream) : launch_fwd_q2<1, false>(p, stream);
-        }
     switch (pick_head_group(p.nH)) {
         case 4: return drop ? launch_fwd<4, true>(p, stream) : launch_fwd<4, false>(p, stream);
         case 3: return drop ? launch_fwd<3, true>(p, stream) : launch_fwd<3, false>(p, stream);

@@ -149,14 +149,19 @@ class WindowAttnCoreFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         # dbias and dscale are accumulated into by the kernels (C ABI): one zero fill for both
         nb = bias_c.numel() if bias_c is not None else 0
-        zeros = torch.zeros(nb + hs.numel(), dtype=torch.float32, device=qkv.device)
+        mfma_bf16 = qkv.dtype == torch.bfloat16 and ws == 64 and C == 32 * nh and not (flags & _lib.HS_ATTN_FORCE_VALU)
+        if mfma_bf16:  # that path writes its parameter gradients (HS_ATTN_OVERWRITE_GRADS): no zero fill
+            flags |= _lib.HS_ATTN_OVERWRITE_GRADS
+            zeros = torch.empty(nb + hs.numel(), dtype=torch.float32, device=qkv.device)
+        else:
+            zeros = torch.zeros(nb + hs.numel(), dtype=torch.float32, device=qkv.device)
         dbias = zeros[:nb].view(bias_c.shape) if bias_c is not None else None
         dscale = zeros[nb:].view(hs.shape)
         nws = int(lib.hs_window_attn_bwd_workspace(B, N, C, nh, ws, dt))
         wsp = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws else None
         # algorithmic traffic: qkv (3C) + dout (C) read, dqkv (3C) written -- plus out (C) in the fp32 / VALU kernels; the bf16
         # MFMA kernel forms D = rowsum(P o dP) from its own registers and never reads `out`; flops: 5 contractions of 2*Ws*hd
-        streams = 7 if (qkv.dtype == torch.bfloat16 and ws == 64 and C == 32 * nh and not (flags & _lib.HS_ATTN_FORCE_VALU)) else 8
+        streams = 7 if mfma_bf16 else 8
         with _timed("window_attn_bwd", qkv.device, streams * B * N * C * qkv.element_size(), 10 * B * N * C * ws):
             check(lib.hs_window_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), ptr(dscale), ptr(wsp),
                                          ptr(bias_c), ptr(hs), ptr(idx), roll, ptr(labels),

@@ -40,6 +40,8 @@ typedef enum { HS_F32 = 0, HS_BF16 = 1 } hs_dtype;
 #define HS_ATTN_COSINE 1u      /* cosine attention: L2-normalise q,k (eps 1e-12), per-head scale */
 #define HS_ATTN_FORCE_VALU 2u  /* run the generic fp32-VALU kernels even where an MFMA kernel exists (cross-checks, A/B) */
 #define HS_ATTN_RESIDUAL 4u    /* hs_window_attn_module_fwd: out = x + module(x) (the block's residual add, :316) */
+#define HS_ATTN_OVERWRITE_GRADS 8u /* hs_window_attn_bwd, bf16 MFMA path (window 64, head_dim 32): dbias / dhead_scale are WRITTEN instead of
+                                    added into (no zero fill needed); the fp32 and VALU paths ignore the flag and accumulate */
 
 const char* hs_version(void);
 /* human-readable message of the last failing call on this thread ("" if none) */
