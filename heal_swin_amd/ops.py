@@ -699,12 +699,18 @@ def _lib_tag(kind, m, n, k):
 # fp32 product, 3/16 of the fp32-MFMA time); "strict" keeps exact-fp32 GEMMs (library fp32 GEMM, v_mfma_f32_32x32x2_f32 weight
 # gradients) -- the reference form, used by the finite-difference tests.
 FP32_GEMM = os.environ.get("HS_FP32_GEMM", "bf16x3")
+_BF16X3_MIN = int(os.environ.get("HS_BF16X3_MIN", "160"))  # n k / (n + k) from which a product takes the bf16x3 form (A/B hook)
 _SPLIT_MEMO = []  # the last few splits (key, tensor): dy is split once for the input- and the weight-gradient product
 _MM_OUT_DTYPE = [None]  # whether torch.mm(..., out_dtype=) is available in this build (probed on first use)
 
 
-def _bf16x3_ok(x):
-    return FP32_GEMM == "bf16x3" and x.dtype == torch.float32 and x.is_cuda and x.shape[-1] % 8 == 0
+def _bf16x3_ok(x, n=None, k=None):
+    """bf16x3 for this fp32 product?  Only where the exact-fp32 product is MFMA-bound: n k / (n + k) >= 160 (e.g. 512 x 256; sweep 64 / 100 /
+    128 / 192 / 300 on B@256 fp32: 635 / 625 / 607 / 606 / 632 ms).  Narrow products (C = 96 / 128: stage 0, the whole first stages of HEAL-SWIN-T) move 4 (n + k) bytes per row against
+    2 n k flops at 110 TFLOP/s -- they are HBM-bound in fp32 already and the split passes would only add traffic (measured: the T
+    depth-head companion 35.9 -> 33.2 images/s with bf16x3 everywhere)."""
+    ok = FP32_GEMM == "bf16x3" and x.dtype == torch.float32 and x.is_cuda and x.shape[-1] % 8 == 0
+    return ok and (n is None or n * k >= _BF16X3_MIN * (n + k))
 
 
 def split3(x2d, mode):
@@ -750,7 +756,7 @@ def _mm_f32(a3, b3t, bias=None):
 
 def _lib_linear(x2, w, b):
     m, k = x2.shape[0] if x2.dim() == 2 else x2.numel() // x2.shape[-1], x2.shape[-1]
-    if _bf16x3_ok(x2) and w.dtype == torch.float32 and w.shape[0] % 8 == 0:
+    if _bf16x3_ok(x2, w.shape[0], k) and w.dtype == torch.float32 and w.shape[0] % 8 == 0:
         with _timed(_lib_tag("fwd bf16x3", m, w.shape[0], 3 * k), x2.device, 4 * (m * k + m * w.shape[0]), 6 * m * k * w.shape[0]):
             y = _mm_f32(split3(x2.reshape(m, k), 0), split3(w.reshape(w.shape[0], k), 1).t(), b)
         return y.view(x2.shape[:-1] + (w.shape[0],))
@@ -760,7 +766,7 @@ def _lib_linear(x2, w, b):
 
 def _lib_matmul(dy2, w, res=None):
     m, n = dy2.shape
-    if _bf16x3_ok(dy2) and w.dtype == torch.float32 and w.shape[1] % 8 == 0:
+    if _bf16x3_ok(dy2, w.shape[1], n) and w.dtype == torch.float32 and w.shape[1] % 8 == 0:
         with _timed(_lib_tag("dgrad bf16x3", m, w.shape[1], 3 * n), dy2.device, 4 * (m * n + m * w.shape[1]), 6 * m * n * w.shape[1]):
             dx = _mm_f32(split3(dy2, 0), split3(w.t().contiguous(), 1).t(), res)
         return dx
@@ -860,7 +866,7 @@ class LinearFn(torch.autograd.Function):
         if want_b:
             db32 = db_out if db_out is not None else torch.empty(n_out, dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=dev)
-        if _bf16x3_ok(x2) and n_out % 8 == 0 and x2.dtype == dy2.dtype:
+        if _bf16x3_ok(x2, n_out, k_in) and n_out % 8 == 0 and x2.dtype == dy2.dtype:
             # dW = dY^T X as three bf16 weight-gradient products over the hi / lo column blocks of the [hi | hi | lo] splits
             # (the split of dY is shared with the input-gradient product): hi^T hi + hi^T lo + lo^T hi; the bias gradient takes
             # the column sums of dY_hi and dY_lo
