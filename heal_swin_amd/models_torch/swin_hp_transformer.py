@@ -59,6 +59,10 @@ class HSLinear(nn.Linear):
         """(self(x), alias of x for a residual connection around the branch): see ops.LinearFn."""
         return ops.linear_passthrough(x, self.weight, self.bias)
 
+    def forward_residual(self, x, residual):
+        """self(x) + residual with the add in the product's epilogue."""
+        return ops.linear_residual(x, self.weight, self.bias, residual)
+
 
 class DropPath(nn.Module):
     """Stochastic depth per sample (the reference imports timm's; identity when p == 0 or in eval)."""
@@ -91,14 +95,17 @@ class Mlp(nn.Module):
         self.fc2 = HSLinear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x, apply_out_drop=True, residual_alias=False):
-        """residual_alias: also return an alias of x whose gradient is folded into fc1's input-gradient GEMM."""
+    def forward(self, x, apply_out_drop=True, residual_alias=False, residual=None):
+        """residual_alias: also return an alias of x whose gradient is folded into fc1's input-gradient GEMM.
+        residual: added to the output inside fc2's epilogue (ops.RESID_EPILOGUE path; no output dropout then)."""
         exact_gelu = isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none"
         if exact_gelu and x.dtype in (torch.bfloat16, torch.float32) and x.is_cuda:
             # one autograd node: GELU (+ hidden dropout) ride on the GEMM epilogues, masks regenerated in backward (ops.MlpFn)
             out = ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                          drop_p=self.drop.p if self.training else 0.0, passthrough=residual_alias)
+                          drop_p=self.drop.p if self.training else 0.0, passthrough=residual_alias, residual=residual)
             y, x_res = out if residual_alias else (out, None)
+        elif residual is not None:
+            return self.fc2(self.drop(self.act(self.fc1(x)))) + residual
         else:
             x_res = None
             if residual_alias:
@@ -164,7 +171,7 @@ class WindowAttention(nn.Module):
             return None
         return ops.RelPosBiasFn.apply(self.relative_position_bias_table, self._rel_idx32, self.window_size)
 
-    def attend(self, x, window_size, idx, roll, labels, apply_proj_drop=True, residual_alias=False):
+    def attend(self, x, window_size, idx, roll, labels, apply_proj_drop=True, residual_alias=False, residual=None):
         """x: [B, N, C] in natural order -> attention branch output [B, N, C] in natural order
         (residual_alias: also an alias of x whose gradient is folded into the qkv input-gradient GEMM)."""
         drop = self.attn_drop.p if self.training else 0.0  # dropout on the attention probabilities (ref :169), in-kernel
@@ -181,6 +188,8 @@ class WindowAttention(nn.Module):
             qkv = self.qkv(x)
         o = ops.window_attn_core(qkv, self.bias(), self.head_scale(), idx, roll, labels, self.num_heads, window_size,
                                  self.use_cos_attn, attn_drop=drop)
+        if residual is not None:  # x + proj(o) from the proj product's epilogue (ops.RESID_EPILOGUE; no proj dropout on this path)
+            return self.proj.forward_residual(o, residual)
         y = self.proj(o)
         y = self.proj_drop(y) if apply_proj_drop else y  # the caller fuses proj_drop into the next norm kernel
         return (y, x_res) if residual_alias else y
@@ -265,13 +274,19 @@ class SwinTransformerBlock(nn.Module):
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "
                 f"window_size={self.window_size}, shift_size={self.shift_size}, mlp_ratio={self.mlp_ratio}")
 
-    def _attention_branch(self, x, apply_proj_drop=True, residual_alias=False):
+    def _attention_branch(self, x, apply_proj_drop=True, residual_alias=False, residual=None):
         if not self._shifted:
-            return self.attn.attend(x, self.window_size, None, 0, None, apply_proj_drop, residual_alias)
+            return self.attn.attend(x, self.window_size, None, 0, None, apply_proj_drop, residual_alias, residual)
         idx, _, labels = self.shifter.tables(x.device)
         if self._is_roll:  # modular offset instead of a table
-            return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels, apply_proj_drop, residual_alias)
-        return self.attn.attend(x, self.window_size, idx, 0, labels, apply_proj_drop, residual_alias)
+            return self.attn.attend(x, self.window_size, None, self.shift_size % x.shape[1], labels, apply_proj_drop, residual_alias,
+                                    residual)
+        return self.attn.attend(x, self.window_size, idx, 0, labels, apply_proj_drop, residual_alias, residual)
+
+    def _stochastic(self):
+        """Any dropout / DropPath on the two residual branches active right now?"""
+        return self.training and ((isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0) or
+                                  self.attn.proj_drop.p > 0 or self.mlp.drop.p > 0)
 
     def _hs_norms(self):
         return isinstance(self.norm1, HSLayerNorm) and isinstance(self.norm2, HSLayerNorm)
@@ -307,6 +322,27 @@ class SwinTransformerBlock(nn.Module):
             x1 = self.attn.fused_module(xs, self.window_size, idx, roll, labels, norm=self.norm1, residual=True)
             m = self.mlp(self.norm2(x1), apply_out_drop=False)
             return x1, (m, None, 0.0), None
+        if ops.RESID_EPILOGUE and x.dtype == torch.bfloat16 and not comp and x_lo is None and not self._stochastic():
+            # a residual add leaves its branch's last product's epilogue WHERE that product runs on hs_gemm_nt anyway (the
+            # HBM-bound shapes of stages 0-1); the norm behind it is then a plain LayerNorm whose second output is an alias of its
+            # input (the alias' gradient is added inside the LayerNorm backward kernel).  Elsewhere the add stays in the norm kernel.
+            C = self.dim
+            proj_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, C, x.dtype)
+            fc2_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, self.mlp.fc1.weight.shape[0], x.dtype)
+            if proj_own or fc2_own:
+                if pending is None:
+                    n1, xs = ops.layer_norm_passthrough(x, self.norm1.weight, self.norm1.bias)
+                else:
+                    t, rs, dp = pending
+                    xs, n1 = ops.add_layer_norm(x, t, self.norm1.weight, self.norm1.bias, row_scale=rs, drop_p=dp)
+                if proj_own:
+                    x1 = self._attention_branch(n1, apply_proj_drop=False, residual=xs)
+                    n2, x1 = ops.layer_norm_passthrough(x1, self.norm2.weight, self.norm2.bias)
+                else:
+                    x1, n2 = ops.add_layer_norm(xs, self._attention_branch(n1, apply_proj_drop=False), self.norm2.weight, self.norm2.bias)
+                if fc2_own:
+                    return self.mlp(n2, apply_out_drop=False, residual=x1), None, None
+                return x1, (self.mlp(n2, apply_out_drop=False), None, 0.0), None
         if pending is None:  # x feeds norm1 AND the residual add below: the alias keeps the two gradients in one kernel
             n1, x = ops.layer_norm_passthrough(x, self.norm1.weight, self.norm1.bias)
         elif comp:

@@ -670,6 +670,17 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     return kk <= 128 or n <= 128 or (n <= 256 and kk <= 256)
 
 
+def own_gemm_legal(n, k, dtype):
+    """Whether `hs_gemm_nt` CAN run an [*, k] x [n, k]^T product (the policy question is own_gemm_ok)."""
+    return dtype == torch.bfloat16 and OWN_GEMM != "0" and k % 8 == 0 and n % 8 == 0 and n >= 16
+
+
+# Residual adds in the GEMM epilogue (v1 blocks without stochastic regularisers): x1 = x + proj(o) and x2 = x1 + fc2(act) leave the
+# proj / fc2 product's epilogue (EPI_RESID: acc + bias + residual, ONE rounding), so the LayerNorm that follows is a plain
+# LayerNorm (reads 1, writes 1) instead of the fused add + LayerNorm (reads 2, writes 2): 2 of 8 tensor-units per block.
+RESID_EPILOGUE = os.environ.get("HS_RESID_EPILOGUE", "1") != "0"
+
+
 def gemm_nt(a2d, w, bias=None, epi=0, aux=None, a2=None, w2=None, want_c=True, drop_p=0.0, seed=0):
     """c = epilogue(a2d @ w^T (+ a2 @ w2^T) + bias) through `hs_gemm_nt`; returns (c, aux).  a2d [m, k] bf16 (row stride free),
     w [n, k] bf16 (row stride free), bias fp32 [n] or None."""
@@ -836,8 +847,8 @@ class LinearFn(torch.autograd.Function):
     [f_out, C, 1]): it is used as the [n_out, k_in] matrix it is, so the PARAMETER itself (a leaf) receives the gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, passthrough=False):
-        _require_gpu(x, weight, bias)
+    def forward(ctx, x, weight, bias, passthrough=False, residual=None):
+        _require_gpu(x, weight, bias, residual)
         n_out = weight.shape[0]
         k_in = weight.numel() // n_out
         w = _cast_param(weight, x.dtype).view(n_out, k_in)
@@ -846,6 +857,15 @@ class LinearFn(torch.autograd.Function):
         ctx.w_cast = w if w.dtype != weight.dtype else None  # activation-dtype copy, reused by the input-gradient GEMM
         ctx.cast_cache = CAST_CACHE
         ctx.passthrough = passthrough
+        ctx.has_residual = residual is not None
+        if residual is not None:
+            # y = x W^T + b + residual: the add rides on the product's epilogue (one rounding); its gradient is dy itself
+            assert not passthrough
+            if own_gemm_legal(n_out, k_in, x.dtype) and x.is_contiguous():
+                res2 = residual.reshape(-1, n_out)
+                res2 = res2 if res2.is_contiguous() else res2.contiguous()
+                return gemm_nt(x.reshape(-1, k_in), w, bias, _lib.HS_EPI_RESID, aux=res2)[0].view(x.shape[:-1] + (n_out,))
+            return _lib_linear(x, w, None if bias is None else _cast_param(bias, x.dtype)) + residual
         if own_gemm_ok(_lib.HS_EPI_BIAS, n_out, k_in, x.dtype) and x.is_contiguous():
             y = gemm_nt(x.reshape(-1, k_in), w, bias)[0].view(x.shape[:-1] + (n_out,))  # fp32 master bias added in the epilogue
         else:
@@ -888,7 +908,7 @@ class LinearFn(torch.autograd.Function):
         n_out = weight.shape[0]
         k_in = weight.numel() // n_out
         if dy is None:  # only the passthrough alias was used downstream
-            return dx_res, None, None, None
+            return dx_res, None, None, None, None
         dy2 = dy.reshape(-1, n_out)
         x2 = x.reshape(-1, k_in)
         if not dy2.is_contiguous():
@@ -898,7 +918,7 @@ class LinearFn(torch.autograd.Function):
             dx = _input_grad(dy2, weight, ctx.w_cast, None if dx_res is None else dx_res.reshape(-1, k_in), ctx.cast_cache).reshape(x.shape)
         ctx.w_cast = ctx.cast_cache = None
         dw, db = _param_grads(dy2, x2, weight, bias, ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2])
-        return dx, dw, db, None
+        return dx, dw, db, None, (dy if ctx.has_residual else None)
 
 
 def _input_grad(dy2, weight, w_cast, dx_res2=None, cache=None):
@@ -918,6 +938,11 @@ def _input_grad(dy2, weight, w_cast, dx_res2=None, cache=None):
 
 def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
+
+
+def linear_residual(x, weight, bias, residual):
+    """x W^T + b + residual with the add in the product's epilogue (LinearFn)."""
+    return LinearFn.apply(x, weight, bias, False, residual)
 
 
 def linear_passthrough(x, weight, bias=None):
@@ -1187,8 +1212,8 @@ class MlpFn(torch.autograd.Function):
     faster (own_gemm_ok) the standalone `hs_gelu_*` kernels are used instead; both forms draw the same dropout mask."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, drop_p, seed, passthrough):
-        _require_gpu(x, w1, b1, w2, b2)
+    def forward(ctx, x, w1, b1, w2, b2, drop_p, seed, passthrough, residual=None):
+        _require_gpu(x, w1, b1, w2, b2, residual)
         c_in, hid = w1.shape[1], w1.shape[0]
         x2 = x.reshape(-1, c_in)
         if not x2.is_contiguous():
@@ -1203,10 +1228,16 @@ class MlpFn(torch.autograd.Function):
             a = torch.empty_like(h)
             check(lib.hs_gelu_fwd(ptr(h), ptr(a), h.numel(), float(drop_p), int(seed), _lib.dtype_code(dt), stream_ptr(h.device)),
                   "hs_gelu_fwd")
-        if own_gemm_ok(_lib.HS_EPI_BIAS, w2.shape[0], hid, dt):
+        ctx.has_residual = residual is not None
+        if residual is not None and own_gemm_legal(w2.shape[0], hid, dt):
+            res2 = residual.reshape(-1, w2.shape[0])
+            y = gemm_nt(a, w2c, b2, _lib.HS_EPI_RESID, aux=res2 if res2.is_contiguous() else res2.contiguous())[0]
+        elif own_gemm_ok(_lib.HS_EPI_BIAS, w2.shape[0], hid, dt):
             y = gemm_nt(a, w2c, b2)[0]
         else:
             y = _lib_linear(a, w2c, None if b2 is None else _cast_param(b2, dt))
+        if residual is not None and not own_gemm_legal(w2.shape[0], hid, dt):
+            y = y + residual.reshape(-1, w2.shape[0])
         ctx.save_for_backward(x2, h, a, w1, w2)
         ctx.biases = (b1, b2)
         ctx.casts = (w1c if w1c.dtype != w1.dtype else None, w2c if w2c.dtype != w2.dtype else None)
@@ -1222,7 +1253,7 @@ class MlpFn(torch.autograd.Function):
         w1c, w2c = ctx.casts
         p, seed, xshape = ctx.meta
         if dy is None:  # only the passthrough alias was used downstream
-            return dx_res, None, None, None, None, None, None, None
+            return dx_res, None, None, None, None, None, None, None, None
         c_out, hid, c_in = w2.shape[0], w1.shape[0], w1.shape[1]
         dy2 = dy.reshape(-1, c_out)
         if not dy2.is_contiguous():
@@ -1242,14 +1273,14 @@ class MlpFn(torch.autograd.Function):
         ctx.casts = ctx.cast_cache = None
         dw2, db2 = _param_grads(dy2, a, w2, b2, ctx.needs_input_grad[3], b2 is not None and ctx.needs_input_grad[4])
         dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[1], b1 is not None and ctx.needs_input_grad[2])
-        return dx, dw1, db1, dw2, db2, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, (dy if ctx.has_residual else None)
 
 
-def mlp(x, w1, b1, w2, b2, drop_p=0.0, seed=None, passthrough=False):
-    """fc2(dropout(gelu(fc1(x)))) (+ an alias of x when passthrough, see LinearFn)."""
+def mlp(x, w1, b1, w2, b2, drop_p=0.0, seed=None, passthrough=False, residual=None):
+    """fc2(dropout(gelu(fc1(x)))) (+ an alias of x when passthrough, see LinearFn; + residual in fc2's epilogue)."""
     if drop_p > 0.0 and seed is None:
         seed = _draw_seed()
-    return MlpFn.apply(x, w1, b1, w2, b2, float(drop_p), int(seed or 0), bool(passthrough))
+    return MlpFn.apply(x, w1, b1, w2, b2, float(drop_p), int(seed or 0), bool(passthrough), residual)
 
 
 class ConcatLinearFn(torch.autograd.Function):

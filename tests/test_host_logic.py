@@ -101,3 +101,44 @@ def test_npz_sample_format_round_trip(tmp_path):
     spec = D.data_spec_of(ds[0], n_classes=10)
     assert (spec.dim_in, spec.f_in, spec.f_out, spec.base_pix) == (npix, 3, 10, 8)
     assert D.data_spec_of((np.zeros((3, 12 * 256 * 256), np.uint8), None), 12).base_pix == 12
+
+
+def test_fold_head_ce_permutes_class_rows_for_the_backward_kernel():
+    """`hs_ln_head_ce_bwd` wants accumulator register r < 8 of lane half h to be class 8 h + r; the MFMA puts row m = (r & 3) +
+    8 (r >> 2) + 4 h there, so ops._fold_head_ce exchanges row blocks 4..7 and 8..11 of the folded weight (hi rows 0..31 and lo rows
+    32..63 alike) and of the bias vector."""
+    import torch
+    from heal_swin_amd import ops
+
+    torch.manual_seed(0)
+    C, f_out = 64, 12
+    gamma, beta, w = torch.randn(C), torch.randn(C), torch.randn(f_out, C, 1)
+    wf, bv = ops._fold_head(gamma, beta, w, C, "cpu")
+    wp, bp = ops._fold_head_ce(gamma, beta, w, C, "cpu")
+    for h in range(2):
+        for r in range(8):
+            m = (r & 3) + 8 * (r >> 2) + 4 * h  # accumulator row of register r in lane half h
+            cls = 8 * h + r
+            assert torch.equal(wp[m], wf[cls]) and torch.equal(wp[32 + m], wf[32 + cls]) and bp[m] == bv[cls]
+    assert not wp[16:32].any() and not wp[48:].any()
+
+
+def test_bf16x3_policy_and_legality_helpers():
+    import torch
+    from heal_swin_amd import ops
+
+    class T:  # shape / dtype / device stand-in (the helpers never touch data)
+        def __init__(self, k, dtype=torch.float32, cuda=True):
+            self.shape, self.dtype, self.is_cuda = (4, k), dtype, cuda
+    prev = ops.FP32_GEMM
+    try:
+        ops.FP32_GEMM = "bf16x3"
+        assert ops._bf16x3_ok(T(512), 2048, 512) and ops._bf16x3_ok(T(512), 512, 512)   # stage 2 of HEAL-SWIN-B: MFMA-bound in fp32
+        assert not ops._bf16x3_ok(T(128), 384, 128) and not ops._bf16x3_ok(T(96), 288, 96)  # stage 0: HBM-bound, stays exact fp32
+        assert not ops._bf16x3_ok(T(512, torch.bfloat16), 2048, 512) and not ops._bf16x3_ok(T(516), 2048, 516)
+        ops.FP32_GEMM = "strict"
+        assert not ops._bf16x3_ok(T(512), 2048, 512)
+    finally:
+        ops.FP32_GEMM = prev
+    assert ops.own_gemm_legal(128, 512, torch.bfloat16) and not ops.own_gemm_legal(12, 128, torch.bfloat16)
+    assert not ops.own_gemm_legal(128, 512, torch.float32)
