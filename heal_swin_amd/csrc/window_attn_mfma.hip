@@ -1022,16 +1022,21 @@ int persistent_slots(const AttnParams& p, int groups, int waves_per_wg) {
 int bwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / hg, 2 * hg); }  // two wavefronts per head
 int fwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / hg, hg); }
 
-// Measured (B / nside 256 / batch 8, profiles/r02_attn_head_group_ab.txt): the width of the contiguous row segment a workgroup
-// moves matters more than the number of waves behind its barriers -- backward with one head per workgroup (64-byte segments)
-// is 15-25 % slower than with pairs at every stage, four heads (256-byte segments, but eight waves per barrier and one
-// workgroup per CU) 3-8 % slower than pairs; forward with 2 / 1 heads per workgroup 3-7 % / 20 % slower than with 4.
-int pick_head_group_bwd(int nH) {
+// Heads per workgroup.  Forward (one wave per head): 4 where the head count allows (round 2: 2 / 1 heads per workgroup 3-7 % / 20 %
+// slower).  Backward (two waves per head): round 2 measured pairs ahead of four heads on the 5-barrier kernel (8-wave barriers);
+// with the 3-barrier kernel of round 4 FOUR heads per workgroup (8 waves, 137 KB of LDS, one workgroup per CU, 256-byte row
+// segments) win at every stage of HEAL-SWIN-B (profiles/r04_attn_bwd_hg4_ab.txt, same box: 570 -> 515, 290 -> 260, 163 -> 150,
+// 96 -> 93 us).  HS_ATTN_BWD_HG / HS_ATTN_FWD_HG force a size for A/B runs.
+int pick_head_group_bwd(const AttnParams& p) {
     static const int forced = getenv("HS_ATTN_BWD_HG") ? atoi(getenv("HS_ATTN_BWD_HG")) : 0;  // A/B runs
-    if (forced == 1 || (forced == 2 && nH % 2 == 0)) return forced;
-    // 33 KB of LDS per head: pairs (128-B segments) where the head count allows; a 3-head group would need 100 KB and
-    // leave one workgroup per CU, so odd head counts (nH = 3 at stage 0 of the T model) run one head per workgroup and
-    // let the neighbouring workgroup's half of each 128-B line come from L2
+    const int nH = p.nH;
+    if (forced >= 1 && forced <= 4 && nH % forced == 0) return forced;
+    // four heads per workgroup pay on the large launches only (one [B, N, C] tensor >= 64 MB: stages 0-2 of HEAL-SWIN-B at nside
+    // 256); on the small ones (HEAL-SWIN-T: stage 2 at nside 256 88 vs 93 us, at nside 128 33 vs 44 us) two workgroups of four
+    // waves per CU hide each other's prologue and barriers better
+    if (nH % 4 == 0 && (int64_t)p.B * p.N * p.C * 2 >= (64ll << 20)) return 4;
+    // 33 KB of LDS per head; odd head counts (nH = 3 at stage 0 of the T model) run one head per workgroup and let the
+    // neighbouring workgroup's half of each 128-B line come from L2
     return nH % 2 == 0 ? 2 : 1;
 }
 
@@ -1097,7 +1102,7 @@ bool attn_mfma_supported(const AttnParams& p, int dtype) {
 }
 
 int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
-    const int hg = pick_head_group_bwd(p.nH);
+    const int hg = pick_head_group_bwd(p);
     return (int64_t)bwd_slots(p, hg) * p.nH * (kWs * kWs + 2);
 }
 
@@ -1111,15 +1116,21 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     }
 }
 
+template <int HG>
+int launch_bwd_hg(const AttnParams& p, float* workspace, hipStream_t stream) {
+    const bool drop = p.drop_p > 0.f, cos = (p.flags & HS_ATTN_COSINE) != 0;
+    if (cos) return drop ? launch_bwd<HG, true, true>(p, workspace, stream) : launch_bwd<HG, false, true>(p, workspace, stream);
+    return drop ? launch_bwd<HG, true, false>(p, workspace, stream) : launch_bwd<HG, false, false>(p, workspace, stream);
+}
+
 int launch_attn_bwd_mfma(const AttnParams& p, float* workspace, hipStream_t stream) {
     if (!workspace) return fail(HS_ERR_INVALID_ARG, "the MFMA backward needs a workspace (hs_window_attn_bwd_workspace)");
-    const bool drop = p.drop_p > 0.f, cos = (p.flags & HS_ATTN_COSINE) != 0;
-    if (pick_head_group_bwd(p.nH) == 2) {
-        if (cos) return drop ? launch_bwd<2, true, true>(p, workspace, stream) : launch_bwd<2, false, true>(p, workspace, stream);
-        return drop ? launch_bwd<2, true, false>(p, workspace, stream) : launch_bwd<2, false, false>(p, workspace, stream);
+    switch (pick_head_group_bwd(p)) {
+        case 4: return launch_bwd_hg<4>(p, workspace, stream);
+        case 3: return launch_bwd_hg<3>(p, workspace, stream);
+        case 2: return launch_bwd_hg<2>(p, workspace, stream);
+        default: return launch_bwd_hg<1>(p, workspace, stream);
     }
-    if (cos) return drop ? launch_bwd<1, true, true>(p, workspace, stream) : launch_bwd<1, false, true>(p, workspace, stream);
-    return drop ? launch_bwd<1, true, false>(p, workspace, stream) : launch_bwd<1, false, false>(p, workspace, stream);
 }
 
 }  // namespace hs
