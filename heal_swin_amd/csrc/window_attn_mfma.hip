@@ -1067,9 +1067,14 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
     return HS_OK;
 }
 
-int pick_head_group(int nH) {
+int pick_head_group(const AttnParams& p) {
     static const int forced = getenv("HS_ATTN_FWD_HG") ? atoi(getenv("HS_ATTN_FWD_HG")) : 0;  // A/B runs
-    if (forced >= 1 && forced <= 4 && nH % forced == 0) return forced;
+    const int nH = p.nH;
+    if (((forced >= 1 && forced <= 4) || forced == 8) && nH % forced == 0) return forced;
+    // eight heads per workgroup (512-byte row segments, one workgroup of 8 waves per CU) on the large launches: with the
+    // 2-barrier kernel of round 4 stages 1 / 2 of HEAL-SWIN-B run 177 -> 166 / 107 -> 99 us (profiles/r04_attn_fwd_hg8_ab.txt;
+    // round 3 had measured the opposite on the 3-barrier kernel); the small stage 3 (50 MB) loses 10 %
+    if (nH % 8 == 0 && (int64_t)p.B * p.N * p.C * 2 >= (64ll << 20)) return 8;
     if (nH % 4 == 0) return 4;
     if (nH % 3 == 0) return 3;
     if (nH % 2 == 0) return 2;
@@ -1108,7 +1113,8 @@ int64_t attn_bwd_mfma_workspace_floats(const AttnParams& p) {
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     const bool drop = p.drop_p > 0.f;
-    switch (pick_head_group(p.nH)) {
+    switch (pick_head_group(p)) {
+        case 8: return drop ? launch_fwd<8, true>(p, stream) : launch_fwd<8, false>(p, stream);
         case 4: return drop ? launch_fwd<4, true>(p, stream) : launch_fwd<4, false>(p, stream);
         case 3: return drop ? launch_fwd<3, true>(p, stream) : launch_fwd<3, false>(p, stream);
         case 2: return drop ? launch_fwd<2, true>(p, stream) : launch_fwd<2, false>(p, stream);
