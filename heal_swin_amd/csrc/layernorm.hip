@@ -251,6 +251,111 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
     }
 }
 
+// The training default of the forward, specialised like layernorm_bwd_bf16_kernel below (round 4): bf16 rows in 16-byte chunks,
+// y = LN(x) or (sum_out = x + add_in, y = LN(sum_out)); no dropout, DropPath scale, v2 residual or compensated stream.  Next
+// rows' chunks requested packed before the current rows are reduced, 32-bit byte offsets from uniform bases, launch sized to
+// one resident round.
+template <int LPR, int ITERS>
+__global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS == 4 ? 3 : 1)) layernorm_fwd_bf16_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ add_in, const float* __restrict__ gamma, const float* __restrict__ beta,
+    uint16_t* __restrict__ y, uint16_t* __restrict__ sum_out, float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
+    int width) {
+    constexpr int RPW = 64 / LPR, VEC = 8;
+    constexpr bool PF = ITERS <= 2;
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsub = lane / LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * RPW;
+    const int nchunk = width / VEC;
+    const float inv_w = 1.f / (float)width;
+    const bool adding = add_in != nullptr;
+    uint4 px[ITERS], pa[ITERS];
+    auto fetch = [&](int64_t r0) {
+        const int64_t row = r0 + rsub;
+        if (row < rows) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = sub + LPR * it;
+                if (c < nchunk) {
+                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
+                    px[it] = *(const uint4*)((const char*)x + e);
+                    if (adding) pa[it] = *(const uint4*)((const char*)add_in + e);
+                }
+            }
+        }
+    };
+    int64_t row0 = wave * RPW;
+    if (PF && row0 < rows) fetch(row0);
+    for (; row0 < rows; row0 += stride) {
+        const int64_t row = row0 + rsub;
+        const bool live = row < rows;
+        if (!PF) fetch(row0);
+        uint4 cx[ITERS], ca[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            cx[it] = px[it];
+            ca[it] = pa[it];
+        }
+        if (PF && row0 + stride < rows) fetch(row0 + stride);
+        float v[ITERS][VEC];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
+                vec_io<bf16_t, VEC>::decode(cx[it], v[it]);
+                if (adding) {  // the stream as every other consumer sees it: rounded to bf16 exactly as a separate add would store it
+                    float a2[VEC];
+                    vec_io<bf16_t, VEC>::decode(ca[it], a2);
+                    uint32_t w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        w[k] = pack_bf16x2(v[it][2 * k] + a2[2 * k], v[it][2 * k + 1] + a2[2 * k + 1]);
+                        v[it][2 * k] = __uint_as_float(w[k] << 16);
+                        v[it][2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+                    }
+                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
+                    *(uint4*)((char*)sum_out + e) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) sum += v[it][k];
+            }
+        }
+        const float mean = row_sum<LPR>(sum) * inv_w;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float d = v[it][k] - mean;
+                    sq = fmaf(d, d, sq);
+                }
+            }
+        }
+        const float rstd = rsqrtf(row_sum<LPR>(sq) * inv_w + kLnEps);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
+                const float4 g0 = *(const float4*)(gamma + c * VEC), g1 = *(const float4*)(gamma + c * VEC + 4);
+                const float4 b0 = *(const float4*)(beta + c * VEC), b1 = *(const float4*)(beta + c * VEC + 4);
+                const float g[VEC] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[VEC] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float o[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = fmaf((v[it][k] - mean) * rstd, g[k], b[k]);
+                const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
+                *(uint4*)((char*)y + e) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                                                     pack_bf16x2(o[6], o[7]));
+            }
+        }
+        if (live && sub == 0 && mean_out) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Each lane also accumulates sum(dy * xhat) and
 // sum(dy) for its columns; they are combined across the wave's row groups by shuffles, across the workgroup's waves
 // through LDS, and written as one partial row pair per workgroup ([gridDim.x][2][width]) for the final reduce.
@@ -399,6 +504,174 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
     }
 }
 
+// The training default, specialised (round 4): bf16 rows in 16-byte chunks, no dropout, no DropPath scale, one gradient out.
+// Same arithmetic and partial-sum layout as the general kernel above.  What differs is what is in flight: the general kernel
+// needs 110 registers at 512 columns (4 waves per SIMD, one row of x, dy [, dsum] per wave requested at a time: 32-48 KB per CU,
+// 3.2-3.9 TB/s on the 98 304 x 512 rows of stage 2; 162 registers and 1.6-2.0 TB/s at 1024 columns).  Here the chunks of the
+// wave's NEXT rows are requested -- and held packed, 4 registers per 16 bytes -- before the current rows are reduced, and the
+// launch is sized to ONE resident round of workgroups (run_bwd_bf16).
+template <int LPR, int ITERS>
+__global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) layernorm_bwd_bf16_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                                 const float* __restrict__ rstd_in, uint16_t* __restrict__ dx,
+                                                                 float* __restrict__ partials, int64_t rows, int width,
+                                                                 const uint16_t* __restrict__ dres_in) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][width]
+    constexpr int RPW = 64 / LPR, VEC = 8;
+    constexpr bool PF = ITERS <= 2;  // (wider rows have >= 4 chunks per lane and tensor in flight already)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int sub = lane % LPR, rsub = lane / LPR;
+    const int64_t wave = (int64_t)blockIdx.x * nw + wid;
+    const int64_t stride = (int64_t)gridDim.x * nw * RPW;
+    const int nchunk = width / VEC;
+    const float inv_w = 1.f / (float)width;
+    const bool has_res = dres_in != nullptr;
+    float dg[ITERS][VEC], db[ITERS][VEC], gm[ITERS][VEC];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = sub + LPR * it;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+        if (c < nchunk) {
+            g0 = *(const float4*)(gamma + c * VEC);
+            g1 = *(const float4*)(gamma + c * VEC + 4);
+        }
+        gm[it][0] = g0.x; gm[it][1] = g0.y; gm[it][2] = g0.z; gm[it][3] = g0.w;
+        gm[it][4] = g1.x; gm[it][5] = g1.y; gm[it][6] = g1.z; gm[it][7] = g1.w;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            dg[it][k] = 0.f;
+            db[it][k] = 0.f;
+        }
+    }
+    // every tensor is addressed as (uniform base) + (32-bit byte offset): one offset register per chunk instead of a 64-bit
+    // pointer per tensor and chunk (the launcher keeps rows * width * 2 below 4 GiB for this kernel)
+    uint4 px[ITERS], pdy[ITERS], pd2[ITERS];
+    float pmean = 0.f, prstd = 0.f;
+    auto fetch = [&](int64_t r0) {
+        const int64_t row = r0 + rsub;
+        if (row < rows) {
+            const uint32_t ro = (uint32_t)row * 4u;
+            pmean = *(const float*)((const char*)mean_in + ro);
+            prstd = *(const float*)((const char*)rstd_in + ro);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = sub + LPR * it;
+                if (c < nchunk) {
+                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
+                    px[it] = *(const uint4*)((const char*)x + e);
+                    pdy[it] = *(const uint4*)((const char*)dy + e);
+                    if (has_res) pd2[it] = *(const uint4*)((const char*)dres_in + e);
+                }
+            }
+        }
+    };
+    int64_t row0 = wave * RPW;
+    if (PF && row0 < rows) fetch(row0);
+    for (; row0 < rows; row0 += stride) {
+        const int64_t row = row0 + rsub;
+        const bool live = row < rows;
+        if (!PF) fetch(row0);
+        uint4 cx[ITERS], cdy[ITERS], cd2[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            cx[it] = px[it];
+            cdy[it] = pdy[it];
+            cd2[it] = pd2[it];
+        }
+        const float mean = pmean, rstd = prstd;
+        if (PF && row0 + stride < rows) fetch(row0 + stride);
+        // x and dy stay PACKED across the row reductions and are decoded a second time behind them (xhat and dy * gamma in fp32
+        // would be 16 registers per chunk over the two shuffle trees: 114 registers, 4 waves per SIMD; this form needs 80: 6)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
+                const uint32_t wx[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w}, wd[4] = {cdy[it].x, cdy[it].y, cdy[it].z, cdy[it].w};
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float xv = (k & 1) ? __uint_as_float(wx[k >> 1] & 0xffff0000u) : __uint_as_float(wx[k >> 1] << 16);
+                    const float dv = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+                    const float xh = (xv - mean) * rstd, g = dv * gm[it][k];
+                    s1 += g;
+                    s2 = fmaf(g, xh, s2);
+                    dg[it][k] = fmaf(dv, xh, dg[it][k]);
+                    db[it][k] += dv;
+                }
+            }
+        }
+        const float m1 = row_sum<LPR>(s1) * inv_w, m2 = row_sum<LPR>(s2) * inv_w;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {  // (opaque copies: the second decode must not be merged with the first)
+            asm volatile("" : "+v"(cx[it].x), "+v"(cx[it].y), "+v"(cx[it].z), "+v"(cx[it].w));
+            asm volatile("" : "+v"(cdy[it].x), "+v"(cdy[it].y), "+v"(cdy[it].z), "+v"(cdy[it].w));
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (live && c < nchunk) {
+                const uint32_t wx[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w}, wd[4] = {cdy[it].x, cdy[it].y, cdy[it].z, cdy[it].w};
+                const uint32_t w2[4] = {cd2[it].x, cd2[it].y, cd2[it].z, cd2[it].w};
+                float o[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float xv = (k & 1) ? __uint_as_float(wx[k >> 1] & 0xffff0000u) : __uint_as_float(wx[k >> 1] << 16);
+                    const float dv = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+                    const float xh = (xv - mean) * rstd, g = dv * gm[it][k];
+                    o[k] = rstd * (g - m1 - xh * m2);
+                    if (has_res) o[k] += (k & 1) ? __uint_as_float(w2[k >> 1] & 0xffff0000u) : __uint_as_float(w2[k >> 1] << 16);
+                }
+                const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
+                *(uint4*)((char*)dx + e) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                                                      pack_bf16x2(o[6], o[7]));
+            }
+        }
+    }
+    // fold the wave's row groups (lanes sub, sub+LPR, ... hold the same columns), then the workgroup's waves through LDS
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) {
+                dg[it][k] += __shfl_xor(dg[it][k], off, 64);
+                db[it][k] += __shfl_xor(db[it][k], off, 64);
+            }
+        }
+    if (wid > 0 && rsub == 0) {
+        float* mine = red + (size_t)(wid - 1) * 2 * width;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (c < nchunk)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    mine[c * VEC + k] = dg[it][k];
+                    mine[width + c * VEC + k] = db[it][k];
+                }
+        }
+    }
+    __syncthreads();
+    if (wid == 0 && rsub == 0) {
+        float* outp = partials + (size_t)blockIdx.x * 2 * width;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = sub + LPR * it;
+            if (c < nchunk)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float a = dg[it][k], b = db[it][k];
+                    for (int w = 0; w < nw - 1; ++w) {
+                        a += red[(size_t)w * 2 * width + c * VEC + k];
+                        b += red[(size_t)w * 2 * width + width + c * VEC + k];
+                    }
+                    outp[c * VEC + k] = a;
+                    outp[width + c * VEC + k] = b;
+                }
+        }
+    }
+}
+
 // Sum of the per-workgroup partial rows [nblocks][2 * width] into dgamma | dbeta (overwrite, or add when accumulate != 0) in
 // ONE launch: a workgroup owns 64 columns, each of its 16 waves folds every 16th row (256-byte row segments, 8 loads in
 // flight), the 16 wave sums are combined in a fixed order.  Deterministic.  (Two dependent launches -- a 16-group level and
@@ -478,6 +751,58 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     return HS_OK;
 }
 
+template <int LPR, int ITERS>
+int run_fwd_bf16(const void* x, const void* add_in, const float* g, const float* b, void* y, void* sum_out, float* mean, float* rstd,
+                 int64_t rows, int width, hipStream_t s) {
+    auto kern = layernorm_fwd_bf16_kernel<LPR, ITERS>;
+    static int resident = 0;
+    if (resident == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 256, 0) != hipSuccess || n < 1) n = 4;
+        resident = n;
+    }
+    static const int per_cu_override = getenv("HS_LN_FWD_PER_CU") ? atoi(getenv("HS_LN_FWD_PER_CU")) : 0;  // A/B runs
+    constexpr int rows_per_pass = 4 * (64 / LPR);
+    int64_t blocks = (int64_t)usable_cus() * (per_cu_override > 0 ? per_cu_override : resident);
+    const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
+    if (blocks > by_rows) blocks = by_rows;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)add_in, g, b, (uint16_t*)y,
+                       (uint16_t*)sum_out, mean, rstd, rows, width);
+    HS_LAUNCH_CHECK("layernorm_fwd_bf16");
+    return HS_OK;
+}
+
+// One resident round: as many workgroups as the chip holds at this instantiation's register / LDS footprint (every workgroup
+// then sees the same number of rows and there is no second, partly filled round), at most kBwdMaxBlocks partial rows, at
+// least one row group per wave.  HS_LN_BWD_FAST=0 sends everything through the general kernel (A/B runs).
+template <int LPR, int ITERS>
+int run_bwd_bf16(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
+                 float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in, int accumulate) {
+    auto kern = layernorm_bwd_bf16_kernel<LPR, ITERS>;
+    const size_t smem = (size_t)3 * 2 * width * sizeof(float);
+    if (smem > 48 * 1024) HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    static int resident_width = 0, resident = 0;  // per instantiation; the LDS footprint follows the width
+    if (resident_width != width) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 256, smem) != hipSuccess || n < 1) n = 4;
+        resident = n;
+        resident_width = width;
+    }
+    constexpr int rows_per_pass = 4 * (64 / LPR);
+    static const int per_cu_override = getenv("HS_LN_BWD_PER_CU") ? atoi(getenv("HS_LN_BWD_PER_CU")) : 0;  // A/B runs
+    int64_t blocks = (int64_t)usable_cus() * (per_cu_override > 0 ? per_cu_override : resident);
+    if (blocks > kBwdMaxBlocks) blocks = kBwdMaxBlocks;
+    const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
+    if (blocks > by_rows) blocks = by_rows;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, (const uint16_t*)dy, (const uint16_t*)x, g, mean, rstd,
+                       (uint16_t*)dx, ws, rows, width, (const uint16_t*)dres_in);
+    HS_LAUNCH_CHECK("layernorm_bwd_bf16");
+    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 63) / 64), dim3(1024), 0, s, ws, dgamma, dbeta, (int)blocks,
+                       width, accumulate);
+    HS_LAUNCH_CHECK("layernorm_param_reduce");
+    return HS_OK;
+}
+
 // picks lanes-per-row and the per-lane register tile for a row of `width` elements in VEC-wide chunks
 template <typename T, int VEC, typename F>
 int with_shape(int width, F&& f) {
@@ -519,6 +844,10 @@ int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const f
     if (rows == 0) return HS_OK;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
+        static const bool fast = !(getenv("HS_LN_FWD_FAST") && atoi(getenv("HS_LN_FWD_FAST")) == 0);
+        if (fast && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32) && !residual && !ex.row_scale && ex.drop_p == 0.f &&
+            !ex.lo_in && !ex.lo_out)
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_bf16<decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s); });
         if (width % 8 == 0)
             return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
         return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
@@ -538,6 +867,9 @@ int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* 
     if (int st = check_extra(ex, rows)) return st;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HS_BF16) {
+        static const bool fast = !(getenv("HS_LN_BWD_FAST") && atoi(getenv("HS_LN_BWD_FAST")) == 0);
+        if (fast && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32) && !ex.row_scale && ex.drop_p == 0.f && !dadd_out)
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd_bf16<decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, accumulate); });
         if (width % 8 == 0)
             return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
         return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
@@ -572,7 +904,8 @@ int hs_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const
 }
 
 int64_t hs_layernorm_bwd_workspace(int64_t rows, int width) {
-    return (int64_t)(hs::bwd_blocks(rows) + hs::kReduceGroups) * 2 * width;
+    (void)rows;  // the bf16 kernel sizes its launch by the chip, not by the rows: room for the largest launch of either kernel
+    return (int64_t)(hs::kBwdMaxBlocks + hs::kReduceGroups) * 2 * width;
 }
 
 int hs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
