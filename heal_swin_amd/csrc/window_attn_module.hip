@@ -6,8 +6,11 @@
 // partition / reverse / shift back around it (:319-330) and, optionally, the block's norm1 in front (:315, v1 placement)
 // and its residual add behind (:316).  qkv [B, N, 3C], the attention output and the probabilities never exist in HBM:
 // per token 2 C * 2 B of traffic instead of 10 C * 2 B for  qkv GEMM -> hs_window_attn_fwd -> proj GEMM  (SURVEY 8d).
-// Inference / no-grad path: nothing is saved for a backward (training keeps the three-kernel path, whose backward needs
-// qkv and the attention output).
+// Inference form: nothing is saved for a backward.  TRAINING form (TRAIN, round 4: hs_window_attn_module_fwd_train): the same
+// launch also writes what the composed backward (hs_layernorm_bwd, hs_linear_wgrad, hs_window_attn_bwd, hs_gemm_nt) reads --
+// LayerNorm(x) and its row statistics, qkv [B, N, 3C], the attention output [B, N, C] and the score rows' log-sum-exp --
+// in natural token order, straight from the registers / LDS tiles they live in: per token 2 C (x in, out) + 5 C (saved) * 2 B
+// instead of the 13 C * 2 B of LayerNorm -> qkv GEMM -> hs_window_attn_fwd -> proj GEMM (+ residual), none of it re-read.
 //
 // Workgroup = nH wavefronts (one per SIMD, up to 512 registers each), persistent, one 64-token window at a time:
 //   * the bf16 weights of qkv ([3C, C], 96 KB at C = 128) stay in LDS for the whole launch, proj's ([C, C]) in REGISTERS
@@ -71,6 +74,13 @@ struct ModParams {
     int64_t N;
     int slots;
     unsigned flags;
+    // training form (null in the inference form), natural token order
+    uint16_t* xn_out;   // [B, N, C]   LayerNorm(x): input of the qkv product (its weight gradient reads it)
+    uint16_t* qkv_out;  // [B, N, 3C]  as the qkv Linear would have written it
+    uint16_t* o_out;    // [B, N, C]   attention output: input of the proj product
+    float* mean_out;    // [B, N]      LayerNorm statistics
+    float* rstd_out;
+    float* lse_out;     // [B, nH, N]  log-sum-exp of every score row, by SHIFTED position (as hs_window_attn_fwd)
 };
 constexpr unsigned kFlagResidual = 4u;  // out = x + module(x)   (HS_ATTN_RESIDUAL)
 
@@ -93,15 +103,43 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int r0) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NH, bool COS>
+// 16 accumulator values of a transposed output tile (lane = token, register r = feature (r&3) + 8*(r>>2) + 4*half) -> two
+// 16-byte pieces of the token's 64-byte head slice: lanes < 32 hold bytes [0,16) and [32,48), lanes >= 32 bytes [16,32) and [48,64)
+// (v_permlane32_swap pairs the 8-byte pieces of the two lane halves)
+__device__ __forceinline__ void swap_rows_t(const uint32_t (&packed)[8], u32x4& p0, u32x4& p1) {  // packed[i] = registers 2i, 2i+1
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = packed[i];
+#pragma unroll
+    for (int m = 0; m < 4; m += 2)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const auto r = __builtin_amdgcn_permlane32_swap(w[2 * m + d], w[2 * m + 2 + d], false, false);
+            w[2 * m + d] = r[0];
+            w[2 * m + 2 + d] = r[1];
+        }
+    p0 = u32x4{w[0], w[1], w[2], w[3]};
+    p1 = u32x4{w[4], w[5], w[6], w[7]};
+}
+__device__ __forceinline__ void pack_rows_t(const f32x16& v, u32x4& p0, u32x4& p1) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    swap_rows_t(w, p0, p1);
+}
+constexpr float kLn2 = 0.6931471805599453f;
+
+template <int NH, bool COS, bool TRAIN>
 __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int C = 32 * NH, NT = NH * 64, KS = C / 16, NCH = C / 8;  // channels, threads, 16-deep k-steps, 16-byte chunks per row
     constexpr int W_OFF = 0, X_OFF = 3 * C * kRowB, O_OFF = X_OFF + 2 * kWs * kRowB, M_OFF = O_OFF + kWs * kRowB;
     constexpr int XP = (16 + NH - 1) / NH;  // x-tile DMA pieces (1 KB = 4 rows) per wave
     // + two 256-B label patches (64 bytes used) + fp32 parameter block: LayerNorm gamma | beta, qkv bias (q | k rows), proj bias
-    constexpr int P_OFF = M_OFF + 2 * 256, P_LNG = 0, P_LNB = 128, P_BQ = 256, P_BK = 384, P_BP = 512;  // float offsets, 128 each
-    __shared__ __attribute__((aligned(16))) unsigned char smem[P_OFF + 5 * 128 * 4];
+    constexpr int P_OFF = M_OFF + 2 * 256, P_LNG = 0, P_LNB = 128, P_BQ = 256, P_BK = 384, P_BP = 512, P_BV = 640;  // float offsets, 128 each
+    // + (training form) the natural-order token of each of the 64 window rows, current / next window: two 256-byte tables
+    constexpr int T_OFF = P_OFF + 6 * 128 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[T_OFF + 2 * 256];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -132,6 +170,7 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             ps[P_BQ + i] = p.qkv_b ? p.qkv_b[i] : 0.f;
             ps[P_BK + i] = p.qkv_b ? p.qkv_b[C + i] : 0.f;
             ps[P_BP + i] = p.proj_b ? p.proj_b[i] : 0.f;
+            ps[P_BV + i] = p.qkv_b ? p.qkv_b[2 * C + i] : 0.f;
         }
     }
     const uint32_t pbase = lds0 + P_OFF;
@@ -157,35 +196,35 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.x, 0, (int)(((int64_t)p.B * N * C * 2) > 0x7FFFFE00ll ? 0x7FFFFE00ll : (int64_t)p.B * N * C * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)p.labels, 0, p.labels ? (int)N : 0, 0x00020000);
-    int prow[XP], pchunk[XP];
-#pragma unroll
-    for (int j = 0; j < XP; ++j) {
-        const int q = (wave + NH * j) * 64 + lane;
-        prow[j] = q >> 4;
-        pchunk[j] = (q & 15) ^ (prow[j] & 15);
-    }
-    int64_t tok[XP], tok_next[XP];  // token (global row) of this lane's piece rows: current / next window
-    auto tokens_of = [&](int64_t wi, int64_t (&t)[XP]) {
+    // piece j of this wave: LDS position q = (wave + NH j) * 64 + lane -> (tile row q / 16, logical chunk (q % 16) ^ (row % 16)).
+    // Recomputed from an opaque copy of the lane index that is refreshed once per window (two shifts and an xor per use): kept
+    // in registers over the window loop -- with everything derived from them, hoisted -- they were spilled, and a reload at the
+    // loop top waits for the previous window's stores
+    int lane_o = lane;
+    auto prow_of = [&](int j) { return ((wave + NH * j) * 64 + lane_o) >> 4; };
+    auto pchunk_of = [&](int j) { return (lane_o & 15) ^ (prow_of(j) & 15); };
+    uint32_t tok[XP], tok_next[XP];  // token (row of this launch's x) of this lane's piece rows: current / next window (< 2^30: the chunk limit)
+    auto tokens_of = [&](int64_t wi, uint32_t (&t)[XP]) {
         const int b = (int)(wi / nW);
         const int64_t j0 = (wi - (int64_t)b * nW) * kWs;
 #pragma unroll
         for (int j = 0; j < XP; ++j) {
-            const int64_t js = j0 + (prow[j] & 63);  // shifted position -> natural-order token (gather = scatter map)
+            const int64_t js = j0 + (prow_of(j) & 63);  // shifted position -> natural-order token (gather = scatter map)
             int64_t src;
             if (p.idx) src = p.idx[js];
             else {
                 src = js + p.roll;
                 if (src >= N) src -= N;
             }
-            t[j] = (int64_t)b * N + src;
+            t[j] = (uint32_t)((int64_t)b * N + src);
         }
     };
-    auto issue_x = [&](const int64_t (&t)[XP], int64_t wi, int buf) {
+    auto issue_x = [&](const uint32_t (&t)[XP], int64_t wi, int buf) {
 #pragma unroll
         for (int j = 0; j < XP; ++j) {
             const int pc = wave + NH * j;
             if (pc < 16) {
-                const uint32_t voff = pchunk[j] < NCH ? (uint32_t)(t[j] * (C * 2) + pchunk[j] * 16) : kOob;
+                const uint32_t voff = pchunk_of(j) < NCH ? (uint32_t)(t[j] * (C * 2) + pchunk_of(j) * 16) : kOob;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(smem + X_OFF + buf * (kWs * kRowB) + pc * 1024), 16, voff, 0, 0, 0);
             }
         }
@@ -196,28 +235,67 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
         }
     };
 
+    auto note_tokens = [&](int64_t w, int buf) {  // (training form) row -> token table of window w
+        if (tid < kWs) {
+            const int b = (int)(w / nW);
+            const int64_t js = (w - (int64_t)b * nW) * kWs + tid;
+            int64_t src;
+            if (p.idx) src = p.idx[js];
+            else {
+                src = js + p.roll;
+                if (src >= N) src -= N;
+            }
+            const uint32_t t = (uint32_t)((int64_t)b * N + src);
+            asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + T_OFF + buf * 256 + tid * 4), "v"(t) : "memory");
+        }
+    };
+    // whole 2C-byte token rows of an LDS tile (x / O tile image) -> dst[token]: the scatter half of the shift
+    auto store_rows = [&](uint32_t tile_base, uint16_t* dst) {
+        u32x4 rows[XP];
+#pragma unroll
+        for (int j = 0; j < XP; ++j)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(rows[j]) : "v"(tile_base + (uint32_t)((wave + NH * j) * 1024 + lane * 16)));
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(rows[j]) : "n"(XP - 1 - j));
+            if (wave + NH * j < 16 && pchunk_of(j) < NCH) *(u32x4*)(dst + (int64_t)tok[j] * C + pchunk_of(j) * 8) = rows[j];
+        }
+    };
+
     int64_t wi = blockIdx.x;
     tokens_of(wi, tok);
     issue_x(tok, wi, 0);
+    if constexpr (TRAIN) note_tokens(wi, 0);
     int cur = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weights and the first window's x rows have landed
     const uint32_t wbase = lds0 + W_OFF, obase = lds0 + O_OFF;
 
     for (; wi < total_windows; wi += p.slots) {
+        asm volatile("" : "+v"(lane_o));
         const bool more = wi + p.slots < total_windows;
         if (more) tokens_of(wi + p.slots, tok_next);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights (first pass) and this window's x rows have landed
+        // (this wave's pieces of the window's x tile were waited for in front of the previous window's output stores -- not here,
+        // where a vmcnt(0) would also wait for those stores' acknowledgements: 1-2 k cycles per window with nothing else to run)
+        if constexpr (TRAIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first window's token table)
         __builtin_amdgcn_s_barrier();
-        const uint32_t xbase = lds0 + X_OFF + cur * (kWs * kRowB);
+        const uint32_t xbase = lds0 + X_OFF + cur * (kWs * kRowB), tbase = lds0 + T_OFF + cur * 256;
+        if constexpr (TRAIN) {
+            if (more) note_tokens(wi + p.slots, cur ^ 1);  // read from the next window's first barrier on
+        }
         // region labels of this window (fetched with its x tile into label patch `cur`): 16 words, every lane reads all
-        uint32_t labw[16];
+        // (the words are read again where a cut window needs them: 16 registers held across every phase cost the training form spills)
         bool mixed = false;
-        if (p.labels) {
+        auto read_labels = [&](uint32_t (&labw)[16]) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(labw[i]) : "v"(lds0 + M_OFF + cur * 256), "n"(4 * i));
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(labw[0]), "+v"(labw[1]), "+v"(labw[2]), "+v"(labw[3]), "+v"(labw[4]), "+v"(labw[5]), "+v"(labw[6]),
                            "+v"(labw[7]), "+v"(labw[8]), "+v"(labw[9]), "+v"(labw[10]), "+v"(labw[11]), "+v"(labw[12]),
                            "+v"(labw[13]), "+v"(labw[14]), "+v"(labw[15]));
+        };
+        if (p.labels) {
+            uint32_t labw[16];
+            read_labels(labw);
             const uint32_t first = (labw[0] & 0xffu) * 0x01010101u;
 #pragma unroll
             for (int i = 0; i < 16; ++i) mixed |= labw[i] != first;
@@ -227,10 +305,16 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
         // ------------------------------------------------------------ optional LayerNorm of the 64 rows, in place
         if (has_ln) {
             // thread -> (row tid / 4 [+ NT / 4 per pass], quarter tid % 4 = CPQ chunks of 8 channels)
-            for (int row = tid >> 2; row < kWs; row += NT / 4) {
-                const int qd = tid & 3;
+            // (opaque copy of the thread index: the row / chunk / parameter addresses below are loop-invariant, and hoisted out of the
+            // window loop they were spilled -- reloaded here behind the next window's DMA, i.e. behind a full vmcnt(0))
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            for (int row = tl >> 2; row < kWs; row += NT / 4) {
+                const int qd = tl & 3;
                 // the row quarter and its gamma / beta are requested together: one LDS round trip for the whole phase
                 u32x4 v[CPQ], gw[CPQ][2], bw[CPQ][2];
+                uint32_t rtok = 0;  // (training form) token of this row; the oldest LDS read of the phase: returned before v[0]
+                if constexpr (TRAIN) asm volatile("ds_read_b32 %0, %1" : "=v"(rtok) : "v"(tbase + row * 4));
 #pragma unroll
                 for (int c = 0; c < CPQ; ++c) v[c] = ld128(xbase + swz(row, qd * CPQ + c));
 #pragma unroll
@@ -268,6 +352,13 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                 s2 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s2), 0xB1, 0xF, 0xF, true));
                 s2 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s2), 0x4E, 0xF, 0xF, true));
                 const float rstd = rsqrtf(s2 * (1.f / C) + kLnEps);
+                if constexpr (TRAIN) {
+                    asm volatile("" : "+v"(rtok));
+                    if (qd == 0) {
+                        p.mean_out[rtok] = mean;
+                        p.rstd_out[rtok] = rstd;
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < CPQ; ++c) {
                     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(gw[c][0]), "+v"(gw[c][1]), "+v"(bw[c][0]), "+v"(bw[c][1]) : "n"(4 * (CPQ - 1 - c)));
@@ -284,9 +375,15 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        if constexpr (TRAIN) store_rows(xbase, p.xn_out);  // LayerNorm(x), whole rows from the tile the qkv product reads
 
         // ------------------------------------------------------------ q^T, k^T, v of this head: 6 accumulators, KS k-steps
         f32x16 aq[2], ak[2], av[2];
+        uint32_t ltok[2] = {0u, 0u};  // (training form) tokens of this lane's two rows
+        if constexpr (TRAIN) {
+            asm volatile("ds_read_b32 %0, %1" : "=v"(ltok[0]) : "v"(tbase + l31 * 4));
+            asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(ltok[1]) : "v"(tbase + l31 * 4));
+        }
         {   // accumulators start at the bias: q^T / k^T rows d = 8 g + 4 half + 0..3 (group g = r / 4), v column d = l31
             u32x4 bqv[4], bkv[4];
 #pragma unroll
@@ -296,6 +393,7 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(bqv[0]), "+v"(bqv[1]), "+v"(bqv[2]), "+v"(bqv[3]), "+v"(bkv[0]), "+v"(bkv[1]), "+v"(bkv[2]), "+v"(bkv[3]));
+            if constexpr (TRAIN) asm volatile("" : "+v"(ltok[0]), "+v"(ltok[1]));
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -337,34 +435,114 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // cosine attention: k rows normalised, 1 / |q| folded into the per-query score factor
+        // ---- bf16 rounding of q^T, k^T, v: ONE packing serves the MFMA operands, the cosine norms and (training form) the stored rows;
+        // the fp32 accumulators are dead behind it.  Word i of a tile = registers 2i, 2i+1.
+        uint32_t qw[2][8], kw[2][8];
+        bf16x8 qf[2][2], kf[2][2], vf[2][2];  // [token tile][8-register step]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                qw[t][i] = pack_bf16x2(aq[t][2 * i], aq[t][2 * i + 1]);
+                kw[t][i] = pack_bf16x2(ak[t][2 * i], ak[t][2 * i + 1]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) vf[t][c] = pack8(av[t], 8 * c);
+        }
+        if constexpr (TRAIN) {  // the q and k rows as the Linear would have stored them: 64-byte head slices, two 16-byte pieces per lane
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint16_t* dst = p.qkv_out + (int64_t)ltok[t] * (3 * C) + 32 * wave + 8 * half;
+                u32x4 p0, p1;
+                swap_rows_t(qw[t], p0, p1);
+                *(u32x4*)dst = p0;
+                *(u32x4*)(dst + 16) = p1;
+                swap_rows_t(kw[t], p0, p1);
+                *(u32x4*)(dst + C) = p0;
+                *(u32x4*)(dst + C + 16) = p1;
+            }
+        }
+        // cosine attention: k rows normalised, 1 / |q| folded into the per-query score factor.  The norms are those of the bf16
+        // rows (what hs_window_attn_fwd / _bwd see in the stored qkv tensor), so that the saved log-sum-exp matches the scores
+        // the backward recomputes
         float qinv[2] = {1.f, 1.f};
         if constexpr (COS) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float sq = 0.f, sk = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sq = fmaf(aq[t][r], aq[t][r], sq);
-                    sk = fmaf(ak[t][r], ak[t][r], sk);
+                for (int i = 0; i < 8; ++i) {
+                    const float q0 = __uint_as_float(qw[t][i] << 16), q1 = __uint_as_float(qw[t][i] & 0xffff0000u);
+                    const float k0 = __uint_as_float(kw[t][i] << 16), k1 = __uint_as_float(kw[t][i] & 0xffff0000u);
+                    sq = fmaf(q0, q0, fmaf(q1, q1, sq));
+                    sk = fmaf(k0, k0, fmaf(k1, k1, sk));
                 }
                 sq += __shfl_xor(sq, 32, 64);
                 sk += __shfl_xor(sk, 32, 64);
                 qinv[t] = 1.f / fmaxf(sqrtf(sq), kNormEps);
                 const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ak[t][r] *= kinv;
+                for (int i = 0; i < 8; ++i)
+                    kw[t][i] = pack_bf16x2(__uint_as_float(kw[t][i] << 16) * kinv, __uint_as_float(kw[t][i] & 0xffff0000u) * kinv);
             }
         }
-        bf16x8 qf[2][2], kf[2][2], vf[2][2];  // [token tile][8-register step]
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                qf[t][c] = pack8(aq[t], 8 * c);
-                kf[t][c] = pack8(ak[t], 8 * c);
-                vf[t][c] = pack8(av[t], 8 * c);
+                qf[t][c] = __builtin_bit_cast(bf16x8, u32x4{qw[t][4 * c], qw[t][4 * c + 1], qw[t][4 * c + 2], qw[t][4 * c + 3]});
+                kf[t][c] = __builtin_bit_cast(bf16x8, u32x4{kw[t][4 * c], kw[t][4 * c + 1], kw[t][4 * c + 2], kw[t][4 * c + 3]});
             }
+
+        if constexpr (TRAIN) {
+            // v a second time as v^T (lane = token like q^T and k^T) for the row-major qkv rows the backward reads: 16 MFMAs in a pass of
+            // their own, behind the packing of q / k / v (the fp32 accumulators of the main pass are dead: a seventh and eighth
+            // accumulator inside it spilled 80 registers), cheaper than a transposing pass through LDS with two more barriers
+            f32x16 avt[2];
+            {
+                u32x4 bvv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bvv[g] = ld128(pbase + (P_BV + 32 * wave + 8 * g + 4 * half) * 4);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bvv[0]), "+v"(bvv[1]), "+v"(bvv[2]), "+v"(bvv[3]));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) avt[t][r] = __uint_as_float(bvv[r >> 2][r & 3]);
+            }
+            const uint32_t xa0 = xbase + l31 * kRowB, xa1 = xbase + (32 + l31) * kRowB;
+            const uint32_t wv = wbase + (2 * C + 32 * wave + l31) * kRowB;
+            const int sx = l31 & 15;
+            u32x4 fx[2][2], fw[2];
+            auto reads = [&](int ks, int set) {
+                const uint32_t co = (uint32_t)(((2 * ks + half) ^ sx) << 4);
+                fx[set][0] = ld128(xa0 + co);
+                fx[set][1] = ld128(xa1 + co);
+                fw[set] = ld128(wv + co);
+            };
+            reads(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int set = ks & 1;
+                if (ks + 1 < KS) {
+                    reads(ks + 1, set ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fx[set][0]), "+v"(fx[set][1]), "+v"(fw[set]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[set][0]), "+v"(fx[set][1]), "+v"(fw[set]));
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    avt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fw[set]), as_frag(fx[set][t]), avt[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint16_t* dst = p.qkv_out + (int64_t)ltok[t] * (3 * C) + 2 * C + 32 * wave + 8 * half;
+                u32x4 p0, p1;
+                pack_rows_t(avt[t], p0, p1);
+                *(u32x4*)dst = p0;
+                *(u32x4*)(dst + 16) = p1;
+            }
+        }
 
         // ------------------------------------------------------------ S^T = k q^T, softmax over keys (log2 domain)
         f32x16 acc[2][2];
@@ -394,6 +572,8 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                     m = fmaxf(m, t);
                 }
             if (mixed) {  // rare: windows cut by the shift boundary
+                uint32_t labw[16];
+                read_labels(labw);
                 uint32_t mine = 0;  // the word holding this lane's query label: index qt * 8 + l31 / 4 is lane-dependent
 #pragma unroll
                 for (int i = 0; i < 8; ++i) mine = (l31 >> 2) == i ? labw[qt * 8 + i] : mine;
@@ -428,6 +608,13 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv;
+            if constexpr (TRAIN) {
+                if (half == 0) {
+                    const int b = (int)(wi / nW);
+                    const int64_t j0 = (wi - (int64_t)b * nW) * kWs;
+                    p.lse_out[((int64_t)b * NH + wave) * N + j0 + qt * 32 + l31] = (m + __builtin_amdgcn_logf(l)) * kLn2;
+                }
+            }
         }
 
         // ------------------------------------------------------------ O^T = v^T P^T  (rows = features, columns = queries)
@@ -454,6 +641,19 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // O tile complete; every wave is done with the x tile
+        if constexpr (TRAIN) store_rows(obase, p.o_out);
+        // the residual operand (x rows of this wave's output pieces; L2 hits) is requested here, under the proj product
+        // (unconditional, straight-line loads -- pieces that do not exist read row 0 -- pinned here by the scheduling barrier:
+        // under per-piece conditions the compiler moved them back down to their use)
+        u32x4v xres[XP];
+        if (residual) {
+#pragma unroll
+            for (int j = 0; j < XP; ++j) {
+                const bool ok = wave + NH * j < 16 && pchunk_of(j) < NCH;
+                xres[j] = __builtin_nontemporal_load((const u32x4v*)(p.x + (ok ? (int64_t)tok[j] * C + pchunk_of(j) * 8 : (int64_t)0)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         // ------------------------------------------------------------ Y^T = Wp O^T for this wave's 32 output channels
         f32x16 ay[2];
@@ -503,6 +703,8 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
 
         // ------------------------------------------------------------ whole token rows -> out[token] (the scatter half of the shift)
         {
+            // the NEXT window's x rows (requested a window ago) have landed, and with them everything this window has stored so far
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             u32x4 rows[XP];
 #pragma unroll
             for (int j = 0; j < XP; ++j)
@@ -510,11 +712,11 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
 #pragma unroll
             for (int j = 0; j < XP; ++j) {
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(rows[j]) : "n"(XP - 1 - j));
-                if (wave + NH * j < 16 && pchunk[j] < NCH) {
-                    const int64_t e = tok[j] * C + pchunk[j] * 8;
+                if (wave + NH * j < 16 && pchunk_of(j) < NCH) {
+                    const int64_t e = (int64_t)tok[j] * C + pchunk_of(j) * 8;
                     u32x4 v = rows[j];
                     if (residual) {
-                        const u32x4v xr = __builtin_nontemporal_load((const u32x4v*)(p.x + e));
+                        const u32x4v xr = xres[j];
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             v[i] = pack_bf16x2(__uint_as_float(v[i] << 16) + __uint_as_float(xr[i] << 16),
@@ -537,10 +739,16 @@ int launch_module(const ModParams& p0, bool cosine, hipStream_t stream) {
     const int64_t windows = (int64_t)p.B * (p.N / kWs);
     const int cus = usable_cus();
     p.slots = (int)(windows < cus ? windows : cus);  // one persistent workgroup per CU (144 KB of LDS each)
-    if (cosine)
-        hipLaunchKernelGGL((attn_module_fwd_kernel<NH, true>), dim3(p.slots), dim3(NH * 64), 0, stream, p);
-    else
-        hipLaunchKernelGGL((attn_module_fwd_kernel<NH, false>), dim3(p.slots), dim3(NH * 64), 0, stream, p);
+    const bool train = p.qkv_out != nullptr;
+#define HS_MOD_LAUNCH(COS, TRAIN) hipLaunchKernelGGL((attn_module_fwd_kernel<NH, COS, TRAIN>), dim3(p.slots), dim3(NH * 64), 0, stream, p)
+    if (cosine) {
+        if (train) HS_MOD_LAUNCH(true, true);
+        else HS_MOD_LAUNCH(true, false);
+    } else {
+        if (train) HS_MOD_LAUNCH(false, true);
+        else HS_MOD_LAUNCH(false, false);
+    }
+#undef HS_MOD_LAUNCH
     HS_LAUNCH_CHECK("attn_module_fwd");
     return HS_OK;
 }
@@ -554,37 +762,73 @@ int hs_window_attn_module_supported(int channels, int num_heads, int window_size
     return dtype == HS_BF16 && window_size == hs::kWs && num_heads * 32 == channels && (channels == 96 || channels == 128);
 }
 
-int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
-                              const float* ln_gamma, const float* ln_beta, const float* bias, const float* head_scale,
-                              const int32_t* idx, int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens, int channels,
-                              int num_heads, int window_size, unsigned flags, int dtype, void* stream) {
+namespace {
+struct TrainOut {
+    void *xn = nullptr, *qkv = nullptr, *o = nullptr;
+    float *mean = nullptr, *rstd = nullptr, *lse = nullptr;
+};
+int module_fwd_impl(const char* who, const void* x, void* out, const TrainOut& tr, const void* qkv_w, const float* qkv_b, const void* proj_w,
+                    const float* proj_b, const float* ln_gamma, const float* ln_beta, const float* bias, const float* head_scale,
+                    const int32_t* idx, int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens, int channels, int num_heads,
+                    int window_size, unsigned flags, int dtype, void* stream) {
     using namespace hs;
-    HS_CHECK_ARG(x && out && qkv_w && proj_w && head_scale, "hs_window_attn_module_fwd: null pointer");
-    HS_CHECK_ARG(batch > 0 && n_tokens > 0 && n_tokens % kWs == 0, "hs_window_attn_module_fwd: n_tokens must be a positive multiple of 64");
-    HS_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "hs_window_attn_module_fwd: ln_gamma and ln_beta go together");
-    HS_CHECK_ARG(roll >= 0 && roll < n_tokens, "hs_window_attn_module_fwd: roll must be in [0, n_tokens)");
+    HS_CHECK_ARG(x && out && qkv_w && proj_w && head_scale, "%s: null pointer", who);
+    HS_CHECK_ARG(batch > 0 && n_tokens > 0 && n_tokens % kWs == 0, "%s: n_tokens must be a positive multiple of 64", who);
+    HS_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "%s: ln_gamma and ln_beta go together", who);
+    HS_CHECK_ARG(roll >= 0 && roll < n_tokens, "%s: roll must be in [0, n_tokens)", who);
     if (!hs_window_attn_module_supported(channels, num_heads, window_size, dtype))
-        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_fwd: bf16, window 64, head_dim 32 and C = 96 or 128 only (got C = %d, "
-                    "heads %d, window %d): the qkv weights must fit the LDS", channels, num_heads, window_size);
+        return fail(HS_ERR_UNSUPPORTED, "%s: bf16, window 64, head_dim 32 and C = 96 or 128 only (got C = %d, heads %d, window %d): "
+                    "the qkv weights must fit the LDS", who, channels, num_heads, window_size);
     // The x tiles are addressed through a buffer descriptor (32-bit byte offsets, < 2 GiB): larger activation tensors are
     // processed in batch chunks of whole images, one launch each (images are independent).
     const int64_t image_bytes = n_tokens * channels * 2;
-    if (image_bytes > 0x7FFFFE00ll)
-        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_fwd: one image beyond the 2 GiB buffer-offset range");
+    if (image_bytes > 0x7FFFFE00ll) return fail(HS_ERR_UNSUPPORTED, "%s: one image beyond the 2 GiB buffer-offset range", who);
     const int chunk = (int)std::min<int64_t>(batch, 0x7FFFFE00ll / image_bytes);
     const bool cosine = (flags & HS_ATTN_COSINE) != 0;
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         ModParams p{};
-        p.x = (const uint16_t*)x + (int64_t)b0 * n_tokens * channels;
-        p.out = (uint16_t*)out + (int64_t)b0 * n_tokens * channels;
+        const int64_t t0 = (int64_t)b0 * n_tokens;
+        p.x = (const uint16_t*)x + t0 * channels;
+        p.out = (uint16_t*)out + t0 * channels;
         p.qkv_w = (const uint16_t*)qkv_w; p.qkv_b = qkv_b;
         p.proj_w = (const uint16_t*)proj_w; p.proj_b = proj_b; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.bias = bias;
         p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = std::min(chunk, batch - b0);
         p.N = n_tokens; p.flags = flags;
+        if (tr.qkv) {
+            p.xn_out = (uint16_t*)tr.xn + t0 * channels;
+            p.qkv_out = (uint16_t*)tr.qkv + t0 * 3 * channels;
+            p.o_out = (uint16_t*)tr.o + t0 * channels;
+            p.mean_out = tr.mean + t0;
+            p.rstd_out = tr.rstd + t0;
+            p.lse_out = tr.lse + t0 * num_heads;
+        }
         const int rc = num_heads == 4 ? launch_module<4>(p, cosine, (hipStream_t)stream) : launch_module<3>(p, cosine, (hipStream_t)stream);
         if (rc != HS_OK) return rc;
     }
     return HS_OK;
+}
+}  // namespace
+
+int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
+                              const float* ln_gamma, const float* ln_beta, const float* bias, const float* head_scale,
+                              const int32_t* idx, int64_t roll, const uint8_t* labels, int batch, int64_t n_tokens, int channels,
+                              int num_heads, int window_size, unsigned flags, int dtype, void* stream) {
+    return module_fwd_impl("hs_window_attn_module_fwd", x, out, TrainOut{}, qkv_w, qkv_b, proj_w, proj_b, ln_gamma, ln_beta, bias,
+                           head_scale, idx, roll, labels, batch, n_tokens, channels, num_heads, window_size, flags, dtype, stream);
+}
+
+int hs_window_attn_module_fwd_train(const void* x, void* out, void* xn_out, float* mean_out, float* rstd_out, void* qkv_out,
+                                    void* attn_out, float* lse_out, const void* qkv_w, const float* qkv_b, const void* proj_w,
+                                    const float* proj_b, const float* ln_gamma, const float* ln_beta, const float* bias,
+                                    const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels, int batch,
+                                    int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
+                                    void* stream) {
+    HS_CHECK_ARG(xn_out && mean_out && rstd_out && qkv_out && attn_out && lse_out, "hs_window_attn_module_fwd_train: null output");
+    HS_CHECK_ARG(ln_gamma && ln_beta, "hs_window_attn_module_fwd_train: the training form starts at the block's norm1");
+    TrainOut tr;
+    tr.xn = xn_out; tr.qkv = qkv_out; tr.o = attn_out; tr.mean = mean_out; tr.rstd = rstd_out; tr.lse = lse_out;
+    return module_fwd_impl("hs_window_attn_module_fwd_train", x, out, tr, qkv_w, qkv_b, proj_w, proj_b, ln_gamma, ln_beta, bias,
+                           head_scale, idx, roll, labels, batch, n_tokens, channels, num_heads, window_size, flags, dtype, stream);
 }
 
 }  // extern "C"

@@ -207,6 +207,19 @@ class WindowAttention(nn.Module):
                                       ln_weight=None if norm is None else norm.weight, ln_bias=None if norm is None else norm.bias,
                                       residual=residual)
 
+    def trainable_fused(self, x, window_size):
+        """The one-launch TRAINING form applies (ops.window_attn_module_train_ok): gradients wanted, supported shape, nothing
+        stochastic inside the branch."""
+        return (ops.window_attn_module_train_ok(x, self.num_heads, window_size) and
+                not (self.training and (self.attn_drop.p > 0 or self.proj_drop.p > 0)) and
+                (self.rel_pos_bias is None or window_size == self.window_size))
+
+    def fused_module_train(self, x, window_size, idx, roll, labels, norm):
+        """x + proj(attention(qkv(norm(x)))) by `hs_window_attn_module_fwd_train`, differentiable (ops.window_attn_module_train)."""
+        return ops.window_attn_module_train(x, norm.weight, norm.bias, self.qkv.weight, self.qkv.bias, self.proj.weight,
+                                            self.proj.bias, self.bias(), self.head_scale(), idx, roll, labels, self.num_heads,
+                                            window_size, self.use_cos_attn)
+
     def forward(self, x, mask=None):
         """Reference-compatible entry: x [num_windows*B, Ws, C], mask [nW, Ws, Ws] in {0,-100} or None."""
         B_, Ws, C = x.shape
@@ -329,6 +342,15 @@ class SwinTransformerBlock(nn.Module):
             C = self.dim
             proj_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, C, x.dtype)
             fc2_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, self.mlp.fc1.weight.shape[0], x.dtype)
+            if pending is None and self.attn.trainable_fused(x, self.window_size):
+                # norm1 -> qkv -> attention -> proj -> residual add in ONE launch that also writes what the backward reads
+                idx, roll, labels = self._shift_args(x)
+                x1 = self.attn.fused_module_train(x, self.window_size, idx, roll, labels, self.norm1)
+                if fc2_own:
+                    n2, x1 = ops.layer_norm_passthrough(x1, self.norm2.weight, self.norm2.bias)
+                    return self.mlp(n2, apply_out_drop=False, residual=x1), None, None
+                n2, x1 = ops.layer_norm_passthrough(x1, self.norm2.weight, self.norm2.bias)
+                return x1, (self.mlp(n2, apply_out_drop=False), None, 0.0), None
             if proj_own or fc2_own:
                 if pending is None:
                     n1, xs = ops.layer_norm_passthrough(x, self.norm1.weight, self.norm1.bias)

@@ -115,7 +115,8 @@ class WindowAttnCoreFn(torch.autograd.Function):
     on the un-shifted qkv tensor (reference swin_hp_transformer.py:319-330 around :136-171)."""
 
     @staticmethod
-    def forward(ctx, qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, attn_drop=0.0, seed=0):
+    def forward(ctx, qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, attn_drop=0.0, seed=0, pre=None):
+        """pre = (out, lse): results the fused module kernel already wrote (window_attn_module_train); nothing is launched."""
         _require_gpu(qkv, bias, head_scale, idx, labels)
         B, N, C3 = qkv.shape
         C = C3 // 3
@@ -124,16 +125,19 @@ class WindowAttnCoreFn(torch.autograd.Function):
         hs = _f32(head_scale).reshape(-1)
         assert hs.numel() == num_heads
         bias_c = _f32(bias)
-        out = torch.empty((B, N, C), dtype=qkv.dtype, device=qkv.device)
-        need_grad = any(ctx.needs_input_grad[:3])
-        lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=qkv.device) if need_grad else None
         flags = (_lib.HS_ATTN_COSINE if cosine else 0) | (_lib.HS_ATTN_FORCE_VALU if FORCE_VALU_ATTENTION else 0)
-        # algorithmic traffic: q,k,v read + o written once; flops: QK^T and PV, 2*Ws*hd each per (row, head)
-        with _timed("window_attn_fwd", qkv.device, 4 * B * N * C * qkv.element_size(), 4 * B * N * C * window_size):
-            check(lib.hs_window_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(bias_c), ptr(hs), ptr(idx), int(roll), ptr(labels),
-                                         B, N, C, num_heads, window_size, flags, float(attn_drop), int(seed), dt,
-                                         stream_ptr(qkv.device)),
-                  "hs_window_attn_fwd")
+        if pre is not None:
+            out, lse = pre
+        else:
+            out = torch.empty((B, N, C), dtype=qkv.dtype, device=qkv.device)
+            need_grad = any(ctx.needs_input_grad[:3])
+            lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=qkv.device) if need_grad else None
+            # algorithmic traffic: q,k,v read + o written once; flops: QK^T and PV, 2*Ws*hd each per (row, head)
+            with _timed("window_attn_fwd", qkv.device, 4 * B * N * C * qkv.element_size(), 4 * B * N * C * window_size):
+                check(lib.hs_window_attn_fwd(ptr(qkv), ptr(out), ptr(lse), ptr(bias_c), ptr(hs), ptr(idx), int(roll), ptr(labels),
+                                             B, N, C, num_heads, window_size, flags, float(attn_drop), int(seed), dt,
+                                             stream_ptr(qkv.device)),
+                      "hs_window_attn_fwd")
         ctx.save_for_backward(qkv, out, lse, bias_c, hs, idx, labels)
         ctx.args = (B, N, C, num_heads, window_size, flags, dt, int(roll))
         ctx.drop = (float(attn_drop), int(seed))
@@ -170,7 +174,7 @@ class WindowAttnCoreFn(torch.autograd.Function):
         dbias_out = None if dbias is None else dbias.to(ctx.bias_dtype)
         sdt, sshape = ctx.scale_meta
         dscale_out = dscale.to(sdt).reshape(sshape) if (flags & _lib.HS_ATTN_COSINE) else None
-        return dqkv, dbias_out, dscale_out, None, None, None, None, None, None, None, None
+        return dqkv, dbias_out, dscale_out, None, None, None, None, None, None, None, None, None
 
 
 def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, attn_drop=0.0, seed=None):
@@ -222,6 +226,47 @@ def window_attn_module(x, qkv_w, qkv_b, proj_w, proj_b, bias, head_scale, idx, r
     return out
 
 
+# The TRAINING form of the module kernel (`hs_window_attn_module_fwd_train`): x + proj(attention(qkv(LayerNorm(x)))) in one launch that
+# also writes what the backward reads.  HS_FUSED_ATTN_TRAIN=0 keeps the four-kernel composition (A/B runs).
+FUSED_ATTN_MODULE_TRAIN = os.environ.get("HS_FUSED_ATTN_TRAIN", "1") != "0"
+
+
+def window_attn_module_train_ok(x, num_heads, window_size):
+    return (FUSED_ATTN_MODULE_TRAIN and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and
+            not FORCE_VALU_ATTENTION and bool(lib.hs_window_attn_module_supported(x.shape[-1], num_heads, window_size, _lib.HS_BF16)))
+
+
+def window_attn_module_train(x, ln_weight, ln_bias, qkv_w, qkv_b, proj_w, proj_b, bias, head_scale, idx, roll, labels, num_heads,
+                             window_size, cosine):
+    """x + proj(window_attention(qkv(LayerNorm(x)))) for a block on the training path (reference :315-316 around :124-174).  ONE
+    kernel computes it and writes LayerNorm(x) with its statistics, qkv, the attention output and the log-sum-exp rows; the four
+    autograd nodes of the composed path (LayerNormFn, LinearFn, WindowAttnCoreFn, LinearFn with the residual) are then recorded
+    around those tensors WITHOUT launching anything (`pre=`), so the backward is exactly the composed path's."""
+    _require_gpu(x, qkv_w, proj_w, bias, head_scale, idx, labels)
+    B, N, C = x.shape
+    x = x.contiguous()
+    dev = x.device
+    out, xn, o = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    qkv = torch.empty((B, N, 3 * C), dtype=x.dtype, device=dev)
+    mean = torch.empty(B * N, dtype=torch.float32, device=dev)
+    rstd = torch.empty(B * N, dtype=torch.float32, device=dev)
+    lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=dev)
+    wq, wp = _cast_param(qkv_w, torch.bfloat16).contiguous(), _cast_param(proj_w, torch.bfloat16).contiguous()
+    hs = _f32(head_scale).reshape(-1)
+    flags = (_lib.HS_ATTN_COSINE if cosine else 0) | _lib.HS_ATTN_RESIDUAL
+    # algorithmic traffic: x in (+ again for the residual), out + LayerNorm(x) + qkv + attention output written; flops as the module
+    with _timed("window_attn_module_fwd_train", dev, 9 * B * N * C * 2, B * N * (8 * C * C + 4 * window_size * C)):
+        check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(out), ptr(xn), ptr(mean), ptr(rstd), ptr(qkv), ptr(o), ptr(lse), ptr(wq),
+                                                  ptr(_f32(qkv_b)), ptr(wp), ptr(_f32(proj_b)), ptr(_f32(ln_weight)), ptr(_f32(ln_bias)),
+                                                  ptr(_f32(bias)), ptr(hs), ptr(idx), int(roll), ptr(labels), B, N, C, num_heads,
+                                                  window_size, flags, _lib.HS_BF16, stream_ptr(dev)),
+              "hs_window_attn_module_fwd_train")
+    n1, xs = LayerNormFn.apply(x, ln_weight, ln_bias, None, None, True, None, False, (xn, mean, rstd))
+    qkv_t = LinearFn.apply(n1, qkv_w, qkv_b, False, None, (qkv,))
+    o_t = WindowAttnCoreFn.apply(qkv_t, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, 0.0, 0, (o, lse))
+    return LinearFn.apply(o_t, proj_w, proj_b, False, xs, (out,))
+
+
 # ----------------------------------------------------------------------------- row LayerNorm (+ residual, + train-mode extras)
 def _extras(x, row_scale, drop_p, seed):
     """(row_scale fp32 or None, rows_per_sample, drop_p, seed) for the *_drop_* kernels; None if nothing stochastic is on."""
@@ -269,8 +314,9 @@ class LayerNormFn(torch.autograd.Function):
     optional per-sample DropPath factor and dropout mask (train mode), absent in eval."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, extras, passthrough=False, res_lo=None, want_lo=False):
-        """res_lo / want_lo: compensated residual stream of the v2 placement (y = residual + LN(x) IS the stream): the stream
+    def forward(ctx, x, weight, bias, residual, extras, passthrough=False, res_lo=None, want_lo=False, pre=None):
+        """pre = (y, mean, rstd): results the fused module kernel already wrote (window_attn_module_train); nothing is launched.
+        res_lo / want_lo: compensated residual stream of the v2 placement (y = residual + LN(x) IS the stream): the stream
         operand is residual + res_lo, and with want_lo the call returns (y, y_lo) with y_lo the rounding remainder of y."""
         _require_gpu(x, weight, bias, residual)
         # an output nobody differentiates (the alias, or the non-differentiable y_lo) reaches backward as None instead of a
@@ -284,12 +330,16 @@ class LayerNormFn(torch.autograd.Function):
         res = None if residual is None else residual.contiguous()
         if res is not None:
             assert res.shape == x.shape and res.dtype == x.dtype
-        y = torch.empty_like(x)
-        need_grad = any(ctx.needs_input_grad[:3])
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
-        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
         y_lo = None
-        if want_lo or res_lo is not None:
+        if pre is None:
+            y = torch.empty_like(x)
+            need_grad = any(ctx.needs_input_grad[:3])
+            mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+            rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        if pre is not None:
+            assert res is None and extras is None and not want_lo and res_lo is None
+            y, mean, rstd = pre
+        elif want_lo or res_lo is not None:
             assert not passthrough and (res is not None or res_lo is None)
             y_lo = torch.empty_like(x) if want_lo else None
             rs, rps, p, seed = extras if extras is not None else (None, 1, 0.0, 0)
@@ -323,7 +373,7 @@ class LayerNormFn(torch.autograd.Function):
         if not ctx.second_is_alias:
             dx_alias = None
         if dy is None:  # only the alias was used downstream
-            return dx_alias, None, None, None, None, None, None, None
+            return dx_alias, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma, dbeta, direct = _norm_param_grads(weight, bias, width, x.device, ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
@@ -341,7 +391,7 @@ class LayerNormFn(torch.autograd.Function):
                                             ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
                   "hs_layernorm_drop_bwd")
         dw, db = _norm_param_result(weight, bias, dgamma, dbeta, direct)
-        return dx, dw, db, (dy if has_res else None), None, None, None, None
+        return dx, dw, db, (dy if has_res else None), None, None, None, None, None
 
 
 def layer_norm(x, weight, bias, residual=None, row_scale=None, drop_p=0.0, seed=None):
@@ -847,7 +897,8 @@ class LinearFn(torch.autograd.Function):
     [f_out, C, 1]): it is used as the [n_out, k_in] matrix it is, so the PARAMETER itself (a leaf) receives the gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, passthrough=False, residual=None):
+    def forward(ctx, x, weight, bias, passthrough=False, residual=None, pre=None):
+        """pre = (y,): the product the fused module kernel already wrote (window_attn_module_train); nothing is launched."""
         _require_gpu(x, weight, bias, residual)
         n_out = weight.shape[0]
         k_in = weight.numel() // n_out
@@ -858,6 +909,9 @@ class LinearFn(torch.autograd.Function):
         ctx.cast_cache = CAST_CACHE
         ctx.passthrough = passthrough
         ctx.has_residual = residual is not None
+        if pre is not None:
+            assert not passthrough
+            return pre[0]
         if residual is not None:
             # y = x W^T + b + residual: the add rides on the product's epilogue (one rounding); its gradient is dy itself
             assert not passthrough
@@ -908,7 +962,7 @@ class LinearFn(torch.autograd.Function):
         n_out = weight.shape[0]
         k_in = weight.numel() // n_out
         if dy is None:  # only the passthrough alias was used downstream
-            return dx_res, None, None, None, None
+            return dx_res, None, None, None, None, None
         dy2 = dy.reshape(-1, n_out)
         x2 = x.reshape(-1, k_in)
         if not dy2.is_contiguous():
@@ -918,7 +972,7 @@ class LinearFn(torch.autograd.Function):
             dx = _input_grad(dy2, weight, ctx.w_cast, None if dx_res is None else dx_res.reshape(-1, k_in), ctx.cast_cache).reshape(x.shape)
         ctx.w_cast = ctx.cast_cache = None
         dw, db = _param_grads(dy2, x2, weight, bias, ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2])
-        return dx, dw, db, None, (dy if ctx.has_residual else None)
+        return dx, dw, db, None, (dy if ctx.has_residual else None), None
 
 
 def _input_grad(dy2, weight, w_cast, dx_res2=None, cache=None):

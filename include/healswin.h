@@ -60,7 +60,7 @@ int hs_transpose_many_16(const void* jobs, int count, int blocks_per_job, void* 
  * Lightning DDP, train.py:182-189) runs RCCL's all-reduce kernels on their own stream DURING the backward; a kernel whose grid
  * is sized to fill every CU for its whole duration either delays them to its end or, if they were resident first, runs its
  * last workgroups as a second round.  heal_swin_amd.parallel.GradBucketAllReduce sets this when world_size > 1.
- * Affects hs_linear_wgrad (+ _workspace), hs_gemm_nt, hs_window_attn_* (+ _workspace), hs_window_attn_module_fwd. */
+ * Affects hs_linear_wgrad (+ _workspace), hs_gemm_nt, hs_window_attn_* (+ _workspace), hs_window_attn_module_fwd(_train). */
 int hs_set_reserved_cus(int n);
 int hs_get_reserved_cus(void);
 /* Diagnostic: `n_workgroups` workgroups of `threads` threads and `lds_bytes` of LDS each that stay resident for `microseconds`
@@ -327,6 +327,25 @@ int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const
                               const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels, int batch,
                               int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
                               void* stream);
+
+/* TRAINING form of the module forward (reference :315-316 around :124-174): the same single launch,
+ *     out = x + proj( attention( qkv( LayerNorm(x) ) ) )            (flags: HS_ATTN_RESIDUAL as above; LayerNorm required)
+ * which ALSO writes, in natural token order, everything the backward of the four reference modules reads -- so that
+ * hs_add_layernorm_bwd (norm1), hs_linear_wgrad + hs_gemm_nt (qkv, proj) and hs_window_attn_bwd run on them unchanged:
+ *   xn_out   [dev] bf16 [batch, n_tokens, channels]      LayerNorm(x): the qkv Linear's input
+ *   mean_out, rstd_out [dev] f32 [batch * n_tokens]      the LayerNorm row statistics (as hs_layernorm_fwd)
+ *   qkv_out  [dev] bf16 [batch, n_tokens, 3 * channels]  the qkv Linear's output (as hs_gemm_nt would have rounded it)
+ *   attn_out [dev] bf16 [batch, n_tokens, channels]      hs_window_attn_fwd's `out`: the proj Linear's input
+ *   lse_out  [dev] f32 [batch, num_heads, n_tokens]      hs_window_attn_fwd's `lse` (by shifted position)
+ * HBM traffic per token: x in, out written, 5 C saved = 7 C * 2 B (+ 8 + 4 nH bytes of statistics) against 13 C * 2 B for
+ * hs_layernorm_fwd -> hs_gemm_nt -> hs_window_attn_fwd -> hs_gemm_nt(HS_EPI_RESID), none of the saved tensors re-read in the forward.
+ * Same support set and argument meaning as hs_window_attn_module_fwd. */
+int hs_window_attn_module_fwd_train(const void* x, void* out, void* xn_out, float* mean_out, float* rstd_out, void* qkv_out,
+                                    void* attn_out, float* lse_out, const void* qkv_w, const float* qkv_b, const void* proj_w,
+                                    const float* proj_b, const float* ln_gamma, const float* ln_beta, const float* bias,
+                                    const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels, int batch,
+                                    int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Forward and input-gradient product of the path's Linear layers with the elementwise step behind it fused into the

@@ -136,3 +136,187 @@ def test_module_kernel_batches_beyond_the_2gib_descriptor_range():
         for b in (0, 41, 42, 43):  # images on both sides of the chunk boundary (42 images fit the descriptor)
             yb = ops.window_attn_module(x[b:b + 1], qkv_w, qkv_b, proj_w, proj_b, bias, hs, None, 32, None, nH, 64, False)
             assert torch.equal(y[b:b + 1], yb), b
+
+
+# ----------------------------------------------------------------------------- training form (hs_window_attn_module_fwd_train)
+TRAIN_CASES = [
+    # C, nH, B, nside, strategy, shift, cosine, bias, qkv_bias
+    (128, 4, 2, 16, "none", 0, False, True, True),
+    (128, 4, 2, 16, "nest_roll", 32, False, True, True),
+    (128, 4, 1, 16, "ring_shift", 4, True, True, True),
+    (128, 4, 1, 16, "nest_grid_shift", 32, True, False, False),
+    (96, 3, 2, 16, "nest_roll", 32, False, True, True),
+    (96, 3, 1, 16, "ring_shift", 4, True, True, True),
+    (96, 3, 1, 8, "nest_grid_shift", 32, False, False, False),
+]
+
+
+@pytest.mark.parametrize("C,nH,B,nside,strategy,shift,cosine,use_bias,qkv_bias", TRAIN_CASES)
+def test_module_train_form_vs_oracle_and_composition(C, nH, B, nside, strategy, shift, cosine, use_bias, qkv_bias):
+    """out = x + proj(attention(qkv(LayerNorm(x)))) by ONE launch that also saves LayerNorm(x), its statistics, qkv, the attention
+    output and the log-sum-exp rows; the backward is the composed path's on those tensors.  Output and EVERY gradient (x, norm
+    weight / bias, qkv and proj weight / bias, bias table, head scale) against the oracle's autograd on bf16-rounded inputs, and
+    the saved tensors + gradients against the four-kernel composition (same rounding points: much tighter)."""
+    from heal_swin_amd import ops
+    from oracle import tables as T
+    N = 8 * nside * nside
+    g = torch.Generator().manual_seed(C + nside + shift + 17)
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x = bf(torch.randn(B, N, C, generator=g) * 3.0 + 0.5)
+    P = dict(wqkv=bf(torch.randn(3 * C, C, generator=g) * C ** -0.5), wp=bf(torch.randn(C, C, generator=g) * C ** -0.5),
+             bp=torch.randn(C, generator=g) * 0.2, lng=torch.rand(C, generator=g) + 0.5, lnb=torch.randn(C, generator=g) * 0.2,
+             hscale=torch.rand(nH, generator=g) * (8 if cosine else 0.3) + 0.1)
+    if qkv_bias:
+        P["bqkv"] = torch.randn(3 * C, generator=g) * 0.2
+    if use_bias:
+        P["bias"] = torch.randn(nH, 64, 64, generator=g)
+    dout = bf(torch.randn(B, N, C, generator=g))
+    if strategy == "none":
+        idx = labels = None
+    else:
+        fn = {"nest_roll": lambda: T.nest_roll_shift(N, 64, shift), "nest_grid_shift": lambda: T.nest_grid_shift(nside, 8, 64),
+              "ring_shift": lambda: T.ring_shift(nside, 8, 64, shift)}[strategy]
+        idx_np, _, lab_np = fn()
+        idx, labels = torch.from_numpy(idx_np), torch.from_numpy(lab_np)
+
+    # ---- oracle (CPU fp32 autograd on the oracle's formulas)
+    xr = x.clone().requires_grad_(True)
+    R = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = _reference(xr, R["wqkv"], R.get("bqkv"), R["wp"], R["bp"], R.get("bias"), R["hscale"], idx, labels, nH, cosine,
+                     (R["lng"], R["lnb"]), True)
+    ref.backward(dout)
+
+    use_roll = strategy == "nest_roll"
+    idx_d = None if (use_roll or idx is None) else idx.to(torch.int32).to(DEV)
+    lab_d = None if labels is None else labels.to(torch.uint8).to(DEV)
+    roll = shift if use_roll else 0
+
+    def run(fused):
+        xd = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        D = {k: v.to(DEV).clone().requires_grad_(True) for k, v in P.items()}
+        saved = {}
+        if fused:
+            assert ops.window_attn_module_train_ok(xd, nH, 64)
+            real = ops.lib.hs_window_attn_module_fwd_train
+            out = ops.window_attn_module_train(xd, D["lng"], D["lnb"], D["wqkv"], D.get("bqkv"), D["wp"], D["bp"], D.get("bias"),
+                                               D["hscale"], idx_d, roll, lab_d, nH, 64, cosine)
+            assert real is ops.lib.hs_window_attn_module_fwd_train
+            # the recorded graph: proj LinearFn <- WindowAttnCoreFn <- qkv LinearFn <- LayerNormFn, saved tensors from the kernel
+            node = out.grad_fn
+            saved["o"] = node.saved_tensors[0]
+        else:
+            n1, xs = ops.layer_norm_passthrough(xd, D["lng"], D["lnb"])
+            qkv = ops.linear(n1, D["wqkv"], D.get("bqkv"))
+            o = ops.window_attn_core(qkv, D.get("bias"), D["hscale"], idx_d, roll, lab_d, nH, 64, cosine)
+            out = ops.linear_residual(o, D["wp"], D["bp"], xs)
+            saved.update(xn=n1.detach(), qkv=qkv.detach(), o=o.detach())
+        out.backward(dout.to(DEV).to(torch.bfloat16))
+        return out.detach(), xd.grad, {k: v.grad for k, v in D.items()}, saved
+
+    out_f, dx_f, G_f, S_f = run(True)
+    out_c, dx_c, G_c, S_c = run(False)
+    # vs the oracle: bf16 intermediates inside the kernel
+    assert_close(out_f, ref, 1.5e-2, "train-form out vs oracle")
+    assert_close(dx_f, xr.grad, 4e-2, "train-form dx vs oracle")
+    for k in P:
+        if k == "hscale" and not cosine:
+            continue
+        tol = 8e-2 if k in ("bias", "hscale") else 4e-2  # (the table / scale gradients: the noisy families of tests/test_gpu_model.py)
+        assert_close(G_f[k], R[k].grad, tol, f"train-form d{k} vs oracle")
+    # vs the composition: same formulas, same rounding points, different summation order in the two products
+    assert_close(out_f, out_c, 1e-2, "train-form out vs composition")
+    assert_close(S_f["o"], S_c["o"], 1e-2, "saved attention output vs composition")
+    assert_close(dx_f, dx_c, 2e-2, "train-form dx vs composition")
+    for k in P:
+        if k == "hscale" and not cosine:
+            continue
+        assert_close(G_f[k], G_c[k], 3e-2, f"train-form d{k} vs composition")
+
+
+def test_module_train_form_saved_tensors_equal_the_separate_kernels():
+    """C ABI: xn / mean / rstd are those of hs_layernorm_fwd bit for bit (same arithmetic per row), qkv and the attention output
+    those of hs_gemm_nt / hs_window_attn_fwd on them to bf16 rounding, lse to fp32 rounding of the same scores."""
+    from heal_swin_amd import ops, _lib
+    from heal_swin_amd._lib import check, lib, ptr
+    B, N, C, nH = 2, 8 * 16 * 16, 128, 4
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.randn(B, N, C, generator=g, device=DEV) * 2 + 0.3).to(torch.bfloat16)
+    wq = (torch.randn(3 * C, C, generator=g, device=DEV) * C ** -0.5).to(torch.bfloat16)
+    wp = (torch.randn(C, C, generator=g, device=DEV) * C ** -0.5).to(torch.bfloat16)
+    bq, bp = torch.randn(3 * C, generator=g, device=DEV) * 0.2, torch.randn(C, generator=g, device=DEV) * 0.2
+    lg, lb = torch.rand(C, generator=g, device=DEV) + 0.5, torch.randn(C, generator=g, device=DEV) * 0.2
+    bias = torch.randn(nH, 64, 64, generator=g, device=DEV)
+    hs = torch.full((nH,), 32 ** -0.5, device=DEV)
+    out, xn, o = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    qkv = torch.empty(B, N, 3 * C, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(B * N, device=DEV), torch.empty(B * N, device=DEV)
+    lse = torch.empty(B, nH, N, device=DEV)
+    check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(out), ptr(xn), ptr(mean), ptr(rstd), ptr(qkv), ptr(o), ptr(lse), ptr(wq), ptr(bq),
+                                              ptr(wp), ptr(bp), ptr(lg), ptr(lb), ptr(bias), ptr(hs), None, 32, None, B, N, C, nH, 64,
+                                              _lib.HS_ATTN_RESIDUAL, _lib.HS_BF16, None), "train")
+    xn2, mean2, rstd2 = torch.empty_like(x), torch.empty_like(mean), torch.empty_like(rstd)
+    check(lib.hs_layernorm_fwd(ptr(x), None, ptr(lg), ptr(lb), ptr(xn2), ptr(mean2), ptr(rstd2), B * N, C, _lib.HS_BF16, None), "ln")
+    assert_close(mean, mean2, 1e-5, "mean")
+    assert_close(rstd, rstd2, 1e-5, "rstd")
+    assert_close(xn, xn2, 4e-3, "LayerNorm(x)")  # (one bf16 ulp where the two kernels' fp32 statistics differ in the last bit)
+    with torch.no_grad():
+        qkv2 = ops.gemm_nt(xn.reshape(-1, C), wq, bq)[0].view(B, N, 3 * C)
+        assert_close(qkv, qkv2, 4e-3, "qkv")
+        o2 = torch.empty_like(o)
+        lse2 = torch.empty_like(lse)
+        check(lib.hs_window_attn_fwd(ptr(qkv), ptr(o2), ptr(lse2), ptr(bias), ptr(hs), None, 32, None, B, N, C, nH, 64, 0, 0.0, 0,
+                                     _lib.HS_BF16, None), "core")
+        assert_close(o, o2, 4e-3, "attention output")
+        assert_close(lse, lse2, 1e-5, "lse")
+        out2 = ops.gemm_nt(o.reshape(-1, C), wp, bp, _lib.HS_EPI_RESID, aux=x.reshape(-1, C))[0].view(B, N, C)
+        assert_close(out, out2, 4e-3, "out")
+
+
+def test_model_training_step_uses_the_train_form_and_matches_the_composition():
+    """Stage-0 blocks of a bf16 model in autograd mode run hs_window_attn_module_fwd_train (4 calls: 2 encoder + 2 decoder
+    blocks); loss and every parameter gradient agree with the same model on the four-kernel composition."""
+    from heal_swin_amd import ops
+    from heal_swin_amd.data_spec import DataSpec
+    from heal_swin_amd.models_torch import swin_hp_transformer as M
+    cfg = dict(patch_size=4, window_size=64, shift_size=32, shift_strategy="nest_roll", rel_pos_bias="flat", embed_dim=128, depths=[2, 2],
+               num_heads=[4, 8], mlp_ratio=4.0, qkv_bias=True, qk_scale=None, use_cos_attn=False, drop_rate=0.0, attn_drop_rate=0.0,
+               drop_path_rate=0.0, use_v2_norm_placement=False, ape=False)
+    spec = dict(dim_in=12 * 32 * 32, f_in=3, f_out=12, base_pix=12, class_names=[])
+    torch.manual_seed(11)
+    model = M.SwinHPTransformerSys(M.SwinHPTransformerConfig(**cfg), DataSpec(**spec))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("relative_position_bias_table"):
+                p.normal_(0, 0.02)
+    model = model.to(DEV).train()
+    model.compute_dtype = torch.bfloat16
+    x = torch.randint(0, 256, (2, 3, spec["dim_in"])).float().to(DEV)
+    w = torch.randn(2, 12, spec["dim_in"], device=DEV)
+
+    def step(fused):
+        prev = ops.FUSED_ATTN_MODULE_TRAIN
+        ops.FUSED_ATTN_MODULE_TRAIN = fused
+        calls = []
+        real = ops.window_attn_module_train
+        ops.window_attn_module_train = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            model.zero_grad(set_to_none=True)
+            y = model(x)
+            (y.float() * w).mean().backward()
+        finally:
+            ops.window_attn_module_train = real
+            ops.FUSED_ATTN_MODULE_TRAIN = prev
+        return y.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, len(calls)
+
+    y_f, g_f, n_f = step(True)
+    y_c, g_c, n_c = step(False)
+    assert n_f == 4 and n_c == 0
+    assert_close(y_f, y_c, 1e-2, "logits, train form vs composition")
+    assert set(g_f) == set(g_c)
+    worst = 0.0
+    from _util import errors
+    for n in g_f:
+        e = errors(g_f[n], g_c[n])
+        worst = max(worst, e["scale_err"])
+        assert e["scale_err"] <= 6e-2, (n, e)
+    print(f"train form vs composition: worst parameter-gradient scale error {worst:.2e}")

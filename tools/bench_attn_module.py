@@ -52,9 +52,35 @@ def main():
             o = ops.window_attn_core(qkv, bias, hs, None, shift, labels, nH, 64, False)
             return ops.gemm_nt(o.view(-1, C), wp, bp)[0]
 
-        variants = {"fused module": fused, "fused module + LN + residual": lambda: fused(True, True)}
+        # training forms: what the block runs with gradients enabled (saves LayerNorm(x), qkv, the attention output, statistics)
+        B = args.batch
+        tr = dict(out=torch.empty_like(x), xn=torch.empty_like(x), o=torch.empty_like(x),
+                  qkv=torch.empty(B, N, 3 * C, dtype=torch.bfloat16, device=dev), mean=torch.empty(B * N, device=dev),
+                  rstd=torch.empty(B * N, device=dev), lse=torch.empty(B, nH, N, device=dev))
+
+        def fused_train():
+            from heal_swin_amd import _lib
+            from heal_swin_amd._lib import check, lib, ptr
+            check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(tr["out"]), ptr(tr["xn"]), ptr(tr["mean"]), ptr(tr["rstd"]), ptr(tr["qkv"]),
+                                                      ptr(tr["o"]), ptr(tr["lse"]), ptr(wqkv), ptr(bqkv), ptr(wp), ptr(bp), ptr(ln_g), ptr(ln_b),
+                                                      ptr(bias), ptr(hs), None, shift, ptr(labels), B, N, C, nH, 64, _lib.HS_ATTN_RESIDUAL,
+                                                      _lib.HS_BF16, None), "train")
+
+        def composed_train():
+            from heal_swin_amd import _lib
+            from heal_swin_amd._lib import check, lib, ptr
+            check(lib.hs_layernorm_fwd(ptr(x), None, ptr(ln_g), ptr(ln_b), ptr(tr["xn"]), ptr(tr["mean"]), ptr(tr["rstd"]), B * N, C,
+                                       _lib.HS_BF16, None), "ln")
+            qkv = ops.gemm_nt(tr["xn"].view(-1, C), wqkv, bqkv)[0].view(B, N, 3 * C)
+            check(lib.hs_window_attn_fwd(ptr(qkv), ptr(tr["o"]), ptr(tr["lse"]), ptr(bias), ptr(hs), None, shift, ptr(labels), B, N, C, nH, 64,
+                                         0, 0.0, 0, _lib.HS_BF16, None), "core")
+            return ops.gemm_nt(tr["o"].view(-1, C), wp, bp, _lib.HS_EPI_RESID, aux=x.view(-1, C))[0]
+
+        variants = {"fused module": fused, "fused module + LN + residual": lambda: fused(True, True),
+                    "TRAIN form: fused module + LN + residual, saves xn / qkv / O / statistics": fused_train}
         if not args.only_fused:
             variants["qkv GEMM + attn core + proj GEMM (hs_gemm_nt)"] = composed
+            variants["TRAIN composition: LN -> qkv GEMM -> attn core (+ lse) -> proj GEMM + residual"] = composed_train
         with torch.no_grad():
             for fn in variants.values():
                 fn()
@@ -70,10 +96,10 @@ def main():
                     times[k].append(e0.elapsed_time(e1) * 1e-3)
         for k in variants:
             t = statistics.median(times[k])
-            nbytes = (3 if "residual" in k else 2) * x.numel() * 2
+            nbytes = (9 if "TRAIN" in k else 3 if "residual" in k else 2) * x.numel() * 2  # (TRAIN: x in twice, out + 5 C saved)
             rec = {"case": name, "variant": k, "C": C, "tokens": N, "batch": args.batch, "us": t * 1e6, "module_TFLOPs": flops / t / 1e12,
                    "frac_of_2.5PF": flops / t / 2.5e15, "algorithmic_GBs": nbytes / t / 1e9}
-            print(f"{name} C={C}: {k:50s} {t * 1e6:8.1f} us  {rec['module_TFLOPs']:7.0f} TF/s ({rec['frac_of_2.5PF']:.3f} of 2.5 PF)  "
+            print(f"{name} C={C}: {k:82s} {t * 1e6:8.1f} us  {rec['module_TFLOPs']:7.0f} TF/s ({rec['frac_of_2.5PF']:.3f} of 2.5 PF)  "
                   f"{rec['algorithmic_GBs']:6.0f} GB/s", flush=True)
             out.append(rec)
     if args.json:
