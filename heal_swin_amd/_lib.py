@@ -79,6 +79,7 @@ _SIGNATURES = {
     "hs_set_reserved_cus": [c_int],
     "hs_transpose_many_16": [c_ptr, c_int, c_int, c_ptr],
     "hs_debug_occupy_cus": [c_int, c_int, c_int, ctypes.c_double, c_ptr],
+    "hs_debug_buffer_soffset_probe": [c_ptr, c_int, c_int, c_ptr, c_ptr],
     "hs_window_attn_module_supported": [c_int, c_int, c_int, c_int],
     "hs_window_attn_module_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_i64,
                                   c_int, c_int, c_int, c_uint, c_int, c_ptr],

@@ -22,10 +22,37 @@ __global__ void __launch_bounds__(512) occupy_kernel(int64_t ticks, unsigned* si
     if (acc == 0xffffffffu && sink) *sink = acc;
 }
 
+// The range-check rule the role-separated DMA of hs_gemm_nt (FAST) relies on: with a raw buffer descriptor the SCALAR offset of
+// buffer_load (... lds) takes part in the bounds check like the vector offset, so an operand row beyond num_records reads zeros
+// instead of memory behind the operand.  One wave: lane i loads a dword at voffset = 4 i with soffset = soff from a descriptor
+// over `bytes` bytes, once into registers and once by LDS-DMA.
+__global__ void __launch_bounds__(64) soffset_probe_kernel(const uint32_t* src, int bytes, int soff, uint32_t* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t patch[64];
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, bytes, 0x00020000);
+    const int lane = threadIdx.x;
+    out[lane] = __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, soff, 0);
+    patch[lane] = 0xdeadbeefu;
+    __syncthreads();
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)patch, 4, lane * 4, soff, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    out[64 + lane] = patch[lane];
+#endif
+}
+
 }  // namespace
 }  // namespace hs
 
 extern "C" {
+
+int hs_debug_buffer_soffset_probe(const void* src, int bytes, int soffset, void* out128, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(src && out128 && bytes >= 0 && soffset >= 0, "hs_debug_buffer_soffset_probe: bad argument");
+    hipLaunchKernelGGL(soffset_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)src, bytes, soffset, (uint32_t*)out128);
+    HS_LAUNCH_CHECK("soffset_probe_kernel");
+    return HS_OK;
+}
 
 int hs_debug_occupy_cus(int n_workgroups, int threads, int lds_bytes, double microseconds, void* stream) {
     using namespace hs;

@@ -66,6 +66,11 @@ int hs_get_reserved_cus(void);
 /* Diagnostic: `n_workgroups` workgroups of `threads` threads and `lds_bytes` of LDS each that stay resident for `microseconds`
  * on `stream` -- a stand-in for a communication library's long-lived ring kernels (tools/cu_contention.py). */
 int hs_debug_occupy_cus(int n_workgroups, int threads, int lds_bytes, double microseconds, void* stream);
+/* Diagnostic (tests): one wavefront loads dword i at vector offset 4 i + scalar offset `soffset` through a raw buffer descriptor
+ * over `bytes` bytes of src -- into registers (out128[0..63]) and by LDS-DMA (out128[64..127]).  Pins the hardware rule the
+ * role-separated operand DMA of hs_gemm_nt relies on: the scalar offset takes part in the range check (out-of-range dwords
+ * read 0), so edge tiles never fetch memory behind an operand. */
+int hs_debug_buffer_soffset_probe(const void* src, int bytes, int soffset, void* out128, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-side HEALPix index tables, built once per model on the host (plain C++, no GPU needed).

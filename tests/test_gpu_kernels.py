@@ -790,3 +790,18 @@ def test_batched_weight_transposes_follow_the_parameters():
         with torch.no_grad():
             for p in params:
                 p.add_(0.37 * (step + 1))  # an optimizer step (fused ones do not bump versions: hence force=True above)
+
+
+def test_buffer_scalar_offset_takes_part_in_the_range_check():
+    """the role-separated DMA of hs_gemm_nt puts the k offset and the 32-row group of an operand piece into the
+    SCALAR offset of buffer_load ... lds and relies on the descriptor's range check covering it (rows past an operand's end must
+    read zeros, not the bytes behind the allocation).  Pinned on the hardware: a 256-byte descriptor inside a buffer of ones."""
+    from heal_swin_amd._lib import check, lib, ptr
+    src = torch.full((1024,), 0x3f800000, dtype=torch.int32, device=DEV)  # ones behind the descriptor's end as well
+    out = torch.empty(128, dtype=torch.int32, device=DEV)
+    for soff, n_valid in ((0, 64), (128, 32), (252, 1), (256, 0), (4096, 0)):
+        check(lib.hs_debug_buffer_soffset_probe(ptr(src), 256, soff, ptr(out), None), "probe")
+        got = out.cpu().numpy()
+        want = np.where(np.arange(64) < n_valid, 0x3f800000, 0)
+        assert (got[:64] == want).all(), ("register load", soff, got[:64])
+        assert (got[64:] == want).all(), ("LDS-DMA load", soff, got[64:])
