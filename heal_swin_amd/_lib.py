@@ -56,6 +56,7 @@ _SIGNATURES = {
     "hs_residual_drop": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     "hs_split_bf16x3": [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
+    "hs_gelu_split3": [c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.c_float, ctypes.c_uint64, c_ptr],
     "hs_linear_wgrad_ld": [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_layernorm_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
     "hs_add_layernorm_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],

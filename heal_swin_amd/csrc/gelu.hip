@@ -114,6 +114,44 @@ __global__ void __launch_bounds__(256) residual_drop_kernel(const void* __restri
     }
 }
 
+// fp32 runs with bf16 x 3 products (split3.hip): the GELU output (forward) and the hidden gradient (backward) are read by
+// NOTHING but such products -- fc2 and its weight gradient; fc1's input and weight gradients -- so these forms write the
+// [hi | hi | lo] bf16 operand directly instead of an fp32 tensor that a split pass would read again: 4 (+ 4) bytes in and 6 out per
+// element instead of 4 (+ 4) in, 4 out, 4 in, 6 out.  x [rows, k] fp32 (forward: the pre-activation; backward: dy and it).
+template <bool BWD, bool DROP>
+__global__ void __launch_bounds__(256) gelu_split3_kernel(const float* __restrict__ dy, const float* __restrict__ x, uint16_t* __restrict__ out,
+                                                          int64_t rows, int k, float p, uint64_t seed) {
+    const ElemRng rng(p, seed);
+    const int kq = k >> 2;
+    const int64_t total = rows * kq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / kq;
+        const int c = (int)(i - row * kq) * 4;
+        const int64_t e = row * k + c;
+        const float4 xv = *(const float4*)(x + e);
+        float v[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (BWD) {
+            const float4 g = *(const float4*)(dy + e);
+            v[0] = g.x * gelu_grad_f(v[0]); v[1] = g.y * gelu_grad_f(v[1]); v[2] = g.z * gelu_grad_f(v[2]); v[3] = g.w * gelu_grad_f(v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+        }
+        if (DROP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= rng.mult(e + j);
+        }
+        const uint32_t h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+        const uint2 hi = make_uint2(h0, h1);
+        const uint2 lo = make_uint2(pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u)),
+                                    pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u)));
+        uint16_t* o = out + row * 3 * (int64_t)k + c;
+        *(uint2*)o = hi;
+        *(uint2*)(o + k) = hi;
+        *(uint2*)(o + 2 * k) = lo;
+    }
+}
+
 inline unsigned grid_for(int64_t n, int v) {
     int64_t b = (n / v + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -162,6 +200,25 @@ int hs_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, float drop_p
         else hipLaunchKernelGGL((gelu_bwd_kernel<float, false>), dim3(grid_for(n, 4)), dim3(256), 0, s, dy, x, dx, n, drop_p, seed);
     }
     HS_LAUNCH_CHECK("gelu_bwd");
+    return HS_OK;
+}
+
+int hs_gelu_split3(const float* dy, const float* x, void* out3, int64_t rows, int k, float drop_p, uint64_t seed, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(x && out3 && rows > 0 && k > 0 && k % 4 == 0, "hs_gelu_split3: null pointer, or k not a positive multiple of 4");
+    HS_CHECK_ARG(drop_p >= 0.f && drop_p <= 1.f, "drop_p must be in [0, 1]");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for(rows * k, 4)), block(256);
+    const bool drop = drop_p > 0.f;
+    uint16_t* o = (uint16_t*)out3;
+    if (dy) {
+        if (drop) hipLaunchKernelGGL((gelu_split3_kernel<true, true>), grid, block, 0, s, dy, x, o, rows, k, drop_p, seed);
+        else hipLaunchKernelGGL((gelu_split3_kernel<true, false>), grid, block, 0, s, dy, x, o, rows, k, drop_p, seed);
+    } else {
+        if (drop) hipLaunchKernelGGL((gelu_split3_kernel<false, true>), grid, block, 0, s, dy, x, o, rows, k, drop_p, seed);
+        else hipLaunchKernelGGL((gelu_split3_kernel<false, false>), grid, block, 0, s, dy, x, o, rows, k, drop_p, seed);
+    }
+    HS_LAUNCH_CHECK("gelu_split3");
     return HS_OK;
 }
 

@@ -791,6 +791,37 @@ def split3(x2d, mode):
     return out
 
 
+class _Split:
+    """An fp32 [rows, k] operand that exists ONLY as its bf16x3 split t3 [rows, 3 k] (`hs_gelu_split3`): stands in for the tensor
+    in _lib_linear / _lib_matmul / _param_grads (duck-typed: shape, dtype, device, is_contiguous, record_stream)."""
+
+    def __init__(self, t3, k):
+        self.t3, self.shape, self.dtype, self.device = t3, (t3.shape[0], k), torch.float32, t3.device
+
+    def is_contiguous(self):
+        return True
+
+    def record_stream(self, stream):
+        self.t3.record_stream(stream)
+
+    def dim(self):
+        return 2
+
+
+def _split_of(x2d):
+    """The [hi | hi | lo] split of x2d a forward product just made (still in the memo), or None: the Linear keeps it for its weight
+    gradient instead of splitting the same activations again in the backward (a third of the fp32 step's split passes)."""
+    if isinstance(x2d, _Split):
+        return x2d.t3
+    if x2d is None or x2d.dtype != torch.float32:
+        return None
+    key = (x2d.data_ptr(), tuple(x2d.shape), x2d._version, 0)
+    for kk, _, t in _SPLIT_MEMO:
+        if kk == key:
+            return t
+    return None
+
+
 def _mm_f32(a3, b3t, bias=None):
     """fp32 result of the bf16 product a3 @ b3t (+ bias): hipBLASLt with an fp32 output (`out_dtype`)."""
     if _MM_OUT_DTYPE[0] is None:
@@ -816,6 +847,10 @@ def _mm_f32(a3, b3t, bias=None):
 
 
 def _lib_linear(x2, w, b):
+    if isinstance(x2, _Split):
+        m, k = x2.shape
+        with _timed(_lib_tag("fwd bf16x3", m, w.shape[0], 3 * k), x2.device, 4 * (m * k + m * w.shape[0]), 6 * m * k * w.shape[0]):
+            return _mm_f32(x2.t3, split3(w.reshape(w.shape[0], k), 1).t(), b)
     m, k = x2.shape[0] if x2.dim() == 2 else x2.numel() // x2.shape[-1], x2.shape[-1]
     if _bf16x3_ok(x2, w.shape[0], k) and w.dtype == torch.float32 and w.shape[0] % 8 == 0:
         with _timed(_lib_tag("fwd bf16x3", m, w.shape[0], 3 * k), x2.device, 4 * (m * k + m * w.shape[0]), 6 * m * k * w.shape[0]):
@@ -827,6 +862,9 @@ def _lib_linear(x2, w, b):
 
 def _lib_matmul(dy2, w, res=None):
     m, n = dy2.shape
+    if isinstance(dy2, _Split):
+        with _timed(_lib_tag("dgrad bf16x3", m, w.shape[1], 3 * n), dy2.device, 4 * (m * n + m * w.shape[1]), 6 * m * n * w.shape[1]):
+            return _mm_f32(dy2.t3, split3(w.t().contiguous(), 1).t(), res)
     if _bf16x3_ok(dy2, w.shape[1], n) and w.dtype == torch.float32 and w.shape[1] % 8 == 0:
         with _timed(_lib_tag("dgrad bf16x3", m, w.shape[1], 3 * n), dy2.device, 4 * (m * n + m * w.shape[1]), 6 * m * n * w.shape[1]):
             dx = _mm_f32(split3(dy2, 0), split3(w.t().contiguous(), 1).t(), res)
@@ -848,15 +886,20 @@ def _cast_param_t(p, dtype, cache=None):
     return c
 
 
-def _param_grads(dy2, x2, weight, bias, want_w, want_b):
+def _param_grads(dy2, x2, weight, bias, want_w, want_b, x3=None):
     """Weight / bias gradient of y = x W^T + b from dy2 [rows, n_out], x2 [rows, k_in]: deposited straight into the gradient
     sink's buffers when one knows the parameters (returns (None, None)), else returned in the parameters' dtype."""
     n_out = weight.shape[0]
     k_in = weight.numel() // n_out
     if not (want_w or want_b):
         return None, None
-    hip_ok = (x2.is_contiguous() and dy2.is_contiguous() and n_out % 4 == 0 and
-              ((x2.dtype == torch.bfloat16 and k_in % 8 == 0) or (x2.dtype == torch.float32 and k_in % 4 == 0)))
+    if x2 is None:  # (fp32 runs) only the bf16x3 split of the input was kept: the three-product weight gradient reads nothing else
+        assert x3 is not None and dy2.dtype == torch.float32
+        hip_ok = dy2.is_contiguous() and n_out % 8 == 0
+        assert hip_ok
+    else:
+        hip_ok = (x2.is_contiguous() and dy2.is_contiguous() and n_out % 4 == 0 and
+                  ((x2.dtype == torch.bfloat16 and k_in % 8 == 0) or (x2.dtype == torch.float32 and k_in % 4 == 0)))
     wbuf = _sink_buffer(weight) if (hip_ok and want_w) else None
     bbuf = _sink_buffer(bias) if (wbuf is not None and want_b) else None
     if wbuf is not None and (not want_b or bbuf is not None):
@@ -865,21 +908,21 @@ def _param_grads(dy2, x2, weight, bias, want_w, want_b):
         aw = ASYNC_WGRAD
         wbuf = wbuf.view(n_out, k_in)
         if aw is not None:
-            cur = torch.cuda.current_stream(x2.device)
+            cur = torch.cuda.current_stream(dy2.device)
             aw.stream.wait_stream(cur)
             dy2.record_stream(aw.stream)
-            x2.record_stream(aw.stream)
+            (x2 if x2 is not None else x3).record_stream(aw.stream)
             with torch.cuda.stream(aw.stream):
-                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
+                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3)
         else:
-            LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf)
+            LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3)
         GRAD_SINK.deposited(weight)
         if want_b:
             GRAD_SINK.deposited(bias)
         return None, None
     dw = db = None
     if hip_ok:
-        dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b)
+        dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, x3=x3)
         dw = dw32.to(weight.dtype).view(weight.shape) if want_w else None
         db = db32.to(bias.dtype) if want_b else None
     else:  # odd widths: library GEMM
@@ -903,48 +946,56 @@ class LinearFn(torch.autograd.Function):
         n_out = weight.shape[0]
         k_in = weight.numel() // n_out
         w = _cast_param(weight, x.dtype).view(n_out, k_in)
-        ctx.save_for_backward(x, weight)
+        ctx.x_shape = x.shape
         ctx.bias_param = bias
         ctx.w_cast = w if w.dtype != weight.dtype else None  # activation-dtype copy, reused by the input-gradient GEMM
         ctx.cast_cache = CAST_CACHE
         ctx.passthrough = passthrough
         ctx.has_residual = residual is not None
+        ctx.x3 = None
         if pre is not None:
             assert not passthrough
-            return pre[0]
-        if residual is not None:
+            y = pre[0]
+        elif residual is not None:
             # y = x W^T + b + residual: the add rides on the product's epilogue (one rounding); its gradient is dy itself
             assert not passthrough
             if own_gemm_legal(n_out, k_in, x.dtype) and x.is_contiguous():
                 res2 = residual.reshape(-1, n_out)
                 res2 = res2 if res2.is_contiguous() else res2.contiguous()
-                return gemm_nt(x.reshape(-1, k_in), w, bias, _lib.HS_EPI_RESID, aux=res2)[0].view(x.shape[:-1] + (n_out,))
-            return _lib_linear(x, w, None if bias is None else _cast_param(bias, x.dtype)) + residual
-        if own_gemm_ok(_lib.HS_EPI_BIAS, n_out, k_in, x.dtype) and x.is_contiguous():
+                y = gemm_nt(x.reshape(-1, k_in), w, bias, _lib.HS_EPI_RESID, aux=res2)[0].view(x.shape[:-1] + (n_out,))
+            else:
+                y = _lib_linear(x, w, None if bias is None else _cast_param(bias, x.dtype)) + residual
+                ctx.x3 = _split_of(x.reshape(-1, k_in)) if x.is_contiguous() else None
+        elif own_gemm_ok(_lib.HS_EPI_BIAS, n_out, k_in, x.dtype) and x.is_contiguous():
             y = gemm_nt(x.reshape(-1, k_in), w, bias)[0].view(x.shape[:-1] + (n_out,))  # fp32 master bias added in the epilogue
         else:
             y = _lib_linear(x, w, None if bias is None else _cast_param(bias, x.dtype))
+            ctx.x3 = _split_of(x.reshape(-1, k_in)) if x.is_contiguous() else None
+        # (fp32 runs) where the forward product made a bf16x3 split of x, the weight gradient reads THAT (6 bytes per element) and x
+        # itself (4) is not kept for it
+        ctx.save_for_backward(None if ctx.x3 is not None else x, weight)
         # passthrough: also hand x back (an alias) for the block's residual connection.  The gradient of that second use then
         # arrives HERE together with dy, and the input-gradient GEMM adds it as its beta * C term instead of autograd
         # launching a separate add over the whole activation (v2 norm placement: x + LN(branch(x)), ref :334-335)
         return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None):
+    def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None, x3=None):
         """dW (and db) of one Linear.  With dw_out/db_out (existing fp32 gradient buffers) the result is ADDED there."""
-        rows = x2.shape[0]
-        dev = x2.device
+        rows = dy2.shape[0]
+        dev = dy2.device
         accumulate = 1 if dw_out is not None else 0
         dw32 = dw_out if dw_out is not None else torch.empty((n_out, k_in), dtype=torch.float32, device=dev)
         db32 = None
         if want_b:
             db32 = db_out if db_out is not None else torch.empty(n_out, dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=dev)
-        if _bf16x3_ok(x2, n_out, k_in) and n_out % 8 == 0 and x2.dtype == dy2.dtype:
+        if x3 is not None or (_bf16x3_ok(x2, n_out, k_in) and n_out % 8 == 0 and x2.dtype == dy2.dtype):
             # dW = dY^T X as three bf16 weight-gradient products over the hi / lo column blocks of the [hi | hi | lo] splits
             # (the split of dY is shared with the input-gradient product): hi^T hi + hi^T lo + lo^T hi; the bias gradient takes
             # the column sums of dY_hi and dY_lo
-            dy3, x3 = split3(dy2, 0), split3(x2, 0)
+            dy3 = dy2.t3 if isinstance(dy2, _Split) else split3(dy2, 0)
+            x3 = x3 if x3 is not None else split3(x2, 0)
             with _timed("linear_wgrad bf16x3", dev, 3 * 2 * rows * (n_out + k_in), 6 * rows * n_out * k_in):
                 for i, (yo, xo, dbp) in enumerate(((0, 0, db32), (0, 2 * k_in, None), (2 * n_out, 0, db32))):
                     check(lib.hs_linear_wgrad_ld(ptr(dy3), 3 * n_out, yo, ptr(x3), 3 * k_in, xo, ptr(dw32), ptr(dbp), ptr(ws), rows,
@@ -964,14 +1015,15 @@ class LinearFn(torch.autograd.Function):
         if dy is None:  # only the passthrough alias was used downstream
             return dx_res, None, None, None, None, None
         dy2 = dy.reshape(-1, n_out)
-        x2 = x.reshape(-1, k_in)
+        x2 = None if x is None else x.reshape(-1, k_in)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy2, weight, ctx.w_cast, None if dx_res is None else dx_res.reshape(-1, k_in), ctx.cast_cache).reshape(x.shape)
+            dx = _input_grad(dy2, weight, ctx.w_cast, None if dx_res is None else dx_res.reshape(-1, k_in), ctx.cast_cache).reshape(ctx.x_shape)
         ctx.w_cast = ctx.cast_cache = None
-        dw, db = _param_grads(dy2, x2, weight, bias, ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2])
+        x3, ctx.x3 = ctx.x3, None
+        dw, db = _param_grads(dy2, x2, weight, bias, ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2], x3)
         return dx, dw, db, None, (dy if ctx.has_residual else None), None
 
 
@@ -1273,15 +1325,24 @@ class MlpFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         dt = x.dtype
+        x3 = a3 = None  # (fp32 runs) the bf16x3 splits the two forward products made, kept for the weight gradients
         w1c, w2c = _cast_param(w1, dt), _cast_param(w2, dt)
         need_grad = any(ctx.needs_input_grad[:5])
         if own_gemm_ok(_lib.HS_EPI_GELU, hid, c_in, dt):
             h, a = gemm_nt(x2, w1c, b1, _lib.HS_EPI_GELU, want_c=need_grad, drop_p=drop_p, seed=seed)
         else:
             h = _lib_linear(x2, w1c, None if b1 is None else _cast_param(b1, dt))
-            a = torch.empty_like(h)
-            check(lib.hs_gelu_fwd(ptr(h), ptr(a), h.numel(), float(drop_p), int(seed), _lib.dtype_code(dt), stream_ptr(h.device)),
-                  "hs_gelu_fwd")
+            x3 = _split_of(x2)
+            if _bf16x3_ok(h, w2.shape[0], hid) and w2c.dtype == torch.float32 and w2.shape[0] % 8 == 0 and hid % 8 == 0:
+                # fp32 run, fc2 a bf16x3 product: gelu(h) is written as that product's [hi | hi | lo] operand and never as fp32
+                a3 = torch.empty((h.shape[0], 3 * hid), dtype=torch.bfloat16, device=h.device)
+                check(lib.hs_gelu_split3(None, ptr(h), ptr(a3), h.shape[0], hid, float(drop_p), int(seed), stream_ptr(h.device)),
+                      "hs_gelu_split3")
+                a = _Split(a3, hid)
+            else:
+                a = torch.empty_like(h)
+                check(lib.hs_gelu_fwd(ptr(h), ptr(a), h.numel(), float(drop_p), int(seed), _lib.dtype_code(dt), stream_ptr(h.device)),
+                      "hs_gelu_fwd")
         ctx.has_residual = residual is not None
         if residual is not None and own_gemm_legal(w2.shape[0], hid, dt):
             res2 = residual.reshape(-1, w2.shape[0])
@@ -1290,13 +1351,19 @@ class MlpFn(torch.autograd.Function):
             y = gemm_nt(a, w2c, b2)[0]
         else:
             y = _lib_linear(a, w2c, None if b2 is None else _cast_param(b2, dt))
+            a3 = _split_of(a)
+            if isinstance(a, _Split):
+                a = None
         if residual is not None and not own_gemm_legal(w2.shape[0], hid, dt):
             y = y + residual.reshape(-1, w2.shape[0])
-        ctx.save_for_backward(x2, h, a, w1, w2)
+        assert not isinstance(a, _Split)
+        # (fp32 runs: the weight gradients read the bf16x3 splits the forward products made, not x2 / a themselves)
+        ctx.save_for_backward(None if x3 is not None else x2, h, None if a3 is not None else a, w1, w2)
         ctx.biases = (b1, b2)
         ctx.casts = (w1c if w1c.dtype != w1.dtype else None, w2c if w2c.dtype != w2.dtype else None)
         ctx.cast_cache = CAST_CACHE
         ctx.meta = (float(drop_p), int(seed), x.shape)
+        ctx.splits = (x3, a3)
         y = y.view(x.shape[:-1] + (w2.shape[0],))
         return (y, x.view_as(x)) if passthrough else y
 
@@ -1318,15 +1385,22 @@ class MlpFn(torch.autograd.Function):
             dh = gemm_nt(dy2, _cast_param_t(w2, dt, ctx.cast_cache), None, _lib.HS_EPI_DGELU, aux=h, drop_p=p, seed=seed)[0]
         else:
             da = _lib_matmul(dy2, w2c if (w2c is not None and w2c.dtype == dt) else w2.to(dt))
-            dh = torch.empty_like(h)
-            check(lib.hs_gelu_bwd(ptr(da), ptr(h), ptr(dh), h.numel(), p, seed, _lib.dtype_code(dt), stream_ptr(h.device)), "hs_gelu_bwd")
+            if _bf16x3_ok(da, c_in, hid) and w1.dtype == torch.float32 and c_in % 8 == 0 and hid % 8 == 0:
+                # fp32 run: dh is read by fc1's input- and weight-gradient products only, both bf16x3 -- written as their operand
+                dh3 = torch.empty((h.shape[0], 3 * hid), dtype=torch.bfloat16, device=h.device)
+                check(lib.hs_gelu_split3(ptr(da), ptr(h), ptr(dh3), h.shape[0], hid, p, seed, stream_ptr(h.device)), "hs_gelu_split3")
+                dh = _Split(dh3, hid)
+            else:
+                dh = torch.empty_like(h)
+                check(lib.hs_gelu_bwd(ptr(da), ptr(h), ptr(dh), h.numel(), p, seed, _lib.dtype_code(dt), stream_ptr(h.device)), "hs_gelu_bwd")
             del da
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dh, w1, w1c, None if dx_res is None else dx_res.reshape(-1, c_in), ctx.cast_cache).reshape(xshape)
         ctx.casts = ctx.cast_cache = None
-        dw2, db2 = _param_grads(dy2, a, w2, b2, ctx.needs_input_grad[3], b2 is not None and ctx.needs_input_grad[4])
-        dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[1], b1 is not None and ctx.needs_input_grad[2])
+        (x3, a3), ctx.splits = ctx.splits, (None, None)
+        dw2, db2 = _param_grads(dy2, a, w2, b2, ctx.needs_input_grad[3], b2 is not None and ctx.needs_input_grad[4], a3)
+        dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[1], b1 is not None and ctx.needs_input_grad[2], x3)
         return dx, dw1, db1, dw2, db2, None, None, None, (dy if ctx.has_residual else None)
 
 

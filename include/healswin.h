@@ -431,6 +431,11 @@ int hs_ln_head_bwd(const void* y, const float* mean, const float* rstd, const vo
  * strides ldy / ldx (elements, multiples of 8; dy / x point to the matrices' first elements): the hi / lo blocks of two mode-0 matrices feed the three weight-gradient products (accumulate = 1 on the second and third).
  * ---------------------------------------------------------------------------------------------- */
 int hs_split_bf16x3(const float* x, void* out, int64_t rows, int k, int mode, void* stream);
+/* GELU fused with the split: out3 [rows, 3 k] bf16 = [hi | hi | lo] of dropout(gelu_erf(x)) (dy == NULL: the forward, x the
+ * pre-activation) or of dy * dropout_mask * gelu_erf'(x) (the backward), x / dy [rows, k] fp32 -- for tensors that only
+ * bf16 x 3 products read (the MLP hidden activation and its gradient): no fp32 copy is written.  Same dropout mask as
+ * hs_gelu_fwd / hs_gelu_bwd for (seed, element index row * k + column). */
+int hs_gelu_split3(const float* dy, const float* x, void* out3, int64_t rows, int k, float drop_p, uint64_t seed, void* stream);
 int hs_linear_wgrad_ld(const void* dy, int64_t ldy, int64_t ycol0, const void* x, int64_t ldx, int64_t xcol0, float* dw, float* dbias,
                        float* workspace, int64_t rows, int n_out, int k_in, int accumulate, void* stream);
 

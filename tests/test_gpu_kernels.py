@@ -805,3 +805,31 @@ def test_buffer_scalar_offset_takes_part_in_the_range_check():
         want = np.where(np.arange(64) < n_valid, 0x3f800000, 0)
         assert (got[:64] == want).all(), ("register load", soff, got[:64])
         assert (got[64:] == want).all(), ("LDS-DMA load", soff, got[64:])
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.3])
+def test_gelu_split3_equals_gelu_then_split(drop_p):
+    """hs_gelu_split3 (fp32 runs: the GELU output / the hidden gradient written directly as the [hi | hi | lo] operand of the
+    bf16x3 products that read them) is hs_gelu_fwd / hs_gelu_bwd followed by hs_split_bf16x3 (forward: bit for bit), same dropout mask."""
+    from heal_swin_amd import _lib
+    from heal_swin_amd._lib import check, lib, ptr
+    rows, k, seed = 777, 264, 12345
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(rows, k, generator=g, device=DEV) * 2
+    dy = torch.randn(rows, k, generator=g, device=DEV)
+    for bwd in (False, True):
+        ref = torch.empty_like(x)
+        if bwd:
+            check(lib.hs_gelu_bwd(ptr(dy), ptr(x), ptr(ref), x.numel(), drop_p, seed, _lib.HS_F32, None), "gelu_bwd")
+        else:
+            check(lib.hs_gelu_fwd(ptr(x), ptr(ref), x.numel(), drop_p, seed, _lib.HS_F32, None), "gelu_fwd")
+        ref3 = torch.empty(rows, 3 * k, dtype=torch.bfloat16, device=DEV)
+        check(lib.hs_split_bf16x3(ptr(ref), ptr(ref3), rows, k, 0, None), "split")
+        out3 = torch.empty_like(ref3)
+        check(lib.hs_gelu_split3(ptr(dy) if bwd else None, ptr(x), ptr(out3), rows, k, drop_p, seed, None), "gelu_split3")
+        if not bwd:  # (the backward's product dy * gelu'(x) is contracted differently by the compiler in the two kernels: fp32 ulps)
+            assert torch.equal(out3.view(torch.int16), ref3.view(torch.int16)), drop_p
+        assert torch.equal(out3[:, :k], out3[:, k:2 * k])
+        # and hi + lo reproduces the fp32 value to 2^-16
+        hi, lo = out3[:, :k].float(), out3[:, 2 * k:].float()
+        assert float((hi + lo - ref).abs().max()) <= 2.0 ** -15 * float(ref.abs().max())
