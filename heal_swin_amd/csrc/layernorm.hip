@@ -251,16 +251,39 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
     }
 }
 
-// The training default of the forward, specialised like layernorm_bwd_bf16_kernel below (round 4): bf16 rows in 16-byte chunks,
+// element k of a packed 16-byte chunk, and the chunk of VEC fp32 values rounded to the activation dtype
+template <typename T>
+__device__ __forceinline__ float chunk_elem(const uint4& w, int k);
+template <>
+__device__ __forceinline__ float chunk_elem<bf16_t>(const uint4& w, int k) {
+    const uint32_t d = (k >> 1) == 0 ? w.x : (k >> 1) == 1 ? w.y : (k >> 1) == 2 ? w.z : w.w;
+    return (k & 1) ? __uint_as_float(d & 0xffff0000u) : __uint_as_float(d << 16);
+}
+template <>
+__device__ __forceinline__ float chunk_elem<float>(const uint4& w, int k) {
+    return __uint_as_float(k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w);
+}
+template <typename T>
+__device__ __forceinline__ uint4 chunk_pack(const float* v);
+template <>
+__device__ __forceinline__ uint4 chunk_pack<bf16_t>(const float* v) {
+    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+template <>
+__device__ __forceinline__ uint4 chunk_pack<float>(const float* v) {
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+
+// The training default of the forward, specialised like layernorm_bwd_fast_kernel below (round 4): rows in 16-byte chunks (bf16 or fp32),
 // y = LN(x) or (sum_out = x + add_in, y = LN(sum_out)); no dropout, DropPath scale, v2 residual or compensated stream.  Next
 // rows' chunks requested packed before the current rows are reduced, 32-bit byte offsets from uniform bases, launch sized to
 // one resident round.
-template <int LPR, int ITERS>
-__global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS == 4 ? 3 : 1)) layernorm_fwd_bf16_kernel(
-    const uint16_t* __restrict__ x, const uint16_t* __restrict__ add_in, const float* __restrict__ gamma, const float* __restrict__ beta,
-    uint16_t* __restrict__ y, uint16_t* __restrict__ sum_out, float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
+template <typename T, int LPR, int ITERS>
+__global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS == 4 ? 3 : 1)) layernorm_fwd_fast_kernel(
+    const void* __restrict__ x, const void* __restrict__ add_in, const float* __restrict__ gamma, const float* __restrict__ beta,
+    void* __restrict__ y, void* __restrict__ sum_out, float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
     int width) {
-    constexpr int RPW = 64 / LPR, VEC = 8;
+    constexpr int RPW = 64 / LPR, VEC = 16 / (int)sizeof(T), ES = (int)sizeof(T);
     constexpr bool PF = ITERS <= 2;
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsub = lane / LPR;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -276,7 +299,7 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS 
             for (int it = 0; it < ITERS; ++it) {
                 const int c = sub + LPR * it;
                 if (c < nchunk) {
-                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
+                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
                     px[it] = *(const uint4*)((const char*)x + e);
                     if (adding) pa[it] = *(const uint4*)((const char*)add_in + e);
                 }
@@ -302,19 +325,16 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS 
         for (int it = 0; it < ITERS; ++it) {
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
-                vec_io<bf16_t, VEC>::decode(cx[it], v[it]);
+                vec_io<T, VEC>::decode(cx[it], v[it]);
                 if (adding) {  // the stream as every other consumer sees it: rounded to bf16 exactly as a separate add would store it
                     float a2[VEC];
-                    vec_io<bf16_t, VEC>::decode(ca[it], a2);
-                    uint32_t w[4];
+                    vec_io<T, VEC>::decode(ca[it], a2);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        w[k] = pack_bf16x2(v[it][2 * k] + a2[2 * k], v[it][2 * k + 1] + a2[2 * k + 1]);
-                        v[it][2 * k] = __uint_as_float(w[k] << 16);
-                        v[it][2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
-                    }
-                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
-                    *(uint4*)((char*)sum_out + e) = make_uint4(w[0], w[1], w[2], w[3]);
+                    for (int k = 0; k < VEC; ++k) v[it][k] += a2[k];
+                    const uint4 w = chunk_pack<T>(v[it]);
+                    vec_io<T, VEC>::decode(w, v[it]);
+                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
+                    *(uint4*)((char*)sum_out + e) = w;
                 }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) sum += v[it][k];
@@ -338,15 +358,17 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS 
         for (int it = 0; it < ITERS; ++it) {
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
-                const float4 g0 = *(const float4*)(gamma + c * VEC), g1 = *(const float4*)(gamma + c * VEC + 4);
-                const float4 b0 = *(const float4*)(beta + c * VEC), b1 = *(const float4*)(beta + c * VEC + 4);
-                const float g[VEC] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[VEC] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                float o[VEC];
+                float g[VEC], b[VEC], o[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const float4 g4 = *(const float4*)(gamma + c * VEC + 4 * q), b4 = *(const float4*)(beta + c * VEC + 4 * q);
+                    g[4 * q] = g4.x; g[4 * q + 1] = g4.y; g[4 * q + 2] = g4.z; g[4 * q + 3] = g4.w;
+                    b[4 * q] = b4.x; b[4 * q + 1] = b4.y; b[4 * q + 2] = b4.z; b[4 * q + 3] = b4.w;
+                }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = fmaf((v[it][k] - mean) * rstd, g[k], b[k]);
-                const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
-                *(uint4*)((char*)y + e) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
-                                                     pack_bf16x2(o[6], o[7]));
+                const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
+                *(uint4*)((char*)y + e) = chunk_pack<T>(o);
             }
         }
         if (live && sub == 0 && mean_out) {
@@ -509,15 +531,15 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
 // needs 110 registers at 512 columns (4 waves per SIMD, one row of x, dy [, dsum] per wave requested at a time: 32-48 KB per CU,
 // 3.2-3.9 TB/s on the 98 304 x 512 rows of stage 2; 162 registers and 1.6-2.0 TB/s at 1024 columns).  Here the chunks of the
 // wave's NEXT rows are requested -- and held packed, 4 registers per 16 bytes -- before the current rows are reduced, and the
-// launch is sized to ONE resident round of workgroups (run_bwd_bf16).
-template <int LPR, int ITERS>
-__global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) layernorm_bwd_bf16_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+// launch is sized to ONE resident round of workgroups (run_bwd_fast).
+template <typename T, int LPR, int ITERS>
+__global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) layernorm_bwd_fast_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean_in,
-                                                                 const float* __restrict__ rstd_in, uint16_t* __restrict__ dx,
+                                                                 const float* __restrict__ rstd_in, void* __restrict__ dx,
                                                                  float* __restrict__ partials, int64_t rows, int width,
-                                                                 const uint16_t* __restrict__ dres_in) {
+                                                                 const void* __restrict__ dres_in) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][width]
-    constexpr int RPW = 64 / LPR, VEC = 8;
+    constexpr int RPW = 64 / LPR, VEC = 16 / (int)sizeof(T), ES = (int)sizeof(T);
     constexpr bool PF = ITERS <= 2;  // (wider rows have >= 4 chunks per lane and tensor in flight already)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int sub = lane % LPR, rsub = lane / LPR;
@@ -530,13 +552,11 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = sub + LPR * it;
-        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-        if (c < nchunk) {
-            g0 = *(const float4*)(gamma + c * VEC);
-            g1 = *(const float4*)(gamma + c * VEC + 4);
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const float4 g4 = c < nchunk ? *(const float4*)(gamma + c * VEC + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gm[it][4 * q] = g4.x; gm[it][4 * q + 1] = g4.y; gm[it][4 * q + 2] = g4.z; gm[it][4 * q + 3] = g4.w;
         }
-        gm[it][0] = g0.x; gm[it][1] = g0.y; gm[it][2] = g0.z; gm[it][3] = g0.w;
-        gm[it][4] = g1.x; gm[it][5] = g1.y; gm[it][6] = g1.z; gm[it][7] = g1.w;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             dg[it][k] = 0.f;
@@ -557,7 +577,7 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
             for (int it = 0; it < ITERS; ++it) {
                 const int c = sub + LPR * it;
                 if (c < nchunk) {
-                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
+                    const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
                     px[it] = *(const uint4*)((const char*)x + e);
                     pdy[it] = *(const uint4*)((const char*)dy + e);
                     if (has_res) pd2[it] = *(const uint4*)((const char*)dres_in + e);
@@ -587,11 +607,9 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
         for (int it = 0; it < ITERS; ++it) {
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
-                const uint32_t wx[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w}, wd[4] = {cdy[it].x, cdy[it].y, cdy[it].z, cdy[it].w};
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const float xv = (k & 1) ? __uint_as_float(wx[k >> 1] & 0xffff0000u) : __uint_as_float(wx[k >> 1] << 16);
-                    const float dv = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+                    const float xv = chunk_elem<T>(cx[it], k), dv = chunk_elem<T>(cdy[it], k);
                     const float xh = (xv - mean) * rstd, g = dv * gm[it][k];
                     s1 += g;
                     s2 = fmaf(g, xh, s2);
@@ -610,20 +628,16 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
         for (int it = 0; it < ITERS; ++it) {
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
-                const uint32_t wx[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w}, wd[4] = {cdy[it].x, cdy[it].y, cdy[it].z, cdy[it].w};
-                const uint32_t w2[4] = {cd2[it].x, cd2[it].y, cd2[it].z, cd2[it].w};
                 float o[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const float xv = (k & 1) ? __uint_as_float(wx[k >> 1] & 0xffff0000u) : __uint_as_float(wx[k >> 1] << 16);
-                    const float dv = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+                    const float xv = chunk_elem<T>(cx[it], k), dv = chunk_elem<T>(cdy[it], k);
                     const float xh = (xv - mean) * rstd, g = dv * gm[it][k];
                     o[k] = rstd * (g - m1 - xh * m2);
-                    if (has_res) o[k] += (k & 1) ? __uint_as_float(w2[k >> 1] & 0xffff0000u) : __uint_as_float(w2[k >> 1] << 16);
+                    if (has_res) o[k] += chunk_elem<T>(cd2[it], k);
                 }
-                const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * 2u;
-                *(uint4*)((char*)dx + e) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
-                                                      pack_bf16x2(o[6], o[7]));
+                const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
+                *(uint4*)((char*)dx + e) = chunk_pack<T>(o);
             }
         }
     }
@@ -751,10 +765,10 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     return HS_OK;
 }
 
-template <int LPR, int ITERS>
-int run_fwd_bf16(const void* x, const void* add_in, const float* g, const float* b, void* y, void* sum_out, float* mean, float* rstd,
+template <typename T, int LPR, int ITERS>
+int run_fwd_fast(const void* x, const void* add_in, const float* g, const float* b, void* y, void* sum_out, float* mean, float* rstd,
                  int64_t rows, int width, hipStream_t s) {
-    auto kern = layernorm_fwd_bf16_kernel<LPR, ITERS>;
+    auto kern = layernorm_fwd_fast_kernel<T, LPR, ITERS>;
     static int resident = 0;
     if (resident == 0) {
         int n = 0;
@@ -766,19 +780,18 @@ int run_fwd_bf16(const void* x, const void* add_in, const float* g, const float*
     int64_t blocks = (int64_t)usable_cus() * (per_cu_override > 0 ? per_cu_override : resident);
     const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
     if (blocks > by_rows) blocks = by_rows;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)add_in, g, b, (uint16_t*)y,
-                       (uint16_t*)sum_out, mean, rstd, rows, width);
-    HS_LAUNCH_CHECK("layernorm_fwd_bf16");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, x, add_in, g, b, y, sum_out, mean, rstd, rows, width);
+    HS_LAUNCH_CHECK("layernorm_fwd_fast");
     return HS_OK;
 }
 
 // One resident round: as many workgroups as the chip holds at this instantiation's register / LDS footprint (every workgroup
 // then sees the same number of rows and there is no second, partly filled round), at most kBwdMaxBlocks partial rows, at
 // least one row group per wave.  HS_LN_BWD_FAST=0 sends everything through the general kernel (A/B runs).
-template <int LPR, int ITERS>
-int run_bwd_bf16(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
+template <typename T, int LPR, int ITERS>
+int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
                  float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in, int accumulate) {
-    auto kern = layernorm_bwd_bf16_kernel<LPR, ITERS>;
+    auto kern = layernorm_bwd_fast_kernel<T, LPR, ITERS>;
     const size_t smem = (size_t)3 * 2 * width * sizeof(float);
     if (smem > 48 * 1024) HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     static int resident_width = 0, resident = 0;  // per instantiation; the LDS footprint follows the width
@@ -794,9 +807,8 @@ int run_bwd_bf16(const void* dy, const void* x, const float* g, const float* mea
     if (blocks > kBwdMaxBlocks) blocks = kBwdMaxBlocks;
     const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
     if (blocks > by_rows) blocks = by_rows;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, (const uint16_t*)dy, (const uint16_t*)x, g, mean, rstd,
-                       (uint16_t*)dx, ws, rows, width, (const uint16_t*)dres_in);
-    HS_LAUNCH_CHECK("layernorm_bwd_bf16");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in);
+    HS_LAUNCH_CHECK("layernorm_bwd_fast");
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 63) / 64), dim3(1024), 0, s, ws, dgamma, dbeta, (int)blocks,
                        width, accumulate);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
@@ -843,15 +855,17 @@ int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const f
     if (int st = check_extra(ex, rows)) return st;
     if (rows == 0) return HS_OK;
     hipStream_t s = (hipStream_t)stream;
+    static const bool fast = !(getenv("HS_LN_FWD_FAST") && atoi(getenv("HS_LN_FWD_FAST")) == 0);
+    const bool plain = fast && !residual && !ex.row_scale && ex.drop_p == 0.f && !ex.lo_in && !ex.lo_out;
     if (dtype == HS_BF16) {
-        static const bool fast = !(getenv("HS_LN_FWD_FAST") && atoi(getenv("HS_LN_FWD_FAST")) == 0);
-        if (fast && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32) && !residual && !ex.row_scale && ex.drop_p == 0.f &&
-            !ex.lo_in && !ex.lo_out)
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_bf16<decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s); });
+        if (plain && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32))
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s); });
         if (width % 8 == 0)
             return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
         return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
     }
+    if (plain && width % 4 == 0 && width <= 2048 && rows * width * 4 < (1ll << 32))
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd_fast<float, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s); });
     if (width % 4 == 0)
         return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd<float, 4, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
     return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_fwd<float, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
@@ -866,10 +880,13 @@ int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* 
     HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
     if (int st = check_extra(ex, rows)) return st;
     hipStream_t s = (hipStream_t)stream;
+    static const bool fast = !(getenv("HS_LN_BWD_FAST") && atoi(getenv("HS_LN_BWD_FAST")) == 0);
+    const bool plain = fast && !ex.row_scale && ex.drop_p == 0.f && !dadd_out;
+    if (dtype == HS_F32 && plain && width % 4 == 0 && width <= 2048 && rows * width * 4 < (1ll << 32))
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd_fast<float, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, accumulate); });
     if (dtype == HS_BF16) {
-        static const bool fast = !(getenv("HS_LN_BWD_FAST") && atoi(getenv("HS_LN_BWD_FAST")) == 0);
-        if (fast && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32) && !ex.row_scale && ex.drop_p == 0.f && !dadd_out)
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd_bf16<decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, accumulate); });
+        if (plain && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32))
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, accumulate); });
         if (width % 8 == 0)
             return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
         return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_bwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, dadd_out, ex, v1_mode, accumulate); });
