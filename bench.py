@@ -447,7 +447,7 @@ def main():
                        "parallelism": f"dp{world}",
                        "step": "fwd + CE loss + bwd + grad all-reduce + Adam" + ("" if args.unfused_loss else " (loss fused into the decoder tail: model.forward_seg_loss)"),
                        "launch": "hip graph replay" if args.graph else "eager",
-                       "params_M": res.params_m, "final_loss": res.loss,
+                       "params_M": res.params_m, "final_loss": res.loss, "peak_device_memory_GB": res.peak_gb,
                        "library_gemm_selection": gemm_selection},
         }
         # whole-step model FLOPs (analytic forward count == FlopCounterMode; backward = 2x) against the dense bf16 peak
@@ -471,6 +471,7 @@ def main():
         r32 = run_workload(ctx, "fp32", k, 2, timing=False)
         out["fp32"] = {"value": args.batch * k / r32.elapsed, "unit": "images/s", "ms_per_step": 1e3 * r32.elapsed / k, "steps": k,
                        "warmup": 2, "batch_per_gpu": args.batch, "workload": wl["name"], "final_loss": r32.loss,
+                       "peak_device_memory_GB": r32.peak_gb,
                        "gemm": "bf16x3: every Linear product as one bf16 GEMM of three-fold depth over hi / lo splits, fp32 accumulation "
                                "(ops.FP32_GEMM, csrc/split3.hip; logits 7e-6 of the oracle at this size, tests/test_gpu_baseline_configs.py)",
                        "note": "fp32 activations and MFMA-f32 attention kernels; library GEMMs with " + (
@@ -669,6 +670,7 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
 
     args, wl, dev, world, rank = ctx.args, ctx.wl, ctx.dev, ctx.world, ctx.rank
     batch = getattr(ctx, "batch", None) or args.batch
+    torch.cuda.reset_peak_memory_stats(dev)
     model, cfg, spec = build_model(wl)
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
@@ -774,7 +776,8 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
                 "reserved_cus": int(__import__("heal_swin_amd")._lib.lib.hs_get_reserved_cus()), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
                 "exchange": f"{args.comm_dtype} wire format of fp32 flat buckets, async all-reduce launched from gradient hooks during backward"}
     res = types.SimpleNamespace(elapsed=elapsed, loss=float(loss.item()), timings=timings if rank == 0 else None, rccl=rccl,
-                                params_m=round(sum(p.numel() for p in model.parameters()) / 1e6, 2))
+                                params_m=round(sum(p.numel() for p in model.parameters()) / 1e6, 2),
+                                peak_gb=round(torch.cuda.max_memory_allocated(dev) / 1e9, 1))
     dp.remove()
     del model, dp, opt, imgs, labels, loss, step
     if args.graph:
