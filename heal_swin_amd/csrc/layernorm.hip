@@ -275,14 +275,15 @@ __device__ __forceinline__ uint4 chunk_pack<float>(const float* v) {
 }
 
 // The training default of the forward, specialised like layernorm_bwd_fast_kernel below (round 4): rows in 16-byte chunks (bf16 or fp32),
-// y = LN(x) or (sum_out = x + add_in, y = LN(sum_out)); no dropout, DropPath scale, v2 residual or compensated stream.  Next
+// y = [residual +] LN(x) or (sum_out = x + add_in, y = LN(sum_out)); no dropout, DropPath scale or compensated stream.  Next
 // rows' chunks requested packed before the current rows are reduced, 32-bit byte offsets from uniform bases, launch sized to
 // one resident round.
 template <typename T, int LPR, int ITERS>
-__global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS == 4 ? 3 : 1)) layernorm_fwd_fast_kernel(
+__global__ void __launch_bounds__(256, (ITERS == 1 ? 6 : ITERS == 2 ? 5 : ITERS == 4 ? 3 : 1)) layernorm_fwd_fast_kernel(
     const void* __restrict__ x, const void* __restrict__ add_in, const float* __restrict__ gamma, const float* __restrict__ beta,
     void* __restrict__ y, void* __restrict__ sum_out, float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
-    int width) {
+    int width, const void* __restrict__ residual) {
+    // (add_in and residual are exclusive: the second packed stream `pa` carries whichever is given)
     constexpr int RPW = 64 / LPR, VEC = 16 / (int)sizeof(T), ES = (int)sizeof(T);
     constexpr bool PF = ITERS <= 2;
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsub = lane / LPR;
@@ -290,7 +291,8 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS 
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * RPW;
     const int nchunk = width / VEC;
     const float inv_w = 1.f / (float)width;
-    const bool adding = add_in != nullptr;
+    const bool adding = add_in != nullptr, with_res = residual != nullptr;
+    const void* second = adding ? add_in : residual;
     uint4 px[ITERS], pa[ITERS];
     auto fetch = [&](int64_t r0) {
         const int64_t row = r0 + rsub;
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS 
                 if (c < nchunk) {
                     const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
                     px[it] = *(const uint4*)((const char*)x + e);
-                    if (adding) pa[it] = *(const uint4*)((const char*)add_in + e);
+                    if (second) pa[it] = *(const uint4*)((const char*)second + e);
                 }
             }
         }
@@ -367,6 +369,10 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 8 : ITERS == 2 ? 5 : ITERS 
                 }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = fmaf((v[it][k] - mean) * rstd, g[k], b[k]);
+                if (with_res) {  // v2 placement (ref :334-335): y = residual + LN(x), one rounding
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o[k] += chunk_elem<T>(ca[it], k);
+                }
                 const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
                 *(uint4*)((char*)y + e) = chunk_pack<T>(o);
             }
@@ -767,7 +773,7 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
 
 template <typename T, int LPR, int ITERS>
 int run_fwd_fast(const void* x, const void* add_in, const float* g, const float* b, void* y, void* sum_out, float* mean, float* rstd,
-                 int64_t rows, int width, hipStream_t s) {
+                 int64_t rows, int width, hipStream_t s, const void* residual) {
     auto kern = layernorm_fwd_fast_kernel<T, LPR, ITERS>;
     static int resident = 0;
     if (resident == 0) {
@@ -780,7 +786,7 @@ int run_fwd_fast(const void* x, const void* add_in, const float* g, const float*
     int64_t blocks = (int64_t)usable_cus() * (per_cu_override > 0 ? per_cu_override : resident);
     const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
     if (blocks > by_rows) blocks = by_rows;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, x, add_in, g, b, y, sum_out, mean, rstd, rows, width);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, x, add_in, g, b, y, sum_out, mean, rstd, rows, width, residual);
     HS_LAUNCH_CHECK("layernorm_fwd_fast");
     return HS_OK;
 }
@@ -856,16 +862,16 @@ int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const f
     if (rows == 0) return HS_OK;
     hipStream_t s = (hipStream_t)stream;
     static const bool fast = !(getenv("HS_LN_FWD_FAST") && atoi(getenv("HS_LN_FWD_FAST")) == 0);
-    const bool plain = fast && !residual && !ex.row_scale && ex.drop_p == 0.f && !ex.lo_in && !ex.lo_out;
+    const bool plain = fast && !(residual && add_in) && !ex.row_scale && ex.drop_p == 0.f && !ex.lo_in && !ex.lo_out;
     if (dtype == HS_BF16) {
         if (plain && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32))
-            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s); });
+            return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s, residual); });
         if (width % 8 == 0)
             return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 8, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
         return with_shape<bf16_t, 1>(width, [&](auto lpr, auto it) { return run_fwd<bf16_t, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
     }
     if (plain && width % 4 == 0 && width <= 2048 && rows * width * 4 < (1ll << 32))
-        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd_fast<float, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s); });
+        return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd_fast<float, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s, residual); });
     if (width % 4 == 0)
         return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_fwd<float, 4, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
     return with_shape<float, 1>(width, [&](auto lpr, auto it) { return run_fwd<float, 1, decltype(lpr)::value, decltype(it)::value>(x, residual, gamma, beta, y, mean, rstd, rows, width, s, add_in, sum_out, ex); });
