@@ -131,14 +131,14 @@ def measure_pmc_traffic(workload, batch, timeout_s=240):
 def pmc_traffic_per_launch(attn_agg, records=None):
     """HBM bytes per launch, averaged over this run's launch mix by matching each launch's algorithmic byte count against
     `records` (measured in this run, measure_pmc_traffic) or, without them, against the committed passes of the same kernels
-    and shapes (profiles/r04_attn_pmc_hbm_traffic.json); (None, source) if a launch shape is not covered."""
+    and shapes (profiles/r04b_attn_pmc_hbm_traffic.json); (None, source) if a launch shape is not covered."""
     source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/bench_attn.py at the same stage shapes (after the timed region)"
     if records is None:
-        path = os.path.join(ROOT, "profiles", "r04_attn_pmc_hbm_traffic.json")
+        path = os.path.join(ROOT, "profiles", "r04b_attn_pmc_hbm_traffic.json")
         if not os.path.exists(path):
             return None, None
         records = json.load(open(path))["records"]
-        source = "profiles/r04_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc passes of the same kernels and shapes; looked up: rocprofv3 unavailable or failed in this run)"
+        source = "profiles/r04b_attn_pmc_hbm_traffic.json (committed rocprofv3 --pmc passes of the same kernels and shapes; looked up: rocprofv3 unavailable or failed in this run)"
     table = _traffic_table(records)
     tot, n = 0.0, 0
     for tag, a in attn_agg.items():
