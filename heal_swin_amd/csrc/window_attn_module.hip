@@ -375,7 +375,9 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if constexpr (TRAIN) store_rows(xbase, p.xn_out);  // LayerNorm(x), whole rows from the tile the qkv product reads
+        if constexpr (TRAIN) {
+            if (has_ln) store_rows(xbase, p.xn_out);  // LayerNorm(x), whole rows from the tile the qkv product reads
+        }
 
         // ------------------------------------------------------------ q^T, k^T, v of this head: 6 accumulators, KS k-steps
         f32x16 aq[2], ak[2], av[2];
@@ -795,11 +797,11 @@ int module_fwd_impl(const char* who, const void* x, void* out, const TrainOut& t
         p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = std::min(chunk, batch - b0);
         p.N = n_tokens; p.flags = flags;
         if (tr.qkv) {
-            p.xn_out = (uint16_t*)tr.xn + t0 * channels;
+            p.xn_out = tr.xn ? (uint16_t*)tr.xn + t0 * channels : nullptr;
             p.qkv_out = (uint16_t*)tr.qkv + t0 * 3 * channels;
             p.o_out = (uint16_t*)tr.o + t0 * channels;
-            p.mean_out = tr.mean + t0;
-            p.rstd_out = tr.rstd + t0;
+            p.mean_out = tr.mean ? tr.mean + t0 : nullptr;
+            p.rstd_out = tr.rstd ? tr.rstd + t0 : nullptr;
             p.lse_out = tr.lse + t0 * num_heads;
         }
         const int rc = num_heads == 4 ? launch_module<4>(p, cosine, (hipStream_t)stream) : launch_module<3>(p, cosine, (hipStream_t)stream);
@@ -823,8 +825,8 @@ int hs_window_attn_module_fwd_train(const void* x, void* out, void* xn_out, floa
                                     const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels, int batch,
                                     int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
                                     void* stream) {
-    HS_CHECK_ARG(xn_out && mean_out && rstd_out && qkv_out && attn_out && lse_out, "hs_window_attn_module_fwd_train: null output");
-    HS_CHECK_ARG(ln_gamma && ln_beta, "hs_window_attn_module_fwd_train: the training form starts at the block's norm1");
+    HS_CHECK_ARG(qkv_out && attn_out && lse_out, "hs_window_attn_module_fwd_train: null output");
+    HS_CHECK_ARG(!ln_gamma || (xn_out && mean_out && rstd_out), "hs_window_attn_module_fwd_train: with a LayerNorm in front its output and statistics are saved too");
     TrainOut tr;
     tr.xn = xn_out; tr.qkv = qkv_out; tr.o = attn_out; tr.mean = mean_out; tr.rstd = rstd_out; tr.lse = lse_out;
     return module_fwd_impl("hs_window_attn_module_fwd_train", x, out, tr, qkv_w, qkv_b, proj_w, proj_b, ln_gamma, ln_beta, bias,

@@ -182,6 +182,12 @@ class WindowAttention(nn.Module):
             # no-grad forward of a stage whose qkv weights fit the LDS: qkv -> attention -> proj in ONE kernel
             y = self.fused_module(x, window_size, idx, roll, labels)
             return (y, x) if residual_alias else y
+        if residual is None and self.trainable_fused(x, window_size):
+            # training forward of a stage whose qkv weights fit the LDS, branch without a norm in front (v2 placement): qkv ->
+            # attention -> proj in ONE launch that also writes what the backward reads (ops.window_attn_module_train)
+            return ops.window_attn_module_train(x, None, None, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
+                                                self.bias(), self.head_scale(), idx, roll, labels, self.num_heads, window_size,
+                                                self.use_cos_attn, residual_alias=residual_alias)
         if residual_alias:
             qkv, x_res = self.qkv.forward_passthrough(x)
         else:

@@ -237,30 +237,44 @@ def window_attn_module_train_ok(x, num_heads, window_size):
 
 
 def window_attn_module_train(x, ln_weight, ln_bias, qkv_w, qkv_b, proj_w, proj_b, bias, head_scale, idx, roll, labels, num_heads,
-                             window_size, cosine):
+                             window_size, cosine, residual_alias=False):
     """x + proj(window_attention(qkv(LayerNorm(x)))) for a block on the training path (reference :315-316 around :124-174).  ONE
     kernel computes it and writes LayerNorm(x) with its statistics, qkv, the attention output and the log-sum-exp rows; the four
     autograd nodes of the composed path (LayerNormFn, LinearFn, WindowAttnCoreFn, LinearFn with the residual) are then recorded
-    around those tensors WITHOUT launching anything (`pre=`), so the backward is exactly the composed path's."""
+    around those tensors WITHOUT launching anything (`pre=`), so the backward is exactly the composed path's.
+    ln_weight None (v2 norm placement, ref :334-335): proj(window_attention(qkv(x))) without norm and residual; with residual_alias
+    the call returns (y, alias of x) as `LinearFn`'s passthrough form does (the alias' gradient rides on the qkv input-gradient GEMM)."""
     _require_gpu(x, qkv_w, proj_w, bias, head_scale, idx, labels)
     B, N, C = x.shape
     x = x.contiguous()
     dev = x.device
-    out, xn, o = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    has_ln = ln_weight is not None
+    out, o = torch.empty_like(x), torch.empty_like(x)
+    xn = torch.empty_like(x) if has_ln else None
     qkv = torch.empty((B, N, 3 * C), dtype=x.dtype, device=dev)
-    mean = torch.empty(B * N, dtype=torch.float32, device=dev)
-    rstd = torch.empty(B * N, dtype=torch.float32, device=dev)
+    mean = torch.empty(B * N, dtype=torch.float32, device=dev) if has_ln else None
+    rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if has_ln else None
     lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=dev)
     wq, wp = _cast_param(qkv_w, torch.bfloat16).contiguous(), _cast_param(proj_w, torch.bfloat16).contiguous()
     hs = _f32(head_scale).reshape(-1)
-    flags = (_lib.HS_ATTN_COSINE if cosine else 0) | _lib.HS_ATTN_RESIDUAL
+    flags = (_lib.HS_ATTN_COSINE if cosine else 0) | (_lib.HS_ATTN_RESIDUAL if has_ln else 0)
     # algorithmic traffic: x in (+ again for the residual), out + LayerNorm(x) + qkv + attention output written; flops as the module
-    with _timed("window_attn_module_fwd_train", dev, 9 * B * N * C * 2, B * N * (8 * C * C + 4 * window_size * C)):
+    with _timed("window_attn_module_fwd_train", dev, (9 if has_ln else 6) * B * N * C * 2, B * N * (8 * C * C + 4 * window_size * C)):
         check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(out), ptr(xn), ptr(mean), ptr(rstd), ptr(qkv), ptr(o), ptr(lse), ptr(wq),
                                                   ptr(_f32(qkv_b)), ptr(wp), ptr(_f32(proj_b)), ptr(_f32(ln_weight)), ptr(_f32(ln_bias)),
                                                   ptr(_f32(bias)), ptr(hs), ptr(idx), int(roll), ptr(labels), B, N, C, num_heads,
                                                   window_size, flags, _lib.HS_BF16, stream_ptr(dev)),
               "hs_window_attn_module_fwd_train")
+    if not has_ln:
+        x_res = None
+        if residual_alias:
+            qkv_t, x_res = LinearFn.apply(x, qkv_w, qkv_b, True, None, (qkv,))
+        else:
+            qkv_t = LinearFn.apply(x, qkv_w, qkv_b, False, None, (qkv,))
+        o_t = WindowAttnCoreFn.apply(qkv_t, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, 0.0, 0, (o, lse))
+        y = LinearFn.apply(o_t, proj_w, proj_b, False, None, (out,))
+        return (y, x_res) if residual_alias else y
+    assert not residual_alias
     n1, xs = LayerNormFn.apply(x, ln_weight, ln_bias, None, None, True, None, False, (xn, mean, rstd))
     qkv_t = LinearFn.apply(n1, qkv_w, qkv_b, False, None, (qkv,))
     o_t = WindowAttnCoreFn.apply(qkv_t, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, 0.0, 0, (o, lse))
@@ -975,7 +989,6 @@ class LinearFn(torch.autograd.Function):
         ctx.has_residual = residual is not None
         ctx.x3 = None
         if pre is not None:
-            assert not passthrough
             y = pre[0]
         elif residual is not None:
             # y = x W^T + b + residual: the add rides on the product's epilogue (one rounding); its gradient is dy itself

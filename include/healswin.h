@@ -334,7 +334,9 @@ int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const
                               void* stream);
 
 /* TRAINING form of the module forward (reference :315-316 around :124-174): the same single launch,
- *     out = x + proj( attention( qkv( LayerNorm(x) ) ) )            (flags: HS_ATTN_RESIDUAL as above; LayerNorm required)
+ *     out = [x +] proj( attention( qkv( [LayerNorm](x) ) ) )        (flags: HS_ATTN_RESIDUAL as above; v1 norm placement: LayerNorm +
+ *                                                                     residual, v2 placement (:334-335): neither -- xn_out, mean_out,
+ *                                                                     rstd_out NULL then, the qkv Linear's input is x itself)
  * which ALSO writes, in natural token order, everything the backward of the four reference modules reads -- so that
  * hs_add_layernorm_bwd (norm1), hs_linear_wgrad + hs_gemm_nt (qkv, proj) and hs_window_attn_bwd run on them unchanged:
  *   xn_out   [dev] bf16 [batch, n_tokens, channels]      LayerNorm(x): the qkv Linear's input

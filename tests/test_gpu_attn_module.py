@@ -140,19 +140,22 @@ def test_module_kernel_batches_beyond_the_2gib_descriptor_range():
 
 # ----------------------------------------------------------------------------- training form (hs_window_attn_module_fwd_train)
 TRAIN_CASES = [
-    # C, nH, B, nside, strategy, shift, cosine, bias, qkv_bias
-    (128, 4, 2, 16, "none", 0, False, True, True),
-    (128, 4, 2, 16, "nest_roll", 32, False, True, True),
-    (128, 4, 1, 16, "ring_shift", 4, True, True, True),
-    (128, 4, 1, 16, "nest_grid_shift", 32, True, False, False),
-    (96, 3, 2, 16, "nest_roll", 32, False, True, True),
-    (96, 3, 1, 16, "ring_shift", 4, True, True, True),
-    (96, 3, 1, 8, "nest_grid_shift", 32, False, False, False),
+    # C, nH, B, nside, strategy, shift, cosine, bias, qkv_bias, v1 (LayerNorm in front + residual behind; False: v2 placement, neither)
+    (128, 4, 2, 16, "none", 0, False, True, True, True),
+    (128, 4, 2, 16, "nest_roll", 32, False, True, True, True),
+    (128, 4, 1, 16, "ring_shift", 4, True, True, True, True),
+    (128, 4, 1, 16, "nest_grid_shift", 32, True, False, False, True),
+    (96, 3, 2, 16, "nest_roll", 32, False, True, True, True),
+    (96, 3, 1, 16, "ring_shift", 4, True, True, True, True),
+    (96, 3, 1, 8, "nest_grid_shift", 32, False, False, False, True),
+    (96, 3, 2, 16, "ring_shift", 4, True, True, True, False),
+    (128, 4, 1, 16, "nest_roll", 32, False, True, True, False),
+    (128, 4, 1, 16, "nest_grid_shift", 32, True, False, True, False),
 ]
 
 
-@pytest.mark.parametrize("C,nH,B,nside,strategy,shift,cosine,use_bias,qkv_bias", TRAIN_CASES)
-def test_module_train_form_vs_oracle_and_composition(C, nH, B, nside, strategy, shift, cosine, use_bias, qkv_bias):
+@pytest.mark.parametrize("C,nH,B,nside,strategy,shift,cosine,use_bias,qkv_bias,v1", TRAIN_CASES)
+def test_module_train_form_vs_oracle_and_composition(C, nH, B, nside, strategy, shift, cosine, use_bias, qkv_bias, v1):
     """out = x + proj(attention(qkv(LayerNorm(x)))) by ONE launch that also saves LayerNorm(x), its statistics, qkv, the attention
     output and the log-sum-exp rows; the backward is the composed path's on those tensors.  Output and EVERY gradient (x, norm
     weight / bias, qkv and proj weight / bias, bias table, head scale) against the oracle's autograd on bf16-rounded inputs, and
@@ -162,10 +165,11 @@ def test_module_train_form_vs_oracle_and_composition(C, nH, B, nside, strategy, 
     N = 8 * nside * nside
     g = torch.Generator().manual_seed(C + nside + shift + 17)
     bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
-    x = bf(torch.randn(B, N, C, generator=g) * 3.0 + 0.5)
+    x = bf(torch.randn(B, N, C, generator=g) * (3.0 if v1 else 1.0) + (0.5 if v1 else 0.0))
     P = dict(wqkv=bf(torch.randn(3 * C, C, generator=g) * C ** -0.5), wp=bf(torch.randn(C, C, generator=g) * C ** -0.5),
-             bp=torch.randn(C, generator=g) * 0.2, lng=torch.rand(C, generator=g) + 0.5, lnb=torch.randn(C, generator=g) * 0.2,
-             hscale=torch.rand(nH, generator=g) * (8 if cosine else 0.3) + 0.1)
+             bp=torch.randn(C, generator=g) * 0.2, hscale=torch.rand(nH, generator=g) * (8 if cosine else 0.3) + 0.1)
+    if v1:
+        P.update(lng=torch.rand(C, generator=g) + 0.5, lnb=torch.randn(C, generator=g) * 0.2)
     if qkv_bias:
         P["bqkv"] = torch.randn(3 * C, generator=g) * 0.2
     if use_bias:
@@ -183,7 +187,9 @@ def test_module_train_form_vs_oracle_and_composition(C, nH, B, nside, strategy, 
     xr = x.clone().requires_grad_(True)
     R = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     ref = _reference(xr, R["wqkv"], R.get("bqkv"), R["wp"], R["bp"], R.get("bias"), R["hscale"], idx, labels, nH, cosine,
-                     (R["lng"], R["lnb"]), True)
+                     (R["lng"], R["lnb"]) if v1 else None, v1)
+    if not v1:  # the block's `x + norm(branch)` uses x a second time: the alias handed back by the call carries that gradient
+        ref = ref + 0.5 * xr
     ref.backward(dout)
 
     use_roll = strategy == "nest_roll"
@@ -198,18 +204,25 @@ def test_module_train_form_vs_oracle_and_composition(C, nH, B, nside, strategy, 
         if fused:
             assert ops.window_attn_module_train_ok(xd, nH, 64)
             real = ops.lib.hs_window_attn_module_fwd_train
-            out = ops.window_attn_module_train(xd, D["lng"], D["lnb"], D["wqkv"], D.get("bqkv"), D["wp"], D["bp"], D.get("bias"),
-                                               D["hscale"], idx_d, roll, lab_d, nH, 64, cosine)
+            out = ops.window_attn_module_train(xd, D.get("lng"), D.get("lnb"), D["wqkv"], D.get("bqkv"), D["wp"], D["bp"], D.get("bias"),
+                                               D["hscale"], idx_d, roll, lab_d, nH, 64, cosine, residual_alias=not v1)
+            if not v1:
+                out = out[0] + 0.5 * out[1]
             assert real is ops.lib.hs_window_attn_module_fwd_train
             # the recorded graph: proj LinearFn <- WindowAttnCoreFn <- qkv LinearFn <- LayerNormFn, saved tensors from the kernel
-            node = out.grad_fn
+            node = out.grad_fn if v1 else out.grad_fn.next_functions[0][0]
             saved["o"] = node.saved_tensors[0]
-        else:
+        elif v1:
             n1, xs = ops.layer_norm_passthrough(xd, D["lng"], D["lnb"])
             qkv = ops.linear(n1, D["wqkv"], D.get("bqkv"))
             o = ops.window_attn_core(qkv, D.get("bias"), D["hscale"], idx_d, roll, lab_d, nH, 64, cosine)
             out = ops.linear_residual(o, D["wp"], D["bp"], xs)
             saved.update(xn=n1.detach(), qkv=qkv.detach(), o=o.detach())
+        else:
+            qkv, xs = ops.linear_passthrough(xd, D["wqkv"], D.get("bqkv"))
+            o = ops.window_attn_core(qkv, D.get("bias"), D["hscale"], idx_d, roll, lab_d, nH, 64, cosine)
+            out = ops.linear(o, D["wp"], D["bp"]) + 0.5 * xs
+            saved.update(qkv=qkv.detach(), o=o.detach())
         out.backward(dout.to(DEV).to(torch.bfloat16))
         return out.detach(), xd.grad, {k: v.grad for k, v in D.items()}, saved
 
