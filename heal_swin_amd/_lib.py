@@ -33,6 +33,9 @@ _SIGNATURES = {
     "hs_build_ring_shift": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "hs_attn_mask_from_labels": [c_ptr, c_i64, c_int, c_ptr],
     "hs_rel_bias_gather": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
+    "hs_rel_bias_scatter_grad_sorted_add": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
+    "hs_cos_head_scale_fwd": [c_ptr, c_ptr, c_int, c_ptr],
+    "hs_cos_head_scale_bwd": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr],
     "hs_rel_bias_scatter_grad": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_rel_bias_scatter_grad_sorted": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_window_attn_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,

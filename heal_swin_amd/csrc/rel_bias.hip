@@ -36,7 +36,7 @@ __global__ void rel_bias_scatter_grad_kernel(const float* __restrict__ dbias, co
 // whole index (15.8 us per attention backward before)
 __global__ void __launch_bounds__(256) rel_bias_scatter_grad_sorted_kernel(const float* __restrict__ dbias, const int32_t* __restrict__ order,
                                                                            const int32_t* __restrict__ offsets, float* __restrict__ dtable,
-                                                                           int rows, int nH, int ws2) {
+                                                                           int rows, int nH, int ws2, int accumulate) {
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
     const bool live = g < rows * nH;
     const int t = live ? g / nH : 0, h = live ? g - t * nH : 0;
@@ -46,7 +46,23 @@ __global__ void __launch_bounds__(256) rel_bias_scatter_grad_sorted_kernel(const
     for (int k = k0 + sub; k < k1; k += 16) acc += dbias[(int64_t)h * ws2 + order[k]];
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (live && sub == 0) dtable[g] = acc;
+    if (live && sub == 0) dtable[g] = accumulate ? dtable[g] + acc : acc;
+}
+
+// Cosine attention's per-head score scale (ref swin_hp_transformer.py:144-147): scale = exp(min(logit_scale, ln 100)), and its
+// backward d logit_scale = d scale * scale * [logit_scale <= ln 100] -- one launch each instead of torch's clamp / exp / mul /
+// compare / where kernels (seven launches of a few microseconds per block and step; 24 blocks in HEAL-SWIN-T)
+constexpr float kLogitMax = 4.605170185988092f;  // ln(1 / 0.01)
+__global__ void __launch_bounds__(64) cos_scale_kernel(const float* __restrict__ ls, const float* __restrict__ dscale, float* __restrict__ out,
+                                                       int n, int accumulate) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float l = ls[i], s = __expf(fminf(l, kLogitMax));
+    if (!dscale) out[i] = s;
+    else {
+        const float d = l <= kLogitMax ? dscale[i] * s : 0.f;
+        out[i] = accumulate ? out[i] + d : d;
+    }
 }
 
 }  // namespace
@@ -79,8 +95,34 @@ int hs_rel_bias_scatter_grad_sorted(const float* dbias, const int32_t* order, co
     HS_CHECK_ARG(dbias && order && offsets && dtable && table_rows > 0 && num_heads > 0 && window_size > 0, "bad arguments");
     const int n = table_rows * num_heads * 16;
     hipLaunchKernelGGL(rel_bias_scatter_grad_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dbias, order,
-                       offsets, dtable, table_rows, num_heads, window_size * window_size);
+                       offsets, dtable, table_rows, num_heads, window_size * window_size, 0);
     HS_LAUNCH_CHECK("rel_bias_scatter_grad_sorted");
+    return HS_OK;
+}
+
+int hs_rel_bias_scatter_grad_sorted_add(const float* dbias, const int32_t* order, const int32_t* offsets, float* dtable,
+                                        int table_rows, int num_heads, int window_size, void* stream) {
+    HS_CHECK_ARG(dbias && order && offsets && dtable && table_rows > 0 && num_heads > 0 && window_size > 0, "bad arguments");
+    const int n = table_rows * num_heads * 16;
+    hipLaunchKernelGGL(rel_bias_scatter_grad_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dbias, order,
+                       offsets, dtable, table_rows, num_heads, window_size * window_size, 1);
+    HS_LAUNCH_CHECK("rel_bias_scatter_grad_sorted_add");
+    return HS_OK;
+}
+
+int hs_cos_head_scale_fwd(const float* logit_scale, float* scale, int num_heads, void* stream) {
+    HS_CHECK_ARG(logit_scale && scale && num_heads > 0, "hs_cos_head_scale_fwd: bad arguments");
+    hipLaunchKernelGGL(cos_scale_kernel, dim3((num_heads + 63) / 64), dim3(64), 0, (hipStream_t)stream, logit_scale, (const float*)nullptr,
+                       scale, num_heads, 0);
+    HS_LAUNCH_CHECK("cos_head_scale_fwd");
+    return HS_OK;
+}
+
+int hs_cos_head_scale_bwd(const float* logit_scale, const float* dscale, float* dlogit_scale, int num_heads, int accumulate, void* stream) {
+    HS_CHECK_ARG(logit_scale && dscale && dlogit_scale && num_heads > 0, "hs_cos_head_scale_bwd: bad arguments");
+    hipLaunchKernelGGL(cos_scale_kernel, dim3((num_heads + 63) / 64), dim3(64), 0, (hipStream_t)stream, logit_scale, dscale, dlogit_scale,
+                       num_heads, accumulate);
+    HS_LAUNCH_CHECK("cos_head_scale_bwd");
     return HS_OK;
 }
 

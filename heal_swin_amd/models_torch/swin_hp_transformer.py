@@ -160,6 +160,8 @@ class WindowAttention(nn.Module):
     def head_scale(self):
         """Per-head multiplier of the raw scores: exp(min(logit_scale, ln 100)) (ref :144-147) or the qk scale."""
         if self.use_cos_attn:
+            if self.logit_scale.is_cuda and self.logit_scale.dtype == torch.float32:
+                return ops.cos_head_scale(self.logit_scale)  # one launch forward, one backward
             return torch.exp(torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01))).reshape(-1)
         dev = self.qkv.weight.device
         if self._scale_cache is None or self._scale_cache.device != dev:

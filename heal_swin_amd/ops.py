@@ -74,6 +74,7 @@ class RelPosBiasFn(torch.autograd.Function):
         ctx.save_for_backward(rel_idx)
         ctx.shape = (rows, nh, window_size)
         ctx.table_dtype = table.dtype
+        ctx.table = table if table.dtype == torch.float32 else None
         return bias
 
     @staticmethod
@@ -81,11 +82,49 @@ class RelPosBiasFn(torch.autograd.Function):
         (rel_idx,) = ctx.saved_tensors
         rows, nh, ws = ctx.shape
         dbias = dbias.to(torch.float32).contiguous()
-        dtable = torch.empty((rows, nh), dtype=torch.float32, device=dbias.device)
         order, offsets = _rel_idx_groups(rel_idx, rows)
+        buf = _sink_buffer(ctx.table)
+        if buf is not None:  # straight into the gradient sink's buffer (no AccumulateGrad add kernel)
+            check(lib.hs_rel_bias_scatter_grad_sorted_add(ptr(dbias), ptr(order), ptr(offsets), ptr(buf), rows, nh, ws,
+                                                          stream_ptr(dbias.device)), "hs_rel_bias_scatter_grad_sorted_add")
+            GRAD_SINK.deposited(ctx.table)
+            return None, None, None
+        dtable = torch.empty((rows, nh), dtype=torch.float32, device=dbias.device)
         check(lib.hs_rel_bias_scatter_grad_sorted(ptr(dbias), ptr(order), ptr(offsets), ptr(dtable), rows, nh, ws,
                                                   stream_ptr(dbias.device)), "hs_rel_bias_scatter_grad_sorted")
         return dtable.to(ctx.table_dtype), None, None
+
+
+class CosHeadScaleFn(torch.autograd.Function):
+    """exp(min(logit_scale, ln 100)) per head (reference swin_hp_transformer.py:144-147) in one launch, backward in one launch that
+    deposits straight into the gradient sink where one is installed (torch: clamp, exp + mul, compare, where, add_)."""
+
+    @staticmethod
+    def forward(ctx, logit_scale):
+        _require_gpu(logit_scale)
+        ls = logit_scale.detach().reshape(-1)
+        out = torch.empty_like(ls)
+        check(lib.hs_cos_head_scale_fwd(ptr(ls), ptr(out), ls.numel(), stream_ptr(ls.device)), "hs_cos_head_scale_fwd")
+        ctx.param = logit_scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dscale):
+        p = ctx.param
+        ls = p.detach().reshape(-1)
+        dscale = dscale.to(torch.float32).contiguous()
+        buf = _sink_buffer(p)
+        if buf is not None:
+            check(lib.hs_cos_head_scale_bwd(ptr(ls), ptr(dscale), ptr(buf.view(-1)), ls.numel(), 1, stream_ptr(ls.device)), "hs_cos_head_scale_bwd")
+            GRAD_SINK.deposited(p)
+            return None
+        d = torch.empty_like(ls)
+        check(lib.hs_cos_head_scale_bwd(ptr(ls), ptr(dscale), ptr(d), ls.numel(), 0, stream_ptr(ls.device)), "hs_cos_head_scale_bwd")
+        return d.view(p.shape)
+
+
+def cos_head_scale(logit_scale):
+    return CosHeadScaleFn.apply(logit_scale)
 
 
 _REL_IDX_GROUPS = {}

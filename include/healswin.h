@@ -124,6 +124,14 @@ int hs_rel_bias_scatter_grad(const float* dbias, const int32_t* rel_idx, float* 
  * int32[T + 1] = start of each row's run in `order`.  One thread per (t, h), entries added in ascending (i, j) order. */
 int hs_rel_bias_scatter_grad_sorted(const float* dbias, const int32_t* order, const int32_t* offsets, float* dtable,
                                     int table_rows, int num_heads, int window_size, void* stream);
+/* ... ADDED to dtable (an fp32 gradient buffer that already holds other contributions). */
+int hs_rel_bias_scatter_grad_sorted_add(const float* dbias, const int32_t* order, const int32_t* offsets, float* dtable,
+                                        int table_rows, int num_heads, int window_size, void* stream);
+/* Cosine attention's per-head score scale, models_torch/swin_hp_transformer.py:144-147:
+ *   scale[h] = exp(min(logit_scale[h], ln 100));   d logit_scale[h] = d scale[h] * scale[h] * [logit_scale[h] <= ln 100]
+ * (overwritten, or added to when accumulate != 0).  All [dev] f32[num_heads]. */
+int hs_cos_head_scale_fwd(const float* logit_scale, float* scale, int num_heads, void* stream);
+int hs_cos_head_scale_bwd(const float* logit_scale, const float* dscale, float* dlogit_scale, int num_heads, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused  shift -> window_partition -> attention core -> window_reverse -> shift_back.

@@ -834,3 +834,40 @@ def test_gelu_split3_equals_gelu_then_split(drop_p):
         # and hi + lo reproduces the fp32 value to 2^-16
         hi, lo = out3[:, :k].float(), out3[:, 2 * k:].float()
         assert float((hi + lo - ref).abs().max()) <= 2.0 ** -15 * float(ref.abs().max())
+
+
+def test_cos_head_scale_matches_the_torch_formula():
+    """exp(clamp(logit_scale, max=ln 100)) (ref :144-147) and its gradient in one launch each, including a head beyond the clamp and
+    one exactly on it; `accumulate` adds into an existing buffer."""
+    import math
+    ops, _, _ = _mods()
+    from heal_swin_amd._lib import check, lib, ptr
+    ls = torch.tensor([[[0.3]], [[2.3026]], [[math.log(100.0)]], [[5.0]], [[-1.0]]], device=DEV, requires_grad=True)
+    ref_in = ls.detach().clone().requires_grad_(True)
+    ref = torch.exp(torch.clamp(ref_in, max=math.log(1.0 / 0.01))).reshape(-1)
+    out = ops.cos_head_scale(ls)
+    g = torch.tensor([1.0, -2.0, 0.5, 3.0, 0.25], device=DEV)
+    ref.backward(g)
+    out.backward(g)
+    assert_close(out, ref, 1e-6, "scale")
+    assert_close(ls.grad, ref_in.grad, 1e-6, "d logit_scale")
+    assert float(ls.grad.reshape(-1)[3]) == 0.0
+    buf = torch.ones(5, device=DEV)
+    check(lib.hs_cos_head_scale_bwd(ptr(ls.detach().reshape(-1)), ptr(g), ptr(buf), 5, 1, None), "bwd")
+    assert_close(buf - 1.0, ref_in.grad.reshape(-1), 1e-6, "accumulated d logit_scale")
+
+
+def test_rel_bias_scatter_grad_sorted_add_accumulates():
+    ops, _, _ = _mods()
+    from heal_swin_amd import _lib
+    from heal_swin_amd._lib import check, lib, ptr
+    ws, nh = 64, 4
+    rel = torch.from_numpy(_lib.rel_pos_index(ws).astype(np.int32).reshape(-1)).to(DEV)
+    rows = int(rel.max()) + 1
+    dbias = torch.randn(nh, ws, ws, device=DEV)
+    order, offsets = ops._rel_idx_groups(rel, rows)
+    ref = torch.empty(rows, nh, device=DEV)
+    check(lib.hs_rel_bias_scatter_grad_sorted(ptr(dbias), ptr(order), ptr(offsets), ptr(ref), rows, nh, ws, None), "scatter")
+    acc = torch.full((rows, nh), 2.0, device=DEV)
+    check(lib.hs_rel_bias_scatter_grad_sorted_add(ptr(dbias), ptr(order), ptr(offsets), ptr(acc), rows, nh, ws, None), "scatter add")
+    assert torch.equal(acc, ref + 2.0)
