@@ -34,6 +34,7 @@
 // All LDS traffic of the main phases is inline asm: a compiler-visible LDS access beside the DMA queue would be preceded by
 // s_waitcnt vmcnt(0) and serialise the next window's loads behind every phase.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "window_attn.h"
@@ -74,6 +75,8 @@ struct ModParams {
     int64_t N;
     int slots;
     unsigned flags;
+    int dma_mode;  // where the next window's x tile is requested (HS_MOD_DMA, A/B): 0 (default) = in front of the LayerNorm, 1 = behind the
+                   // second k-step of the qkv product, 2 = one piece behind each of its first k-steps
     // training form (null in the inference form), natural token order
     uint16_t* xn_out;   // [B, N, C]   LayerNorm(x): input of the qkv product (its weight gradient reads it)
     uint16_t* qkv_out;  // [B, N, 3C]  as the qkv Linear would have written it
@@ -81,6 +84,9 @@ struct ModParams {
     float* mean_out;    // [B, N]      LayerNorm statistics
     float* rstd_out;
     float* lse_out;     // [B, nH, N]  log-sum-exp of every score row, by SHIFTED position (as hs_window_attn_fwd)
+#ifdef HS_MOD_TRACE
+    unsigned long long* trace;  // measurement build: shader-clock stamps [wave][window < 8][phase < 16] of workgroup 0
+#endif
 };
 constexpr unsigned kFlagResidual = 4u;  // out = x + module(x)   (HS_ATTN_RESIDUAL)
 
@@ -204,9 +210,9 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
     auto prow_of = [&](int j) { return ((wave + NH * j) * 64 + lane_o) >> 4; };
     auto pchunk_of = [&](int j) { return (lane_o & 15) ^ (prow_of(j) & 15); };
     uint32_t tok[XP], tok_next[XP];  // token (row of this launch's x) of this lane's piece rows: current / next window (< 2^30: the chunk limit)
-    auto tokens_of = [&](int64_t wi, uint32_t (&t)[XP]) {
-        const int b = (int)(wi / nW);
-        const int64_t j0 = (wi - (int64_t)b * nW) * kWs;
+    // a window = (image b, window r of that image); the loop advances the pair by `slots` windows without a division
+    auto tokens_of = [&](int b, int r, uint32_t (&t)[XP]) {
+        const int64_t j0 = (int64_t)r * kWs;
 #pragma unroll
         for (int j = 0; j < XP; ++j) {
             const int64_t js = j0 + (prow_of(j) & 63);  // shifted position -> natural-order token (gather = scatter map)
@@ -219,26 +225,25 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             t[j] = (uint32_t)((int64_t)b * N + src);
         }
     };
-    auto issue_x = [&](const uint32_t (&t)[XP], int64_t wi, int buf) {
+    auto issue_x = [&](const uint32_t (&t)[XP], int r, int buf, int only = -1) {  // only >= 0: piece `only` (and the labels with piece 0)
 #pragma unroll
         for (int j = 0; j < XP; ++j) {
+            if (only >= 0 && j != only) continue;
             const int pc = wave + NH * j;
             if (pc < 16) {
                 const uint32_t voff = pchunk_of(j) < NCH ? (uint32_t)(t[j] * (C * 2) + pchunk_of(j) * 16) : kOob;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(smem + X_OFF + buf * (kWs * kRowB) + pc * 1024), 16, voff, 0, 0, 0);
             }
         }
-        if (wave == 0 && p.labels) {  // 64 label bytes = 16 dwords; the other lanes read past the descriptor (zeros)
-            const int64_t j0 = (wi % nW) * kWs;
-            const uint32_t voff = lane < 16 ? (uint32_t)(j0 + lane * 4) : kOob;
+        if (only <= 0 && wave == 0 && p.labels) {  // 64 label bytes = 16 dwords; the other lanes read past the descriptor (zeros)
+            const uint32_t voff = lane < 16 ? (uint32_t)(r * kWs + lane * 4) : kOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void*)(smem + M_OFF + buf * 256), 4, voff, 0, 0, 0);
         }
     };
 
-    auto note_tokens = [&](int64_t w, int buf) {  // (training form) row -> token table of window w
+    auto note_tokens = [&](int b, int r, int buf) {  // (training form) row -> token table of window (b, r)
         if (tid < kWs) {
-            const int b = (int)(w / nW);
-            const int64_t js = (w - (int64_t)b * nW) * kWs + tid;
+            const int64_t js = (int64_t)r * kWs + tid;
             int64_t src;
             if (p.idx) src = p.idx[js];
             else {
@@ -262,10 +267,19 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
         }
     };
 
+#ifdef HS_MOD_TRACE
+    int tr_w = 0;
+    auto TR = [&](int ph) {
+        if (p.trace && blockIdx.x == 0 && tr_w < 8 && lane == 0) p.trace[(wave * 8 + tr_w) * 16 + ph] = clock64();
+    };
+#else
+    auto TR = [&](int) {};
+#endif
     int64_t wi = blockIdx.x;
-    tokens_of(wi, tok);
-    issue_x(tok, wi, 0);
-    if constexpr (TRAIN) note_tokens(wi, 0);
+    int b_c = (int)((uint32_t)blockIdx.x / (uint32_t)nW), r_c = (int)((uint32_t)blockIdx.x - (uint32_t)b_c * (uint32_t)nW);
+    tokens_of(b_c, r_c, tok);
+    issue_x(tok, r_c, 0);
+    if constexpr (TRAIN) note_tokens(b_c, r_c, 0);
     int cur = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weights and the first window's x rows have landed
     const uint32_t wbase = lds0 + W_OFF, obase = lds0 + O_OFF;
@@ -273,14 +287,20 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
     for (; wi < total_windows; wi += p.slots) {
         asm volatile("" : "+v"(lane_o));
         const bool more = wi + p.slots < total_windows;
-        if (more) tokens_of(wi + p.slots, tok_next);
+        int b_n = b_c, r_n = r_c + p.slots;
+        while (r_n >= nW) {
+            r_n -= nW;
+            ++b_n;
+        }
+        if (more) tokens_of(b_n, r_n, tok_next);
         // (this wave's pieces of the window's x tile were waited for in front of the previous window's output stores -- not here,
         // where a vmcnt(0) would also wait for those stores' acknowledgements: 1-2 k cycles per window with nothing else to run)
         if constexpr (TRAIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first window's token table)
         __builtin_amdgcn_s_barrier();
+        TR(0);
         const uint32_t xbase = lds0 + X_OFF + cur * (kWs * kRowB), tbase = lds0 + T_OFF + cur * 256;
         if constexpr (TRAIN) {
-            if (more) note_tokens(wi + p.slots, cur ^ 1);  // read from the next window's first barrier on
+            if (more) note_tokens(b_n, r_n, cur ^ 1);  // read from the next window's first barrier on
         }
         // region labels of this window (fetched with its x tile into label patch `cur`): 16 words, every lane reads all
         // (the words are read again where a cut window needs them: 16 registers held across every phase cost the training form spills)
@@ -300,7 +320,10 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
 #pragma unroll
             for (int i = 0; i < 16; ++i) mixed |= labw[i] != first;
         }
-        if (more) issue_x(tok_next, wi + p.slots, cur ^ 1);  // in flight during everything below
+        // (requested here, as early as the buffer is free.  Moving the ~100 issue cycles per LDS-DMA piece into the shadow of the qkv
+        // product's MFMAs -- dma_mode 1 / 2 -- shortens this phase by 400 cycles in the in-kernel timeline and LENGTHENS the launch by
+        // 3-6 %: the tile then arrives later than the stores of this window start to compete with it)
+        if (more && p.dma_mode == 0) issue_x(tok_next, r_n, cur ^ 1);
 
         // ------------------------------------------------------------ optional LayerNorm of the 64 rows, in place
         if (has_ln) {
@@ -375,16 +398,19 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        TR(1);
         if constexpr (TRAIN) {
             if (has_ln) store_rows(xbase, p.xn_out);  // LayerNorm(x), whole rows from the tile the qkv product reads
         }
+        TR(2);
 
         // ------------------------------------------------------------ q^T, k^T, v of this head: 6 accumulators, KS k-steps
         f32x16 aq[2], ak[2], av[2];
-        uint32_t ltok[2] = {0u, 0u};  // (training form) tokens of this lane's two rows
+        uint32_t ltok[4] = {0u, 0u, 0u, 0u};  // (training form) tokens of the rows lane / 4 + 16 i this lane stores qkv pieces of
         if constexpr (TRAIN) {
-            asm volatile("ds_read_b32 %0, %1" : "=v"(ltok[0]) : "v"(tbase + l31 * 4));
-            asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(ltok[1]) : "v"(tbase + l31 * 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ltok[i]) : "v"(tbase + (lane >> 2) * 4), "n"(64 * i));
         }
         {   // accumulators start at the bias: q^T / k^T rows d = 8 g + 4 half + 0..3 (group g = r / 4), v column d = l31
             u32x4 bqv[4], bkv[4];
@@ -395,7 +421,7 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(bqv[0]), "+v"(bqv[1]), "+v"(bqv[2]), "+v"(bqv[3]), "+v"(bkv[0]), "+v"(bkv[1]), "+v"(bkv[2]), "+v"(bkv[3]));
-            if constexpr (TRAIN) asm volatile("" : "+v"(ltok[0]), "+v"(ltok[1]));
+            if constexpr (TRAIN) asm volatile("" : "+v"(ltok[0]), "+v"(ltok[1]), "+v"(ltok[2]), "+v"(ltok[3]));
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -434,9 +460,14 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                     ak[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fw[set][1]), as_frag(fx[set][t]), ak[t], 0, 0, 0);
                     av[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fx[set][t]), as_frag(fw[set][2]), av[t], 0, 0, 0);
                 }
+                if (more) {  // in flight during everything below
+                    if (p.dma_mode == 1 && ks == 1) issue_x(tok_next, r_n, cur ^ 1);
+                    if (p.dma_mode == 2 && ks < XP) issue_x(tok_next, r_n, cur ^ 1, ks);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        TR(3);
         // ---- bf16 rounding of q^T, k^T, v: ONE packing serves the MFMA operands, the cosine norms and (training form) the stored rows;
         // the fp32 accumulators are dead behind it.  Word i of a tile = registers 2i, 2i+1.
         uint32_t qw[2][8], kw[2][8];
@@ -451,18 +482,53 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
 #pragma unroll
             for (int c = 0; c < 2; ++c) vf[t][c] = pack8(av[t], 8 * c);
         }
-        if constexpr (TRAIN) {  // the q and k rows as the Linear would have stored them: 64-byte head slices, two 16-byte pieces per lane
+        if constexpr (TRAIN) {
+            // The q, k and v rows as the qkv Linear would have stored them.  Row-per-lane 16-byte stores (64 rows, 64 partial
+            // lines per instruction) cost this phase 2100 + 1500 cycles of a 19 000-cycle window (in-kernel timeline, -DHS_MOD_TRACE):
+            // the L1 -> L2 path takes a transaction per lane.  Each tensor therefore passes through the wave's OWN 64-byte column
+            // block of the (idle) O tile -- written in the accumulator layout, read back with four adjacent lanes on the four
+            // 16-byte units of one token's head slice -- so an instruction stores 16 tokens x 64 contiguous bytes.  No barrier:
+            // nobody else touches these columns before the O barrier.  v comes from the [feature][token] accumulators by 2-byte
+            // writes (one per packed half), which also replaces the second, transposed v product of the first version.
+            const uint32_t rd = obase + (uint32_t)(lane >> 2) * kRowB;  // rows lane / 4 + 16 i, unit lane % 4 of this wave's block
+            auto flush = [&](int sel) {
+                u32x4 pc[4];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                uint16_t* dst = p.qkv_out + (int64_t)ltok[t] * (3 * C) + 32 * wave + 8 * half;
-                u32x4 p0, p1;
-                swap_rows_t(qw[t], p0, p1);
-                *(u32x4*)dst = p0;
-                *(u32x4*)(dst + 16) = p1;
-                swap_rows_t(kw[t], p0, p1);
-                *(u32x4*)(dst + C) = p0;
-                *(u32x4*)(dst + C + 16) = p1;
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lane >> 2) + 16 * i;
+                    pc[i] = ld128(rd + (uint32_t)(16 * i) * kRowB + (uint32_t)(((4 * wave + (lane & 3)) ^ (row & 15)) << 4));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *(u32x4*)(p.qkv_out + (int64_t)ltok[i] * (3 * C) + sel * C + 32 * wave + 8 * (lane & 3)) = pc[i];
+            };
+            auto stage_t = [&](const uint32_t (&w)[2][8]) {  // q^T / k^T: lane = token, word pair (2 g, 2 g + 1) = 4 features 8 g + 4 half ..
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) st64(obase + swz(t * 32 + l31, 4 * wave + g) + 8 * half, w[t][2 * g], w[t][2 * g + 1]);
+            };
+            stage_t(qw);
+            flush(0);
+            stage_t(kw);
+            flush(1);
+            // v: lane = feature d = l31 (+ half: tokens 4 half ..), word i of tile t = tokens (2 i & 3) + 8 (i >> 1) + 4 half and the next
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int tk = t * 32 + ((2 * i) & 3) + 8 * (i >> 1);  // + 4 half; the partner token is tk + 1
+                    const uint32_t w = __builtin_bit_cast(u32x4, vf[t][i >> 2])[i & 3];
+                    const int row0 = tk + 4 * half;  // (row & 15) of tk + 4 half and of tk + 1 + 4 half differ: two addresses
+                    const uint32_t a0 = obase + swz(row0, 4 * wave + (l31 >> 3)) + (l31 & 7) * 2;
+                    const uint32_t a1 = obase + swz(row0 + 1, 4 * wave + (l31 >> 3)) + (l31 & 7) * 2;
+                    asm volatile("ds_write_b16 %0, %1" ::"v"(a0), "v"(w) : "memory");
+                    asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(a1), "v"(w) : "memory");
+                }
+            flush(2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         // cosine attention: k rows normalised, 1 / |q| folded into the per-query score factor.  The norms are those of the bf16
         // rows (what hs_window_attn_fwd / _bwd see in the stored qkv tensor), so that the saved log-sum-exp matches the scores
@@ -496,56 +562,8 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                 kf[t][c] = __builtin_bit_cast(bf16x8, u32x4{kw[t][4 * c], kw[t][4 * c + 1], kw[t][4 * c + 2], kw[t][4 * c + 3]});
             }
 
-        if constexpr (TRAIN) {
-            // v a second time as v^T (lane = token like q^T and k^T) for the row-major qkv rows the backward reads: 16 MFMAs in a pass of
-            // their own, behind the packing of q / k / v (the fp32 accumulators of the main pass are dead: a seventh and eighth
-            // accumulator inside it spilled 80 registers), cheaper than a transposing pass through LDS with two more barriers
-            f32x16 avt[2];
-            {
-                u32x4 bvv[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bvv[g] = ld128(pbase + (P_BV + 32 * wave + 8 * g + 4 * half) * 4);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bvv[0]), "+v"(bvv[1]), "+v"(bvv[2]), "+v"(bvv[3]));
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) avt[t][r] = __uint_as_float(bvv[r >> 2][r & 3]);
-            }
-            const uint32_t xa0 = xbase + l31 * kRowB, xa1 = xbase + (32 + l31) * kRowB;
-            const uint32_t wv = wbase + (2 * C + 32 * wave + l31) * kRowB;
-            const int sx = l31 & 15;
-            u32x4 fx[2][2], fw[2];
-            auto reads = [&](int ks, int set) {
-                const uint32_t co = (uint32_t)(((2 * ks + half) ^ sx) << 4);
-                fx[set][0] = ld128(xa0 + co);
-                fx[set][1] = ld128(xa1 + co);
-                fw[set] = ld128(wv + co);
-            };
-            reads(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int set = ks & 1;
-                if (ks + 1 < KS) {
-                    reads(ks + 1, set ^ 1);
-                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fx[set][0]), "+v"(fx[set][1]), "+v"(fw[set]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[set][0]), "+v"(fx[set][1]), "+v"(fw[set]));
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    avt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fw[set]), as_frag(fx[set][t]), avt[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                uint16_t* dst = p.qkv_out + (int64_t)ltok[t] * (3 * C) + 2 * C + 32 * wave + 8 * half;
-                u32x4 p0, p1;
-                pack_rows_t(avt[t], p0, p1);
-                *(u32x4*)dst = p0;
-                *(u32x4*)(dst + 16) = p1;
-            }
-        }
-
+        TR(4);
+        TR(5);
         // ------------------------------------------------------------ S^T = k q^T, softmax over keys (log2 domain)
         f32x16 acc[2][2];
 #pragma unroll
@@ -612,13 +630,12 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                 for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv;
             if constexpr (TRAIN) {
                 if (half == 0) {
-                    const int b = (int)(wi / nW);
-                    const int64_t j0 = (wi - (int64_t)b * nW) * kWs;
-                    p.lse_out[((int64_t)b * NH + wave) * N + j0 + qt * 32 + l31] = (m + __builtin_amdgcn_logf(l)) * kLn2;
+                    p.lse_out[((int64_t)b_c * NH + wave) * N + (int64_t)r_c * kWs + qt * 32 + l31] = (m + __builtin_amdgcn_logf(l)) * kLn2;
                 }
             }
         }
 
+        TR(6);
         // ------------------------------------------------------------ O^T = v^T P^T  (rows = features, columns = queries)
         f32x16 ao[2];
 #pragma unroll
@@ -642,7 +659,9 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                      pack_bf16x2(ao[qt][4 * g + 2], ao[qt][4 * g + 3]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TR(7);
         __builtin_amdgcn_s_barrier();  // O tile complete; every wave is done with the x tile
+        TR(8);
         if constexpr (TRAIN) store_rows(obase, p.o_out);
         // the residual operand (x rows of this wave's output pieces; L2 hits) is requested here, under the proj product
         // (unconditional, straight-line loads -- pieces that do not exist read row 0 -- pinned here by the scheduling barrier:
@@ -701,12 +720,15 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                      pack_bf16x2(ay[t][4 * g + 2], ay[t][4 * g + 3]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TR(9);
         __builtin_amdgcn_s_barrier();  // staged tile complete; every wave is done with the O tile
+        TR(10);
 
         // ------------------------------------------------------------ whole token rows -> out[token] (the scatter half of the shift)
         {
             // the NEXT window's x rows (requested a window ago) have landed, and with them everything this window has stored so far
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TR(12);
             u32x4 rows[XP];
 #pragma unroll
             for (int j = 0; j < XP; ++j)
@@ -728,6 +750,12 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                 }
             }
         }
+        TR(11);
+#ifdef HS_MOD_TRACE
+        ++tr_w;
+#endif
+        b_c = b_n;
+        r_c = r_n;
 #pragma unroll
         for (int j = 0; j < XP; ++j) tok[j] = tok_next[j];
         cur ^= 1;
@@ -764,6 +792,15 @@ int hs_window_attn_module_supported(int channels, int num_heads, int window_size
     return dtype == HS_BF16 && window_size == hs::kWs && num_heads * 32 == channels && (channels == 96 || channels == 128);
 }
 
+#ifdef HS_MOD_TRACE
+namespace {
+unsigned long long* g_mod_trace = nullptr;
+}
+int hs_window_attn_module_set_trace(void* buf) {
+    g_mod_trace = (unsigned long long*)buf;
+    return 0;
+}
+#endif
 namespace {
 struct TrainOut {
     void *xn = nullptr, *qkv = nullptr, *o = nullptr;
@@ -796,6 +833,11 @@ int module_fwd_impl(const char* who, const void* x, void* out, const TrainOut& t
         p.proj_w = (const uint16_t*)proj_w; p.proj_b = proj_b; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.bias = bias;
         p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = std::min(chunk, batch - b0);
         p.N = n_tokens; p.flags = flags;
+        static const int dma_mode = getenv("HS_MOD_DMA") ? atoi(getenv("HS_MOD_DMA")) : 0;
+        p.dma_mode = dma_mode;
+#ifdef HS_MOD_TRACE
+        p.trace = g_mod_trace;
+#endif
         if (tr.qkv) {
             p.xn_out = tr.xn ? (uint16_t*)tr.xn + t0 * channels : nullptr;
             p.qkv_out = (uint16_t*)tr.qkv + t0 * 3 * channels;
