@@ -53,7 +53,7 @@ class _SegCrossEntropyFn(torch.autograd.Function):
             from . import ops
             full = torch.zeros((B, P, sp), dtype=logits.dtype, device=logits.device)
             dl = full[:, :, :K].transpose(1, 2)
-            ops.ZERO_PADDED_GRADS[full.data_ptr()] = full  # weak: the entry lives exactly as long as the gradient does
+            ops.RT.zero_padded_grads[full.data_ptr()] = full  # weak: the entry lives exactly as long as the gradient does
         else:
             dl = torch.empty_like(logits)
         scale = (grad.to(torch.float32) / tot[1]).reshape(1)

@@ -798,14 +798,14 @@ class SwinHPTransformerSys(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("SwinHPTransformerSys (heal_swin_amd) runs only on an MI355X (HIP) device; there is no CPU path")
         dt = self._activation_dtype(x)
-        prev, ops.CAST_CACHE = ops.CAST_CACHE, self._param_casts(dt)
-        ops.LAST_CAST_CACHE = ops.CAST_CACHE
+        prev, ops.RT.cast_cache = ops.RT.cast_cache, self._param_casts(dt)
+        ops.RT.last_cast_cache = ops.RT.cast_cache
         try:
             with torch.autocast(device_type="cuda", enabled=False):
                 x, x_downsample = self.forward_features(x.to(dt))
                 return self.decoder(x, x_downsample)
         finally:
-            ops.CAST_CACHE = prev
+            ops.RT.cast_cache = prev
 
     def forward_seg_loss(self, x, labels, class_weights=None):
         """nn.CrossEntropyLoss(weight=class_weights)(self(x), labels.long()) -- the segmentation caller's training step
@@ -819,14 +819,14 @@ class SwinHPTransformerSys(nn.Module):
             labels = labels.to(torch.uint8)
         w = None if class_weights is None else class_weights.to(device=x.device, dtype=torch.float32).contiguous()
         dt = self._activation_dtype(x)
-        prev, ops.CAST_CACHE = ops.CAST_CACHE, self._param_casts(dt)
-        ops.LAST_CAST_CACHE = ops.CAST_CACHE
+        prev, ops.RT.cast_cache = ops.RT.cast_cache, self._param_casts(dt)
+        ops.RT.last_cast_cache = ops.RT.cast_cache
         try:
             with torch.autocast(device_type="cuda", enabled=False):
                 x, x_downsample = self.forward_features(x.to(dt))
                 return self.decoder(x, x_downsample, ce=(labels, w))
         finally:
-            ops.CAST_CACHE = prev
+            ops.RT.cast_cache = prev
 
     def _param_casts(self, dt):
         """bf16 copies of the Linear parameters, re-made in one multi-tensor kernel after each optimizer step (ops.ParamCastCache)."""

@@ -3,6 +3,7 @@
 PyTorch owns the memory (caching allocator), the stream and the autograd graph; every arithmetic step
 below runs in the HIP library.  All ops require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
 """
+import contextlib
 import math
 import os
 import weakref
@@ -17,6 +18,40 @@ from ._lib import check, lib, ptr, stream_ptr
 # with events recorded on the stream the kernel runs on, and (tag, start, end, algorithmic_bytes, flops) is appended.
 KERNEL_TIMINGS = None
 TIMED_PREFIXES = None  # None: every tagged launch; else only tags starting with one of these (each bracket costs ~3 us of stream time)
+
+
+class RuntimeState:
+    """The process-wide switches the ops consult, in ONE object (`ops.RT`) instead of six module globals:
+      grad_sink          gradient sink with flat fp32 buckets (a parallel.GradBucketAllReduce) that kernels ADD parameter gradients into, or None
+      async_wgrad        an AsyncWgrad (side stream for the weight-gradient kernels), or None
+      cast_cache         the ParamCastCache of the model forward that is running (set by SwinHPTransformerSys.forward), or None
+      last_cast_cache    that of the most recent forward: what a backward falls back to when its node kept none
+      prefer_own_gemm    every legal bf16 Linear product on hs_gemm_nt (set while CUs are reserved for a communication library)
+      zero_padded_grads  data_ptr -> zero-padded gradient buffer written by losses.seg_loss' backward (weak values, see PadSliceFn)
+    One training setup per process is the supported configuration (as with DistributedDataParallel); `scoped` swaps fields for the
+    duration of a block and restores them, which is how nested / temporary configurations should be expressed."""
+
+    def __init__(self):
+        self.grad_sink = None
+        self.async_wgrad = None
+        self.cast_cache = None
+        self.last_cast_cache = None
+        self.prefer_own_gemm = False
+        self.zero_padded_grads = weakref.WeakValueDictionary()
+
+    @contextlib.contextmanager
+    def scoped(self, **fields):
+        prev = {k: getattr(self, k) for k in fields}
+        for k, v in fields.items():
+            setattr(self, k, v)
+        try:
+            yield self
+        finally:
+            for k, v in prev.items():
+                setattr(self, k, v)
+
+
+RT = RuntimeState()
 
 
 class _timed:
@@ -87,7 +122,7 @@ class RelPosBiasFn(torch.autograd.Function):
         if buf is not None:  # straight into the gradient sink's buffer (no AccumulateGrad add kernel)
             check(lib.hs_rel_bias_scatter_grad_sorted_add(ptr(dbias), ptr(order), ptr(offsets), ptr(buf), rows, nh, ws,
                                                           stream_ptr(dbias.device)), "hs_rel_bias_scatter_grad_sorted_add")
-            GRAD_SINK.deposited(ctx.table)
+            RT.grad_sink.deposited(ctx.table)
             return None, None, None
         dtable = torch.empty((rows, nh), dtype=torch.float32, device=dbias.device)
         check(lib.hs_rel_bias_scatter_grad_sorted(ptr(dbias), ptr(order), ptr(offsets), ptr(dtable), rows, nh, ws,
@@ -116,7 +151,7 @@ class CosHeadScaleFn(torch.autograd.Function):
         buf = _sink_buffer(p)
         if buf is not None:
             check(lib.hs_cos_head_scale_bwd(ptr(ls), ptr(dscale), ptr(buf.view(-1)), ls.numel(), 1, stream_ptr(ls.device)), "hs_cos_head_scale_bwd")
-            GRAD_SINK.deposited(p)
+            RT.grad_sink.deposited(p)
             return None
         d = torch.empty_like(ls)
         check(lib.hs_cos_head_scale_bwd(ptr(ls), ptr(dscale), ptr(d), ls.numel(), 0, stream_ptr(ls.device)), "hs_cos_head_scale_bwd")
@@ -337,14 +372,14 @@ def _extras(x, row_scale, drop_p, seed):
 
 
 def _sink_buffer(p):
-    """fp32 gradient buffer of parameter p that a kernel may ADD into (a view into GRAD_SINK's flat buckets), or None when no
+    """fp32 gradient buffer of parameter p that a kernel may ADD into (a view into RT.grad_sink's flat buckets), or None when no
     sink is installed or p is not registered with it."""
-    sink = GRAD_SINK
+    sink = RT.grad_sink
     return None if (sink is None or p is None) else sink.grad_buffer(p)
 
 
 def _norm_param_grads(weight, bias, width, device, want):
-    """Buffers the LayerNorm backward writes dgamma / dbeta to: under a GRAD_SINK that knows both parameters their fp32
+    """Buffers the LayerNorm backward writes dgamma / dbeta to: under a RT.grad_sink that knows both parameters their fp32
     gradient buffers (the kernel ADDS, autograd sees no gradient and launches no AccumulateGrad kernels), otherwise fresh
     tensors."""
     wbuf = _sink_buffer(weight) if want else None
@@ -357,8 +392,8 @@ def _norm_param_grads(weight, bias, width, device, want):
 def _norm_param_result(weight, bias, dgamma, dbeta, direct):
     if not direct:
         return dgamma.to(weight.dtype), dbeta.to(bias.dtype)
-    GRAD_SINK.deposited(weight)
-    GRAD_SINK.deposited(bias)
+    RT.grad_sink.deposited(weight)
+    RT.grad_sink.deposited(bias)
     return None, None
 
 
@@ -619,7 +654,7 @@ def gelu_dropout(x, p=0.0, seed=None):
 # ----------------------------------------------------------------------------- Linear with HIP weight gradient
 class AsyncWgrad:
     """Opt-in: run the weight/bias-gradient kernels of every Linear on a SIDE stream (their results go straight into the
-    GRAD_SINK's buffers).  Nothing on the backward critical path consumes dW, and the wgrad kernels are MFMA work while much
+    RT.grad_sink's buffers).  Nothing on the backward critical path consumes dW, and the wgrad kernels are MFMA work while much
     of the rest of backward (LayerNorm, attention) is HBM-bound, so the two can co-schedule on the chip.
     `sync()` makes the current stream wait for everything enqueued so far (the sink calls it before it exchanges a bucket
     and at the end of the pass)."""
@@ -632,11 +667,9 @@ class AsyncWgrad:
         cur.wait_stream(self.stream)
 
 
-ASYNC_WGRAD = None  # an AsyncWgrad instance, or None
 # Direct gradient deposit: an object with `grad_buffer(param) -> fp32 tensor | None` and `deposited(param)` (installed by
 # parallel.GradBucketAllReduce).  Linear / LayerNorm parameter gradients of the parameters it knows are accumulated by the
 # kernels straight into those buffers and autograd sees no gradient for them (no AccumulateGrad kernels, no dtype round trip).
-GRAD_SINK = None
 
 
 class ParamCastCache:
@@ -722,16 +755,14 @@ class ParamCastCache:
             ent[1] = self.versions
 
 
-CAST_CACHE = None  # a refreshed ParamCastCache while a model forward is running (set by SwinHPTransformerSys.forward)
 # the cache of the most recent forward: the BACKWARD of that forward takes the transposed weight copies from it (the
 # parameters have not changed in between: an optimizer step bumps the versions and the next forward refreshes)
-LAST_CAST_CACHE = None
 
 
 def _cast_param(p, dtype):
     if p.dtype == dtype:
         return p
-    c = CAST_CACHE.get(p, dtype) if CAST_CACHE is not None else None
+    c = RT.cast_cache.get(p, dtype) if RT.cast_cache is not None else None
     return p.to(dtype) if c is None else c
 
 
@@ -743,7 +774,6 @@ OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice bel
 # bf16 Linear product then runs on hs_gemm_nt, whose persistent grids honour hs_set_reserved_cus.  The library GEMMs fill all
 # 256 CUs and cannot be masked: with 8 foreign workgroups resident they lose 64 % (256 -> 420 us, profiles/r03_cu_contention.json).
 # Costs ~3 ms per step on an idle chip (HS_OWN_GEMM=1 measurement of round 3), saves ~27 ms under contention (r04_cu_contention.json).
-PREFER_OWN_GEMM = False
 OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "4096"))
 OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "1024"))
 OWN_BIAS_MAX_K = int(os.environ.get("HS_OWN_BIAS_MAX_K", "0"))  # A/B: > 0 sends every bias / residual product with k <= this to hs_gemm_nt
@@ -761,7 +791,7 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     two thresholds for A/B runs."""
     if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 16:
         return False  # (n % 8: whole-row-segment stores; the model pads the 12-class head to 16 rows)
-    if OWN_GEMM == "1" or PREFER_OWN_GEMM:
+    if OWN_GEMM == "1" or RT.prefer_own_gemm:
         return True
     kk = k + k2
     if epi == _lib.HS_EPI_DGELU:
@@ -952,7 +982,7 @@ def _cast_param_t(p, dtype, cache=None):
     FORWARD of this autograd node ran under (kept on its ctx, so that several models in one process each take their own
     copies); falls back to the cache of the most recent forward."""
     if cache is None:
-        cache = CAST_CACHE if CAST_CACHE is not None else LAST_CAST_CACHE
+        cache = RT.cast_cache if RT.cast_cache is not None else RT.last_cast_cache
     c = cache.get_t(p, dtype) if (cache is not None and p.dim() == 2 and cache.current(p)) else None
     if c is None:
         n_out = p.shape[0]
@@ -979,7 +1009,7 @@ def _param_grads(dy2, x2, weight, bias, want_w, want_b, x3=None):
     if wbuf is not None and (not want_b or bbuf is not None):
         # accumulate dW (and db) straight into the sink's gradient buffers (no autograd AccumulateGrad kernels, no dtype
         # round trip); optionally on the side stream
-        aw = ASYNC_WGRAD
+        aw = RT.async_wgrad
         wbuf = wbuf.view(n_out, k_in)
         if aw is not None:
             cur = torch.cuda.current_stream(dy2.device)
@@ -990,9 +1020,9 @@ def _param_grads(dy2, x2, weight, bias, want_w, want_b, x3=None):
                 LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3)
         else:
             LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3)
-        GRAD_SINK.deposited(weight)
+        RT.grad_sink.deposited(weight)
         if want_b:
-            GRAD_SINK.deposited(bias)
+            RT.grad_sink.deposited(bias)
         return None, None
     dw = db = None
     if hip_ok:
@@ -1023,7 +1053,7 @@ class LinearFn(torch.autograd.Function):
         ctx.x_shape = x.shape
         ctx.bias_param = bias
         ctx.w_cast = w if w.dtype != weight.dtype else None  # activation-dtype copy, reused by the input-gradient GEMM
-        ctx.cast_cache = CAST_CACHE
+        ctx.cast_cache = RT.cast_cache
         ctx.passthrough = passthrough
         ctx.has_residual = residual is not None
         ctx.x3 = None
@@ -1132,7 +1162,6 @@ def linear_passthrough(x, weight, bias=None):
 # data_ptr -> zero-padded gradient buffer written by losses.seg_loss' backward (see PadSliceFn).  WEAK values: an entry exists only
 # while the buffer itself is alive (i.e. while autograd still holds the gradient view into it), so nothing is retained when no
 # PadSliceFn consumes it, and a recycled address cannot resurrect a dead buffer.
-ZERO_PADDED_GRADS = weakref.WeakValueDictionary()
 
 
 class PadSliceFn(torch.autograd.Function):
@@ -1147,7 +1176,7 @@ class PadSliceFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        full = ZERO_PADDED_GRADS.pop(g.data_ptr(), None)
+        full = RT.zero_padded_grads.pop(g.data_ptr(), None)
         if (full is not None and g._base is full and full.numel() == math.prod(ctx.shape) and full.dtype == g.dtype and
                 g.shape == ctx.shape[:-1] + (ctx.n,) and g.stride() == full.view(ctx.shape)[..., :ctx.n].stride()):
             return full.view(ctx.shape), None
@@ -1291,7 +1320,7 @@ class ExpandLnHeadFn(torch.autograd.Function):
                                             tokens, C, P, _lib.HS_BF16, stream_ptr(xn2.device)), "hs_expand_ln_head_fwd")
         ctx.save_for_backward(xn2, y, mean, rstd, gamma, beta, weight, wexp)
         ctx.w_cast = wq if wq.dtype != wexp.dtype else None
-        ctx.cast_cache = CAST_CACHE
+        ctx.cast_cache = RT.cast_cache
         return logits
 
     @staticmethod
@@ -1349,7 +1378,7 @@ class ExpandLnHeadCeFn(torch.autograd.Function):
         tot = parts.sum(0)
         ctx.save_for_backward(xn2, y, mean, rstd, gamma, beta, weight, wexp, labels, class_w, tot)
         ctx.w_cast = wq if wq.dtype != wexp.dtype else None
-        ctx.cast_cache = CAST_CACHE
+        ctx.cast_cache = RT.cast_cache
         return tot[0] / tot[1]
 
     @staticmethod
@@ -1434,7 +1463,7 @@ class MlpFn(torch.autograd.Function):
         ctx.save_for_backward(None if x3 is not None else x2, h, None if a3 is not None else a, w1, w2)
         ctx.biases = (b1, b2)
         ctx.casts = (w1c if w1c.dtype != w1.dtype else None, w2c if w2c.dtype != w2.dtype else None)
-        ctx.cast_cache = CAST_CACHE
+        ctx.cast_cache = RT.cast_cache
         ctx.meta = (float(drop_p), int(seed), x.shape)
         ctx.splits = (x3, a3)
         y = y.view(x.shape[:-1] + (w2.shape[0],))
@@ -1504,7 +1533,7 @@ class ConcatLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, skip, weight)
         ctx.bias_param = bias
         ctx.w_cast = w if w is not weight else None
-        ctx.cast_cache = CAST_CACHE
+        ctx.cast_cache = RT.cast_cache
         return y.reshape(x.shape[:-1] + (weight.shape[0],))
 
     @staticmethod
@@ -1546,9 +1575,9 @@ class ConcatLinearFn(torch.autograd.Function):
             wbuf[:, c:].add_(dwb)
             if want_b:
                 bbuf.add_(db32)
-            GRAD_SINK.deposited(weight)
+            RT.grad_sink.deposited(weight)
             if want_b:
-                GRAD_SINK.deposited(bias)
+                RT.grad_sink.deposited(bias)
             return dx, dskip, None, None
         dw = torch.cat([dwa, dwb], 1).to(weight.dtype) if want_w else None
         return dx, dskip, dw, (db32.to(bias.dtype) if want_b else None)

@@ -73,21 +73,21 @@ class GradBucketAllReduce:
                 _lib.check(_lib.lib.hs_set_reserved_cus(want), "hs_set_reserved_cus")
             if want > 0:  # CUs are reserved for the exchange: keep every GEMM on the kernels that honour the reservation
                 from . import ops as _ops
-                self._prefer_prev = _ops.PREFER_OWN_GEMM
-                _ops.PREFER_OWN_GEMM = True
+                self._prefer_prev = _ops.RT.prefer_own_gemm
+                _ops.RT.prefer_own_gemm = True
         if (direct_wgrad or async_wgrad) and on_gpu:
             # kernels accumulate Linear / LayerNorm parameter gradients straight into the bucket views of the parameters
             # REGISTERED HERE (ops asks grad_buffer(p) per parameter; other models in the process are unaffected)
             from . import ops
 
-            ops.GRAD_SINK = self
+            ops.RT.grad_sink = self
             self._direct = True
         if async_wgrad and on_gpu:
             # the Linear weight-gradient kernels additionally run on a side stream (ops.AsyncWgrad)
             from . import ops
 
             self.async_wgrad = ops.AsyncWgrad(self.params[0].device)
-            ops.ASYNC_WGRAD = self.async_wgrad
+            ops.RT.async_wgrad = self.async_wgrad
 
     # ------------------------------------------------------------------ construction
     def _build(self, bucket_bytes):
@@ -159,15 +159,15 @@ class GradBucketAllReduce:
     def suspended(self):
         """No direct deposit inside (e.g. around torch.autograd.grad calls that need the parameter gradients returned)."""
         from . import ops
-        prev_sink, prev_aw = ops.GRAD_SINK, ops.ASYNC_WGRAD
+        prev_sink, prev_aw = ops.RT.grad_sink, ops.RT.async_wgrad
         if prev_sink is self:
-            ops.GRAD_SINK = None
+            ops.RT.grad_sink = None
         if prev_aw is self.async_wgrad:
-            ops.ASYNC_WGRAD = None
+            ops.RT.async_wgrad = None
         try:
             yield
         finally:
-            ops.GRAD_SINK, ops.ASYNC_WGRAD = prev_sink, prev_aw
+            ops.RT.grad_sink, ops.RT.async_wgrad = prev_sink, prev_aw
 
     def attach_optimizer(self, optimizer):
         """Lets a step of `optimizer` mark the start of a new iteration, for callers that zero gradients in place with
@@ -299,17 +299,17 @@ class GradBucketAllReduce:
             self._reserved_prev = None
         if self._prefer_prev is not None:
             from . import ops as _ops
-            _ops.PREFER_OWN_GEMM = self._prefer_prev
+            _ops.RT.prefer_own_gemm = self._prefer_prev
             self._prefer_prev = None
         if not self._direct and self.async_wgrad is None:
             return
         from . import ops
 
         if self.async_wgrad is not None:
-            if ops.ASYNC_WGRAD is self.async_wgrad:
-                ops.ASYNC_WGRAD = None
+            if ops.RT.async_wgrad is self.async_wgrad:
+                ops.RT.async_wgrad = None
             self.async_wgrad = None
         if self._direct:
-            if ops.GRAD_SINK is self:
-                ops.GRAD_SINK = None
+            if ops.RT.grad_sink is self:
+                ops.RT.grad_sink = None
             self._direct = False

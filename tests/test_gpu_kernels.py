@@ -765,7 +765,7 @@ def test_seg_cross_entropy_padded_row_fast_path(K):
     assert float(loss_p) == float(loss_d)
     assert torch.equal(zp.grad[..., :K], zd.grad)
     assert not zp.grad[..., K:].any()
-    assert not ops.ZERO_PADDED_GRADS  # the buffer was consumed by pad_slice's backward
+    assert not ops.RT.zero_padded_grads  # the buffer was consumed by pad_slice's backward
     ref_in = z16[..., :K].float().transpose(1, 2).clone().requires_grad_(True)
     ref = torch.nn.functional.cross_entropy(ref_in, labels, weight=w)
     ref.backward()

@@ -242,7 +242,7 @@ def test_direct_and_async_wgrad_match_autograd_path():
     grads = {}
     for mode, kw in (("autograd", dict(direct_wgrad=False)), ("direct", dict(direct_wgrad=True)), ("async", dict(async_wgrad=True))):
         dp = GradBucketAllReduce(model.parameters(), **kw)
-        assert (ops.ASYNC_WGRAD is not None) == (mode == "async") and (ops.GRAD_SINK is dp) == (mode != "autograd")
+        assert (ops.RT.async_wgrad is not None) == (mode == "async") and (ops.RT.grad_sink is dp) == (mode != "autograd")
         for _ in range(2):  # second pass re-uses the zeroed buckets
             dp.zero_grad()
             model(x).float().square().mean().backward()
@@ -252,7 +252,7 @@ def test_direct_and_async_wgrad_match_autograd_path():
         dp.remove()
         for p in model.parameters():
             p.grad = None
-    assert ops.ASYNC_WGRAD is None and ops.GRAD_SINK is None
+    assert ops.RT.async_wgrad is None and ops.RT.grad_sink is None
     for n in grads["autograd"]:
         assert torch.equal(grads["autograd"][n], grads["direct"][n]), n
         assert torch.equal(grads["autograd"][n], grads["async"][n]), n

@@ -67,7 +67,7 @@ def test_param_cast_cache_survives_fused_optimizers_that_do_not_bump_versions():
 def test_cast_param_falls_back_to_a_plain_cast_without_a_cache():
     from heal_swin_amd import ops
     p = torch.nn.Parameter(torch.randn(4, 4))
-    assert ops.CAST_CACHE is None
+    assert ops.RT.cast_cache is None
     assert ops._cast_param(p, torch.float32) is p
     c = ops._cast_param(p, torch.bfloat16)
     assert c.dtype == torch.bfloat16 and torch.equal(c, p.detach().to(torch.bfloat16))

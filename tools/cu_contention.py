@@ -6,7 +6,7 @@ to exactly one resident round of all 256 CUs, and what does hs_set_reserved_cus(
 A stand-in (`hs_debug_occupy_cus`: k workgroups of 256 threads, 128 VGPRs, 16 KB LDS, resident for the whole measurement on a side
 stream) plays the communication kernels.  Measured: (1) the chip-filling kernels one by one at the HEAL-SWIN-B stage-2 shapes,
 (2) the whole B / nside 256 / batch 8 training step.  Round 4: a duty-cycled occupier shaped like the real exchange beside the always-resident one, and the step with every GEMM on
-hs_gemm_nt (ops.PREFER_OWN_GEMM).  Writes JSON to stdout (-> profiles/r04_cu_contention.json)."""
+hs_gemm_nt (ops.RT.prefer_own_gemm).  Writes JSON to stdout (-> profiles/r04_cu_contention.json)."""
 import json
 import os
 import sys
@@ -148,11 +148,11 @@ def main():
     del cases
     torch.cuda.empty_cache()
     # whole step: library GEMMs where the per-shape policy picks them (idle-chip default) vs every bf16 Linear on hs_gemm_nt
-    # (what GradBucketAllReduce switches on when CUs are reserved, ops.PREFER_OWN_GEMM)
+    # (what GradBucketAllReduce switches on when CUs are reserved, ops.RT.prefer_own_gemm)
     for reserved, own in ((0, False), (16, False), (16, True)):
         check(lib.hs_set_reserved_cus(reserved), "hs_set_reserved_cus")
         step, dp = step_case()
-        ops.PREFER_OWN_GEMM = own
+        ops.RT.prefer_own_gemm = own
         row = {"workload": "HEAL-SWIN-B nside 256 batch 8 bf16 train step", "reserved_cus": reserved,
                "gemms": "all bf16 Linear products on hs_gemm_nt" if own else "per-shape policy (hipBLASLt for the MFMA-bound products)", "ms": {}}
         row["ms"]["idle"] = round(timed(step, 5, 0, 170000) / 1e3, 2)
@@ -163,7 +163,7 @@ def main():
         out["step"].append(row)
         print(row, file=sys.stderr, flush=True)
         dp.remove()
-        ops.PREFER_OWN_GEMM = False
+        ops.RT.prefer_own_gemm = False
         del step, dp
         torch.cuda.empty_cache()
     check(lib.hs_set_reserved_cus(0), "hs_set_reserved_cus")
