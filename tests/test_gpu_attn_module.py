@@ -333,3 +333,59 @@ def test_model_training_step_uses_the_train_form_and_matches_the_composition():
         worst = max(worst, e["scale_err"])
         assert e["scale_err"] <= 6e-2, (n, e)
     print(f"train form vs composition: worst parameter-gradient scale error {worst:.2e}")
+
+
+@pytest.mark.parametrize("v1,cosine,strategy", [(True, False, "nest_roll"), (True, True, "ring_shift"), (False, True, "nest_grid_shift")])
+def test_module_bwd_entry_point_equals_the_autograd_path(v1, cosine, strategy):
+    """C ABI: hs_window_attn_module_fwd_train followed by hs_window_attn_module_bwd (one call each way) gives the gradients the
+    Python mirror's recorded autograd nodes give (ops.window_attn_module_train) -- same kernels, chained by the library."""
+    from heal_swin_amd import ops, _lib
+    from heal_swin_amd._lib import check, lib, ptr
+    from oracle import tables as T
+    B, nside, C, nH, shift = 2, 16, 128, 4, 32
+    N = 8 * nside * nside
+    g = torch.Generator(device=DEV).manual_seed(9)
+    rnd = lambda *s, k=1.0: torch.randn(*s, generator=g, device=DEV) * k  # noqa: E731
+    x = (rnd(B, N, C) * 2 + 0.3).to(torch.bfloat16)
+    P = dict(wq=rnd(3 * C, C, k=C ** -0.5), bq=rnd(3 * C, k=0.2), wp=rnd(C, C, k=C ** -0.5), bp=rnd(C, k=0.2), bias=rnd(nH, 64, 64),
+             hs=torch.rand(nH, generator=g, device=DEV) * (8 if cosine else 0.3) + 0.1)
+    if v1:
+        P.update(lg=torch.rand(C, generator=g, device=DEV) + 0.5, lb=rnd(C, k=0.2))
+    dout = rnd(B, N, C).to(torch.bfloat16)
+    if strategy == "nest_roll":
+        idx, roll, lab_np = None, shift, T.nest_roll_shift(N, 64, shift)[2]
+    else:
+        idx_np, _, lab_np = T.nest_grid_shift(nside, 8, 64) if strategy == "nest_grid_shift" else T.ring_shift(nside, 8, 64, 4)
+        idx, roll = torch.from_numpy(idx_np).to(torch.int32).to(DEV), 0
+    labels = torch.from_numpy(lab_np).to(torch.uint8).to(DEV)
+    # ---- autograd path
+    xd = x.clone().requires_grad_(True)
+    D = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    y = ops.window_attn_module_train(xd, D.get("lg"), D.get("lb"), D["wq"], D["bq"], D["wp"], D["bp"], D["bias"], D["hs"], idx, roll, labels,
+                                     nH, 64, cosine)
+    y.backward(dout)
+    # ---- C ABI, one call each way
+    wq16, wp16 = P["wq"].to(torch.bfloat16).contiguous(), P["wp"].to(torch.bfloat16).contiguous()
+    out, xn, o = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    qkv = torch.empty(B, N, 3 * C, dtype=torch.bfloat16, device=DEV)
+    mean, rstd, lse = torch.empty(B * N, device=DEV), torch.empty(B * N, device=DEV), torch.empty(B, nH, N, device=DEV)
+    flags = (_lib.HS_ATTN_COSINE if cosine else 0) | (_lib.HS_ATTN_RESIDUAL if v1 else 0)
+    check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(out), ptr(xn) if v1 else None, ptr(mean) if v1 else None, ptr(rstd) if v1 else None,
+                                              ptr(qkv), ptr(o), ptr(lse), ptr(wq16), ptr(P["bq"]), ptr(wp16), ptr(P["bp"]),
+                                              ptr(P["lg"]) if v1 else None, ptr(P["lb"]) if v1 else None, ptr(P["bias"]), ptr(P["hs"]),
+                                              ptr(idx), roll, ptr(labels), B, N, C, nH, 64, flags, _lib.HS_BF16, None), "fwd_train")
+    assert torch.equal(out, y.detach())
+    ws = torch.empty(int(lib.hs_window_attn_module_bwd_workspace(B, N, C, nH, 64)), device=DEV)
+    dx = torch.empty_like(x)
+    G = dict(wq=torch.empty(3 * C, C, device=DEV), bq=torch.empty(3 * C, device=DEV), wp=torch.empty(C, C, device=DEV), bp=torch.empty(C, device=DEV),
+             lg=torch.empty(C, device=DEV), lb=torch.empty(C, device=DEV), bias=torch.empty(nH, 64, 64, device=DEV), hs=torch.empty(nH, device=DEV))
+    check(lib.hs_window_attn_module_bwd(ptr(dout), ptr(x), ptr(xn) if v1 else None, ptr(mean) if v1 else None, ptr(rstd) if v1 else None, ptr(qkv),
+                                        ptr(o), ptr(lse), ptr(wq16.t().contiguous()), ptr(wp16.t().contiguous()), ptr(P["lg"]) if v1 else None,
+                                        ptr(P["bias"]), ptr(P["hs"]), ptr(idx), roll, ptr(labels), ptr(dx), ptr(G["wq"]), ptr(G["bq"]),
+                                        ptr(G["wp"]), ptr(G["bp"]), ptr(G["lg"]) if v1 else None, ptr(G["lb"]) if v1 else None, ptr(G["bias"]),
+                                        ptr(G["hs"]), ptr(ws), 0, B, N, C, nH, 64, flags, _lib.HS_BF16, None), "module_bwd")
+    assert_close(dx, xd.grad, 1e-6, "dx")
+    for k in D:
+        if k == "hs" and not cosine:
+            continue
+        assert_close(G[k], D[k].grad, 1e-6, f"d{k}")
