@@ -84,6 +84,12 @@ struct ModParams {
     float* mean_out;    // [B, N]      LayerNorm statistics
     float* rstd_out;
     float* lse_out;     // [B, nH, N]  log-sum-exp of every score row, by SHIFTED position (as hs_window_attn_fwd)
+    // optional second LayerNorm BEHIND the residual add (the block's norm2, ref :337): n2 = LayerNorm(out), with its statistics
+    const float* ln2_g;
+    const float* ln2_b;
+    uint16_t* n2_out;   // [B, N, C]
+    float* mean2_out;   // [B, N]
+    float* rstd2_out;
 #ifdef HS_MOD_TRACE
     unsigned long long* trace;  // measurement build: shader-clock stamps [wave][window < 8][phase < 16] of workgroup 0
 #endif
@@ -142,9 +148,10 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
     constexpr int W_OFF = 0, X_OFF = 3 * C * kRowB, O_OFF = X_OFF + 2 * kWs * kRowB, M_OFF = O_OFF + kWs * kRowB;
     constexpr int XP = (16 + NH - 1) / NH;  // x-tile DMA pieces (1 KB = 4 rows) per wave
     // + two 256-B label patches (64 bytes used) + fp32 parameter block: LayerNorm gamma | beta, qkv bias (q | k rows), proj bias
-    constexpr int P_OFF = M_OFF + 2 * 256, P_LNG = 0, P_LNB = 128, P_BQ = 256, P_BK = 384, P_BP = 512, P_BV = 640;  // float offsets, 128 each
+    constexpr int P_OFF = M_OFF + 2 * 256, P_LNG = 0, P_LNB = 128, P_BQ = 256, P_BK = 384, P_BP = 512, P_BV = 640, P_LN2G = 768,
+                  P_LN2B = 896;  // float offsets, 128 each
     // + (training form) the natural-order token of each of the 64 window rows, current / next window: two 256-byte tables
-    constexpr int T_OFF = P_OFF + 6 * 128 * 4;
+    constexpr int T_OFF = P_OFF + 8 * 128 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[T_OFF + 2 * 256];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
@@ -177,6 +184,8 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             ps[P_BK + i] = p.qkv_b ? p.qkv_b[C + i] : 0.f;
             ps[P_BP + i] = p.proj_b ? p.proj_b[i] : 0.f;
             ps[P_BV + i] = p.qkv_b ? p.qkv_b[2 * C + i] : 0.f;
+            ps[P_LN2G + i] = p.ln2_g ? p.ln2_g[i] : 1.f;
+            ps[P_LN2B + i] = p.ln2_b ? p.ln2_b[i] : 0.f;
         }
     }
     const uint32_t pbase = lds0 + P_OFF;
@@ -729,14 +738,17 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
             // the NEXT window's x rows (requested a window ago) have landed, and with them everything this window has stored so far
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TR(12);
+            const bool norm2 = TRAIN && p.n2_out != nullptr;
             u32x4 rows[XP];
 #pragma unroll
             for (int j = 0; j < XP; ++j)
                 asm volatile("ds_read_b128 %0, %1" : "=v"(rows[j]) : "v"(xbase + (uint32_t)((wave + NH * j) * 1024 + lane * 16)));
+            if (norm2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the parameter reads below would break the counted waits)
 #pragma unroll
             for (int j = 0; j < XP; ++j) {
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(rows[j]) : "n"(XP - 1 - j));
-                if (wave + NH * j < 16 && pchunk_of(j) < NCH) {
+                if (wave + NH * j < 16) {
+                    const bool valid = pchunk_of(j) < NCH;
                     const int64_t e = (int64_t)tok[j] * C + pchunk_of(j) * 8;
                     u32x4 v = rows[j];
                     if (residual) {
@@ -746,7 +758,50 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                             v[i] = pack_bf16x2(__uint_as_float(v[i] << 16) + __uint_as_float(xr[i] << 16),
                                                __uint_as_float(v[i] & 0xffff0000u) + __uint_as_float(xr[i] & 0xffff0000u));
                     }
-                    *(u32x4*)(p.out + e) = v;
+                    if (valid) *(u32x4*)(p.out + e) = v;
+                    if constexpr (TRAIN) {
+                        if (norm2) {
+                            // norm2 of the block (ref :337) on the row just formed: its 16 chunks sit in 16 adjacent lanes (in swizzled
+                            // order), statistics by a 4-step xor tree inside the group, on the bf16 values the consumer of `out` would read
+                            float f[8];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                f[2 * i] = valid ? __uint_as_float(v[i] << 16) : 0.f;
+                                f[2 * i + 1] = valid ? __uint_as_float(v[i] & 0xffff0000u) : 0.f;
+                            }
+                            float s1 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) s1 += f[i];
+#pragma unroll
+                            for (int o2 = 1; o2 < 16; o2 <<= 1) s1 += __shfl_xor(s1, o2, 64);
+                            const float mean2 = s1 * (1.f / C);
+                            float s2 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                f[i] = valid ? f[i] - mean2 : 0.f;
+                                s2 = fmaf(f[i], f[i], s2);
+                            }
+#pragma unroll
+                            for (int o2 = 1; o2 < 16; o2 <<= 1) s2 += __shfl_xor(s2, o2, 64);
+                            const float rstd2 = rsqrtf(s2 * (1.f / C) + kLnEps);
+                            const int pcx = valid ? pchunk_of(j) : 0;
+                            const uint32_t ga = pbase + (P_LN2G + pcx * 8) * 4, ba = pbase + (P_LN2B + pcx * 8) * 4;
+                            u32x4 gw0 = ld128(ga), gw1 = ld128(ga + 16), bw0 = ld128(ba), bw1 = ld128(ba + 16);
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gw0), "+v"(gw1), "+v"(bw0), "+v"(bw1));
+                            u32x4 o2v;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float g0 = __uint_as_float(i < 2 ? gw0[2 * i] : gw1[2 * i - 4]), g1 = __uint_as_float(i < 2 ? gw0[2 * i + 1] : gw1[2 * i - 3]);
+                                const float b0 = __uint_as_float(i < 2 ? bw0[2 * i] : bw1[2 * i - 4]), b1 = __uint_as_float(i < 2 ? bw0[2 * i + 1] : bw1[2 * i - 3]);
+                                o2v[i] = pack_bf16x2(fmaf(f[2 * i] * rstd2, g0, b0), fmaf(f[2 * i + 1] * rstd2, g1, b1));
+                            }
+                            if (valid) *(u32x4*)(p.n2_out + e) = o2v;
+                            if ((lane & 15) == 0) {
+                                p.mean2_out[tok[j]] = mean2;
+                                p.rstd2_out[tok[j]] = rstd2;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -805,6 +860,9 @@ namespace {
 struct TrainOut {
     void *xn = nullptr, *qkv = nullptr, *o = nullptr;
     float *mean = nullptr, *rstd = nullptr, *lse = nullptr;
+    const float *ln2_g = nullptr, *ln2_b = nullptr;  // optional norm2 behind the residual add
+    void* n2 = nullptr;
+    float *mean2 = nullptr, *rstd2 = nullptr;
 };
 int module_fwd_impl(const char* who, const void* x, void* out, const TrainOut& tr, const void* qkv_w, const float* qkv_b, const void* proj_w,
                     const float* proj_b, const float* ln_gamma, const float* ln_beta, const float* bias, const float* head_scale,
@@ -845,6 +903,12 @@ int module_fwd_impl(const char* who, const void* x, void* out, const TrainOut& t
             p.mean_out = tr.mean ? tr.mean + t0 : nullptr;
             p.rstd_out = tr.rstd ? tr.rstd + t0 : nullptr;
             p.lse_out = tr.lse + t0 * num_heads;
+            if (tr.n2) {
+                p.ln2_g = tr.ln2_g; p.ln2_b = tr.ln2_b;
+                p.n2_out = (uint16_t*)tr.n2 + t0 * channels;
+                p.mean2_out = tr.mean2 + t0;
+                p.rstd2_out = tr.rstd2 + t0;
+            }
         }
         const int rc = num_heads == 4 ? launch_module<4>(p, cosine, (hipStream_t)stream) : launch_module<3>(p, cosine, (hipStream_t)stream);
         if (rc != HS_OK) return rc;
@@ -864,13 +928,18 @@ int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const
 int hs_window_attn_module_fwd_train(const void* x, void* out, void* xn_out, float* mean_out, float* rstd_out, void* qkv_out,
                                     void* attn_out, float* lse_out, const void* qkv_w, const float* qkv_b, const void* proj_w,
                                     const float* proj_b, const float* ln_gamma, const float* ln_beta, const float* bias,
-                                    const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels, int batch,
-                                    int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
+                                    const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels,
+                                    const float* norm2_gamma, const float* norm2_beta, void* n2_out, float* mean2_out, float* rstd2_out,
+                                    int batch, int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
                                     void* stream) {
     HS_CHECK_ARG(qkv_out && attn_out && lse_out, "hs_window_attn_module_fwd_train: null output");
+    HS_CHECK_ARG((norm2_gamma != nullptr) == (norm2_beta != nullptr) && (norm2_gamma != nullptr) == (n2_out != nullptr) &&
+                     (n2_out != nullptr) == (mean2_out != nullptr) && (n2_out != nullptr) == (rstd2_out != nullptr),
+                 "hs_window_attn_module_fwd_train: norm2_gamma, norm2_beta, n2_out, mean2_out, rstd2_out go together");
     HS_CHECK_ARG(!ln_gamma || (xn_out && mean_out && rstd_out), "hs_window_attn_module_fwd_train: with a LayerNorm in front its output and statistics are saved too");
     TrainOut tr;
     tr.xn = xn_out; tr.qkv = qkv_out; tr.o = attn_out; tr.mean = mean_out; tr.rstd = rstd_out; tr.lse = lse_out;
+    tr.ln2_g = norm2_gamma; tr.ln2_b = norm2_beta; tr.n2 = n2_out; tr.mean2 = mean2_out; tr.rstd2 = rstd2_out;
     return module_fwd_impl("hs_window_attn_module_fwd_train", x, out, tr, qkv_w, qkv_b, proj_w, proj_b, ln_gamma, ln_beta, bias,
                            head_scale, idx, roll, labels, batch, n_tokens, channels, num_heads, window_size, flags, dtype, stream);
 }

@@ -222,11 +222,13 @@ class WindowAttention(nn.Module):
                 not (self.training and (self.attn_drop.p > 0 or self.proj_drop.p > 0)) and
                 (self.rel_pos_bias is None or window_size == self.window_size))
 
-    def fused_module_train(self, x, window_size, idx, roll, labels, norm):
-        """x + proj(attention(qkv(norm(x)))) by `hs_window_attn_module_fwd_train`, differentiable (ops.window_attn_module_train)."""
+    def fused_module_train(self, x, window_size, idx, roll, labels, norm, norm2=None):
+        """x + proj(attention(qkv(norm(x)))) by `hs_window_attn_module_fwd_train`, differentiable (ops.window_attn_module_train);
+        with norm2 the same launch also applies the block's second LayerNorm: returns (norm2(x1), x1)."""
         return ops.window_attn_module_train(x, norm.weight, norm.bias, self.qkv.weight, self.qkv.bias, self.proj.weight,
                                             self.proj.bias, self.bias(), self.head_scale(), idx, roll, labels, self.num_heads,
-                                            window_size, self.use_cos_attn)
+                                            window_size, self.use_cos_attn,
+                                            norm2=None if norm2 is None else (norm2.weight, norm2.bias))
 
     def forward(self, x, mask=None):
         """Reference-compatible entry: x [num_windows*B, Ws, C], mask [nW, Ws, Ws] in {0,-100} or None."""
@@ -353,11 +355,14 @@ class SwinTransformerBlock(nn.Module):
             if pending is None and self.attn.trainable_fused(x, self.window_size):
                 # norm1 -> qkv -> attention -> proj -> residual add in ONE launch that also writes what the backward reads
                 idx, roll, labels = self._shift_args(x)
-                x1 = self.attn.fused_module_train(x, self.window_size, idx, roll, labels, self.norm1)
-                if fc2_own:
+                # ... and the block's norm2 on the sum it has just formed (ops.FUSED_NORM2)
+                if ops.FUSED_NORM2:
+                    n2, x1 = self.attn.fused_module_train(x, self.window_size, idx, roll, labels, self.norm1, norm2=self.norm2)
+                else:
+                    x1 = self.attn.fused_module_train(x, self.window_size, idx, roll, labels, self.norm1)
                     n2, x1 = ops.layer_norm_passthrough(x1, self.norm2.weight, self.norm2.bias)
+                if fc2_own:
                     return self.mlp(n2, apply_out_drop=False, residual=x1), None, None
-                n2, x1 = ops.layer_norm_passthrough(x1, self.norm2.weight, self.norm2.bias)
                 return x1, (self.mlp(n2, apply_out_drop=False), None, 0.0), None
             if proj_own or fc2_own:
                 if pending is None:

@@ -303,6 +303,9 @@ def window_attn_module(x, qkv_w, qkv_b, proj_w, proj_b, bias, head_scale, idx, r
 # The TRAINING form of the module kernel (`hs_window_attn_module_fwd_train`): x + proj(attention(qkv(LayerNorm(x)))) in one launch that
 # also writes what the backward reads.  HS_FUSED_ATTN_TRAIN=0 keeps the four-kernel composition (A/B runs).
 FUSED_ATTN_MODULE_TRAIN = os.environ.get("HS_FUSED_ATTN_TRAIN", "1") != "0"
+# the block's norm2 as that kernel's epilogue: built, parity-tested, time-NEUTRAL on the step (144.3-144.5 ms either way: the standalone
+# LayerNorm streams at 4.7 TB/s, the one-wave-per-SIMD module kernel pays about as much for the extra phase) -- off by default
+FUSED_NORM2 = os.environ.get("HS_FUSED_NORM2", "0") == "1"
 
 
 def window_attn_module_train_ok(x, num_heads, window_size):
@@ -311,13 +314,15 @@ def window_attn_module_train_ok(x, num_heads, window_size):
 
 
 def window_attn_module_train(x, ln_weight, ln_bias, qkv_w, qkv_b, proj_w, proj_b, bias, head_scale, idx, roll, labels, num_heads,
-                             window_size, cosine, residual_alias=False):
+                             window_size, cosine, residual_alias=False, norm2=None):
     """x + proj(window_attention(qkv(LayerNorm(x)))) for a block on the training path (reference :315-316 around :124-174).  ONE
     kernel computes it and writes LayerNorm(x) with its statistics, qkv, the attention output and the log-sum-exp rows; the four
     autograd nodes of the composed path (LayerNormFn, LinearFn, WindowAttnCoreFn, LinearFn with the residual) are then recorded
     around those tensors WITHOUT launching anything (`pre=`), so the backward is exactly the composed path's.
     ln_weight None (v2 norm placement, ref :334-335): proj(window_attention(qkv(x))) without norm and residual; with residual_alias
-    the call returns (y, alias of x) as `LinearFn`'s passthrough form does (the alias' gradient rides on the qkv input-gradient GEMM)."""
+    the call returns (y, alias of x) as `LinearFn`'s passthrough form does (the alias' gradient rides on the qkv input-gradient GEMM).
+    norm2 = (weight, bias) of the block's second LayerNorm (v1 placement only): the same launch also writes LayerNorm(out); the
+    call then returns (n2, out) as `layer_norm_passthrough(out, ...)` would."""
     _require_gpu(x, qkv_w, proj_w, bias, head_scale, idx, labels)
     B, N, C = x.shape
     x = x.contiguous()
@@ -329,14 +334,23 @@ def window_attn_module_train(x, ln_weight, ln_bias, qkv_w, qkv_b, proj_w, proj_b
     mean = torch.empty(B * N, dtype=torch.float32, device=dev) if has_ln else None
     rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if has_ln else None
     lse = torch.empty((B, num_heads, N), dtype=torch.float32, device=dev)
+    n2 = mean2 = rstd2 = None
+    if norm2 is not None:
+        assert has_ln and not residual_alias
+        n2 = torch.empty_like(x)
+        mean2 = torch.empty(B * N, dtype=torch.float32, device=dev)
+        rstd2 = torch.empty(B * N, dtype=torch.float32, device=dev)
     wq, wp = _cast_param(qkv_w, torch.bfloat16).contiguous(), _cast_param(proj_w, torch.bfloat16).contiguous()
     hs = _f32(head_scale).reshape(-1)
     flags = (_lib.HS_ATTN_COSINE if cosine else 0) | (_lib.HS_ATTN_RESIDUAL if has_ln else 0)
     # algorithmic traffic: x in (+ again for the residual), out + LayerNorm(x) + qkv + attention output written; flops as the module
-    with _timed("window_attn_module_fwd_train", dev, (9 if has_ln else 6) * B * N * C * 2, B * N * (8 * C * C + 4 * window_size * C)):
+    with _timed("window_attn_module_fwd_train", dev, ((9 if has_ln else 6) + (1 if n2 is not None else 0)) * B * N * C * 2,
+                B * N * (8 * C * C + 4 * window_size * C)):
         check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(out), ptr(xn), ptr(mean), ptr(rstd), ptr(qkv), ptr(o), ptr(lse), ptr(wq),
                                                   ptr(_f32(qkv_b)), ptr(wp), ptr(_f32(proj_b)), ptr(_f32(ln_weight)), ptr(_f32(ln_bias)),
-                                                  ptr(_f32(bias)), ptr(hs), ptr(idx), int(roll), ptr(labels), B, N, C, num_heads,
+                                                  ptr(_f32(bias)), ptr(hs), ptr(idx), int(roll), ptr(labels),
+                                                  ptr(None if n2 is None else _f32(norm2[0])), ptr(None if n2 is None else _f32(norm2[1])),
+                                                  ptr(n2), ptr(mean2), ptr(rstd2), B, N, C, num_heads,
                                                   window_size, flags, _lib.HS_BF16, stream_ptr(dev)),
               "hs_window_attn_module_fwd_train")
     if not has_ln:
@@ -352,7 +366,10 @@ def window_attn_module_train(x, ln_weight, ln_bias, qkv_w, qkv_b, proj_w, proj_b
     n1, xs = LayerNormFn.apply(x, ln_weight, ln_bias, None, None, True, None, False, (xn, mean, rstd))
     qkv_t = LinearFn.apply(n1, qkv_w, qkv_b, False, None, (qkv,))
     o_t = WindowAttnCoreFn.apply(qkv_t, bias, head_scale, idx, roll, labels, num_heads, window_size, cosine, 0.0, 0, (o, lse))
-    return LinearFn.apply(o_t, proj_w, proj_b, False, xs, (out,))
+    x1 = LinearFn.apply(o_t, proj_w, proj_b, False, xs, (out,))
+    if n2 is None:
+        return x1
+    return LayerNormFn.apply(x1, norm2[0], norm2[1], None, None, True, None, False, (n2, mean2, rstd2))
 
 
 # ----------------------------------------------------------------------------- row LayerNorm (+ residual, + train-mode extras)

@@ -354,12 +354,16 @@ int hs_window_attn_module_fwd(const void* x, void* out, const void* qkv_w, const
  *   lse_out  [dev] f32 [batch, num_heads, n_tokens]      hs_window_attn_fwd's `lse` (by shifted position)
  * HBM traffic per token: x in, out written, 5 C saved = 7 C * 2 B (+ 8 + 4 nH bytes of statistics) against 13 C * 2 B for
  * hs_layernorm_fwd -> hs_gemm_nt -> hs_window_attn_fwd -> hs_gemm_nt(HS_EPI_RESID), none of the saved tensors re-read in the forward.
+ * norm2_gamma / norm2_beta / n2_out / mean2_out / rstd2_out (all five or none): the block's SECOND LayerNorm (:337) applied to `out`
+ * in the same launch: n2_out [dev] bf16 [batch, n_tokens, channels] = LayerNorm(out) (what the MLP reads), its row statistics in
+ * mean2_out / rstd2_out -- as hs_layernorm_fwd on `out` would have written them.
  * Same support set and argument meaning as hs_window_attn_module_fwd. */
 int hs_window_attn_module_fwd_train(const void* x, void* out, void* xn_out, float* mean_out, float* rstd_out, void* qkv_out,
                                     void* attn_out, float* lse_out, const void* qkv_w, const float* qkv_b, const void* proj_w,
                                     const float* proj_b, const float* ln_gamma, const float* ln_beta, const float* bias,
-                                    const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels, int batch,
-                                    int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
+                                    const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels,
+                                    const float* norm2_gamma, const float* norm2_beta, void* n2_out, float* mean2_out, float* rstd2_out,
+                                    int batch, int64_t n_tokens, int channels, int num_heads, int window_size, unsigned flags, int dtype,
                                     void* stream);
 
 /* Backward of the same unit in one call: the gradients of out = [x +] proj(attention(qkv([LayerNorm](x)))) with respect to x and every

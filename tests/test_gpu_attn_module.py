@@ -264,9 +264,17 @@ def test_module_train_form_saved_tensors_equal_the_separate_kernels():
     qkv = torch.empty(B, N, 3 * C, dtype=torch.bfloat16, device=DEV)
     mean, rstd = torch.empty(B * N, device=DEV), torch.empty(B * N, device=DEV)
     lse = torch.empty(B, nH, N, device=DEV)
+    l2g, l2b = torch.rand(C, generator=g, device=DEV) + 0.5, torch.randn(C, generator=g, device=DEV) * 0.2
+    n2, mean_2, rstd_2 = torch.empty_like(x), torch.empty(B * N, device=DEV), torch.empty(B * N, device=DEV)
     check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(out), ptr(xn), ptr(mean), ptr(rstd), ptr(qkv), ptr(o), ptr(lse), ptr(wq), ptr(bq),
-                                              ptr(wp), ptr(bp), ptr(lg), ptr(lb), ptr(bias), ptr(hs), None, 32, None, B, N, C, nH, 64,
-                                              _lib.HS_ATTN_RESIDUAL, _lib.HS_BF16, None), "train")
+                                              ptr(wp), ptr(bp), ptr(lg), ptr(lb), ptr(bias), ptr(hs), None, 32, None, ptr(l2g), ptr(l2b), ptr(n2),
+                                              ptr(mean_2), ptr(rstd_2), B, N, C, nH, 64, _lib.HS_ATTN_RESIDUAL, _lib.HS_BF16, None), "train")
+    # the block's norm2 in the same launch: hs_layernorm_fwd on the `out` rows it has just written
+    n2r, m2r, r2r = torch.empty_like(x), torch.empty_like(mean_2), torch.empty_like(rstd_2)
+    check(lib.hs_layernorm_fwd(ptr(out), None, ptr(l2g), ptr(l2b), ptr(n2r), ptr(m2r), ptr(r2r), B * N, C, _lib.HS_BF16, None), "ln2")
+    assert_close(mean_2, m2r, 1e-5, "norm2 mean")
+    assert_close(rstd_2, r2r, 1e-5, "norm2 rstd")
+    assert_close(n2, n2r, 4e-3, "norm2(out)")
     xn2, mean2, rstd2 = torch.empty_like(x), torch.empty_like(mean), torch.empty_like(rstd)
     check(lib.hs_layernorm_fwd(ptr(x), None, ptr(lg), ptr(lb), ptr(xn2), ptr(mean2), ptr(rstd2), B * N, C, _lib.HS_BF16, None), "ln")
     assert_close(mean, mean2, 1e-5, "mean")
@@ -324,6 +332,16 @@ def test_model_training_step_uses_the_train_form_and_matches_the_composition():
     y_f, g_f, n_f = step(True)
     y_c, g_c, n_c = step(False)
     assert n_f == 4 and n_c == 0
+    prev2, ops.FUSED_NORM2 = ops.FUSED_NORM2, not ops.FUSED_NORM2  # ... and with the block's norm2 inside the same launch (or outside)
+    try:
+        y_n, g_n, n_n = step(True)
+    finally:
+        ops.FUSED_NORM2 = prev2
+    assert n_n == 4
+    assert_close(y_n, y_f, 1e-2, "logits, norm2 fused vs separate")
+    for n in g_f:
+        from _util import errors as _e
+        assert _e(g_n[n], g_f[n])["scale_err"] <= 6e-2, n
     assert_close(y_f, y_c, 1e-2, "logits, train form vs composition")
     assert set(g_f) == set(g_c)
     worst = 0.0
@@ -373,7 +391,7 @@ def test_module_bwd_entry_point_equals_the_autograd_path(v1, cosine, strategy):
     check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(out), ptr(xn) if v1 else None, ptr(mean) if v1 else None, ptr(rstd) if v1 else None,
                                               ptr(qkv), ptr(o), ptr(lse), ptr(wq16), ptr(P["bq"]), ptr(wp16), ptr(P["bp"]),
                                               ptr(P["lg"]) if v1 else None, ptr(P["lb"]) if v1 else None, ptr(P["bias"]), ptr(P["hs"]),
-                                              ptr(idx), roll, ptr(labels), B, N, C, nH, 64, flags, _lib.HS_BF16, None), "fwd_train")
+                                              ptr(idx), roll, ptr(labels), None, None, None, None, None, B, N, C, nH, 64, flags, _lib.HS_BF16, None), "fwd_train")
     assert torch.equal(out, y.detach())
     ws = torch.empty(int(lib.hs_window_attn_module_bwd_workspace(B, N, C, nH, 64)), device=DEV)
     dx = torch.empty_like(x)

@@ -63,7 +63,7 @@ def main():
             from heal_swin_amd._lib import check, lib, ptr
             check(lib.hs_window_attn_module_fwd_train(ptr(x), ptr(tr["out"]), ptr(tr["xn"]), ptr(tr["mean"]), ptr(tr["rstd"]), ptr(tr["qkv"]),
                                                       ptr(tr["o"]), ptr(tr["lse"]), ptr(wqkv), ptr(bqkv), ptr(wp), ptr(bp), ptr(ln_g), ptr(ln_b),
-                                                      ptr(bias), ptr(hs), None, shift, ptr(labels), B, N, C, nH, 64, _lib.HS_ATTN_RESIDUAL,
+                                                      ptr(bias), ptr(hs), None, shift, ptr(labels), None, None, None, None, None, B, N, C, nH, 64, _lib.HS_ATTN_RESIDUAL,
                                                       _lib.HS_BF16, None), "train")
 
         def composed_train():
