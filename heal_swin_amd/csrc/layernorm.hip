@@ -693,24 +693,29 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
 }
 
 // Sum of the per-workgroup partial rows [nblocks][2 * width] into dgamma | dbeta (overwrite, or add when accumulate != 0) in
-// ONE launch: a workgroup owns 64 columns, each of its 16 waves folds every 16th row (256-byte row segments, 8 loads in
-// flight), the 16 wave sums are combined in a fixed order.  Deterministic.  (Two dependent launches -- a 16-group level and
-// a final level -- cost 10.4 us per LayerNorm backward, 100 times per step; this one ~4 us.)
+// ONE launch: a workgroup owns 16 columns, its 16 waves x 4 row phases fold every 64th row (8 loads in flight), the phases are
+// combined by shuffles and the 16 wave sums in a fixed order through LDS.  Deterministic.  (Two dependent launches -- a 16-group
+// level and a final level -- cost 10.4 us per LayerNorm backward, 100 times per step; 64 columns per workgroup 9.8 us in the step
+// at 512 columns -- 16 workgroups on 256 CUs; this form ~5 us.)
 constexpr int kReduceGroups = 16;  // (still sizes the workspace returned by hs_layernorm_bwd_workspace)
 __global__ void __launch_bounds__(1024) layernorm_param_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta, int nblocks, int width,
                                                                       int accumulate) {
-    __shared__ float part[16][64];
+    // a workgroup owns 16 columns (64 workgroups at 512 columns instead of 16: the 5 MB of partial rows are L2-resident and the
+    // launch was latency-bound on 16 CUs); lane -> (column lane % 16, row phase lane / 16), wave w folds rows 4 w + phase, + 64, ...
+    __shared__ float part[16][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int width2 = 2 * width, col = blockIdx.x * 64 + lane;
+    const int width2 = 2 * width, col = blockIdx.x * 16 + (lane & 15);
     float acc = 0.f;
     if (col < width2) {
 #pragma unroll 8
-        for (int b = wave; b < nblocks; b += 16) acc += partials[(size_t)b * width2 + col];
+        for (int b = wave * 4 + (lane >> 4); b < nblocks; b += 64) acc += partials[(size_t)b * width2 + col];
     }
-    part[wave][lane] = acc;
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 16) part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && col < width2) {
+    if (wave == 0 && lane < 16 && col < width2) {
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) tot += part[w][lane];
@@ -765,7 +770,7 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in, dadd_out,
                        ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed, v1_mode);
     HS_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 63) / 64), dim3(1024), 0, s, ws, dgamma, dbeta, blocks, width,
+    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(1024), 0, s, ws, dgamma, dbeta, blocks, width,
                        accumulate);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
     return HS_OK;
@@ -815,7 +820,7 @@ int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mea
     if (blocks > by_rows) blocks = by_rows;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in);
     HS_LAUNCH_CHECK("layernorm_bwd_fast");
-    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 63) / 64), dim3(1024), 0, s, ws, dgamma, dbeta, (int)blocks,
+    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(1024), 0, s, ws, dgamma, dbeta, (int)blocks,
                        width, accumulate);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
     return HS_OK;
