@@ -318,7 +318,7 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
                     int64_t rows, int n_out, int k_in, int accumulate, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused WindowAttention MODULE forward (inference / no-grad): the whole of WindowAttention.forward,
+ * Fused WindowAttention MODULE forward (inference form here, training form and the module backward below): the whole of WindowAttention.forward,
  * models_torch/swin_hp_transformer.py:124-174 -- qkv Linear, head split, (cosine | scaled) scores, relative-position bias,
  * shift mask, softmax, P V, head merge, proj Linear -- with the shift / window partition / reverse / shift back of
  * SwinTransformerBlock.forward (:319-330) and optionally the block's norm1 in front (:315) and residual add behind (:316):
