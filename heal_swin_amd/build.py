@@ -42,12 +42,27 @@ def _stamp():
     return h.hexdigest()
 
 
+def _unit_stamp(src):
+    """Hash of one translation unit: its source, every header it may include, the flags."""
+    h = hashlib.sha256()
+    for f in [src] + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/healswin.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(CXXFLAGS + [ARCH]).encode())
+    return h.hexdigest()
+
+
 def _compile(src):
     obj = os.path.join(BUILD_DIR, os.path.splitext(src)[0] + ".o")
+    unit_file, unit = obj + ".stamp", _unit_stamp(src)
+    if os.path.exists(obj) and os.path.exists(unit_file) and open(unit_file).read() == unit:
+        return obj, ""  # unchanged since its object was made (incremental rebuilds while iterating on one kernel)
     cmd = [_hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    with open(unit_file, "w") as fh:
+        fh.write(unit)
     return obj, r.stderr
 
 

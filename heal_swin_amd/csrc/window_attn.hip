@@ -94,6 +94,12 @@ int hs_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
     hipStream_t s = (hipStream_t)stream;
     const bool valu = (flags & HS_ATTN_FORCE_VALU) != 0;
     if (!valu && hs::attn_mfma_supported(p, dtype)) return hs::launch_attn_bwd_mfma(p, workspace, s);
+    // HS_ATTN_OVERWRITE_GRADS is a contract of the ENTRY POINT: the bf16 MFMA path writes dbias / dhead_scale, every other path
+    // accumulates -- so a caller that set the flag (and handed over uninitialised buffers) gets them zeroed here first
+    if (flags & HS_ATTN_OVERWRITE_GRADS) {
+        if (p.dbias) HS_HIP_CHECK(hipMemsetAsync(p.dbias, 0, sizeof(float) * (size_t)num_heads * window_size * window_size, s));
+        if (p.dhead_scale) HS_HIP_CHECK(hipMemsetAsync(p.dhead_scale, 0, sizeof(float) * (size_t)num_heads, s));
+    }
     if (!valu && hs::attn_mfma_f32_supported(p, dtype)) return hs::launch_attn_bwd_mfma_f32(p, workspace, s);
     return hs::launch_attn_bwd_generic(p, dtype, s);
 }

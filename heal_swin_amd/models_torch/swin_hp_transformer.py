@@ -821,7 +821,9 @@ class SwinHPTransformerSys(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("SwinHPTransformerSys (heal_swin_amd) runs only on an MI355X (HIP) device; there is no CPU path")
         if labels.dtype != torch.uint8 and self.data_spec.f_out <= 255:
-            labels = labels.to(torch.uint8)
+            # the kernels read one byte per pixel and ignore ids >= f_out.  A plain cast would WRAP (256 -> class 0, and
+            # CrossEntropyLoss' ignore_index -100 -> 156): out-of-range ids are mapped to 255 (ignored) before narrowing
+            labels = torch.where((labels < 0) | (labels > 254), 255, labels).to(torch.uint8)
         w = None if class_weights is None else class_weights.to(device=x.device, dtype=torch.float32).contiguous()
         dt = self._activation_dtype(x)
         prev, ops.RT.cast_cache = ops.RT.cast_cache, self._param_casts(dt)
@@ -835,6 +837,7 @@ class SwinHPTransformerSys(nn.Module):
 
     def _param_casts(self, dt):
         """bf16 copies of the Linear parameters, re-made in one multi-tensor kernel after each optimizer step (ops.ParamCastCache)."""
+        ops.note_forward(torch.is_grad_enabled())
         if dt == torch.float32:
             return None
         cache = self.__dict__.get("_cast_cache")

@@ -28,6 +28,7 @@ class RuntimeState:
       last_cast_cache    that of the most recent forward: what a backward falls back to when its node kept none
       prefer_own_gemm    every legal bf16 Linear product on hs_gemm_nt (set while CUs are reserved for a communication library)
       zero_padded_grads  data_ptr -> zero-padded gradient buffer written by losses.seg_loss' backward (weak values, see PadSliceFn)
+      weight_epoch       generation counter of "the parameters may have changed" for caches that cannot rely on `_version`
     One training setup per process is the supported configuration (as with DistributedDataParallel); `scoped` swaps fields for the
     duration of a block and restores them, which is how nested / temporary configurations should be expressed."""
 
@@ -38,6 +39,8 @@ class RuntimeState:
         self.last_cast_cache = None
         self.prefer_own_gemm = False
         self.zero_padded_grads = weakref.WeakValueDictionary()
+        self.weight_epoch = 0         # moves with every grad-enabled model forward (parameters may have been stepped): _weight_split
+        self._epoch_dirty = False
 
     @contextlib.contextmanager
     def scoped(self, **fields):
@@ -52,6 +55,14 @@ class RuntimeState:
 
 
 RT = RuntimeState()
+
+
+def note_forward(grad_enabled):
+    """Called by the model at the start of every forward: a grad-enabled forward (a training step: an optimizer step follows, and
+    fused optimizers do not bump `_version`) and the first no-grad forward after one open a new weight epoch."""
+    if grad_enabled or RT._epoch_dirty:
+        RT.weight_epoch += 1
+    RT._epoch_dirty = bool(grad_enabled)
 
 
 class _timed:
@@ -871,7 +882,23 @@ def _bf16x3_ok(x, n=None, k=None):
     2 n k flops at 110 TFLOP/s -- they are HBM-bound in fp32 already and the split passes would only add traffic (measured: the T
     depth-head companion 35.9 -> 33.2 images/s with bf16x3 everywhere)."""
     ok = FP32_GEMM == "bf16x3" and x.dtype == torch.float32 and x.is_cuda and x.shape[-1] % 8 == 0
-    return ok and (n is None or n * k >= _BF16X3_MIN * (n + k))
+    ok = ok and (n is None or n * k >= _BF16X3_MIN * (n + k))
+    if ok and _MM_OUT_DTYPE[0] is None:
+        _probe_mm_out_dtype(x.device)
+    return ok and _MM_OUT_DTYPE[0] is not False
+
+
+def _probe_mm_out_dtype(device):
+    """bf16x3 needs `torch.mm(bf16, bf16, out_dtype=float32)`; a build without it runs the exact-fp32 products instead (one warning)."""
+    try:
+        a = torch.zeros((8, 8), dtype=torch.bfloat16, device=device)
+        torch.mm(a, a, out_dtype=torch.float32)
+        _MM_OUT_DTYPE[0] = True
+    except Exception:  # noqa: BLE001  (a build without mm.dtype)
+        _MM_OUT_DTYPE[0] = False
+        import warnings
+        warnings.warn("heal_swin_amd: torch.mm(..., out_dtype=) is unavailable in this PyTorch build; fp32 Linear products run as "
+                      "exact fp32 GEMMs (HS_FP32_GEMM=strict behaviour) instead of bf16x3")
 
 
 def split3(x2d, mode):
@@ -922,35 +949,37 @@ def _split_of(x2d):
     return None
 
 
-_WSPLIT = {}  # (data_ptr, shape, transposed) -> (version, source weight, [hi | lo | hi] split): one split per weight and optimizer step
+_WSPLIT = {}  # (storage address, storage offset, shape, transposed) -> (version, weight epoch, view of the source, [hi | lo | hi] split)
+_WSPLIT_CAPACITY = 1024
 
 
 def _weight_split(w2d, transposed):
     """The [hi | lo | hi] operand (mode 1) of the fp32 weight w2d [n, k] -- or of its transpose [k, n] -- for the bf16x3 products.
-    A weight is read by its forward product and (transposed) by its input-gradient product once per step each: the split (and the
-    transpose copy in front of it) is made once per optimizer step (in-place updates bump `_version`) instead of per call."""
-    key = (w2d.data_ptr(), tuple(w2d.shape), bool(transposed))
+    Cached per weight: callers hand over fresh VIEWS of the parameter (`w.view(n, k)`), so an entry is identified by the storage
+    it views (address + offset + shape; the entry keeps a view alive, so the address cannot be recycled while it is cached) and is
+    valid while the parameter's `_version` (shared by all its views) AND `RT.weight_epoch` are unchanged.  The epoch moves with
+    every grad-enabled model forward, because fused optimizers update parameters WITHOUT bumping `_version` (see ParamCastCache):
+    in a training loop every weight is therefore split once per step and direction (forward, transposed for the input gradient);
+    evaluation loops, gradient accumulation under no_grad re-forwards and activation checkpointing re-use the cached operand."""
+    key = (w2d.untyped_storage().data_ptr(), w2d.storage_offset(), tuple(w2d.shape), tuple(w2d.stride()), bool(transposed))
     hit = _WSPLIT.get(key)
-    if hit is not None and hit[0] == w2d._version and hit[1] is w2d:
-        return hit[2]
+    if hit is not None and hit[0] == w2d._version and hit[1] == RT.weight_epoch:
+        return hit[3]
     src = w2d.t().contiguous() if transposed else w2d.contiguous()
     rows, k = src.shape
     out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=src.device)
     check(lib.hs_split_bf16x3(ptr(src), ptr(out), rows, k, 1, stream_ptr(src.device)), "hs_split_bf16x3")
-    if len(_WSPLIT) > 4096:  # (models come and go in a test session)
-        _WSPLIT.clear()
-    _WSPLIT[key] = (w2d._version, w2d, out)
+    if len(_WSPLIT) >= _WSPLIT_CAPACITY:  # (models come and go in a test session: bounded, oldest entries first)
+        for old in list(_WSPLIT)[:_WSPLIT_CAPACITY // 2]:
+            del _WSPLIT[old]
+    _WSPLIT[key] = (w2d._version, RT.weight_epoch, w2d.detach(), out)
     return out
 
 
 def _mm_f32(a3, b3t, bias=None):
     """fp32 result of the bf16 product a3 @ b3t (+ bias): hipBLASLt with an fp32 output (`out_dtype`)."""
     if _MM_OUT_DTYPE[0] is None:
-        try:
-            torch.mm(a3[:8], b3t, out_dtype=torch.float32)
-            _MM_OUT_DTYPE[0] = True
-        except Exception:  # noqa: BLE001  (a build without mm.dtype)
-            _MM_OUT_DTYPE[0] = False
+        _probe_mm_out_dtype(a3.device)
     if not _MM_OUT_DTYPE[0]:
         raise RuntimeError("HS_FP32_GEMM=bf16x3 needs torch.mm(..., out_dtype=torch.float32); set HS_FP32_GEMM=strict")
     if bias is None:
@@ -1116,6 +1145,12 @@ class LinearFn(torch.autograd.Function):
             # the column sums of dY_hi and dY_lo
             dy3 = dy2.t3 if isinstance(dy2, _Split) else split3(dy2, 0)
             x3 = x3 if x3 is not None else split3(x2, 0)
+            aw = RT.async_wgrad
+            if aw is not None and torch.cuda.current_stream(dev) == aw.stream:
+                # the splits were allocated on the main stream (memo / forward) and are read here on the side stream: tell the
+                # caching allocator, or a block evicted from the memo could be recycled under the lagging weight-gradient kernels
+                dy3.record_stream(aw.stream)
+                x3.record_stream(aw.stream)
             with _timed("linear_wgrad bf16x3", dev, 3 * 2 * rows * (n_out + k_in), 6 * rows * n_out * k_in):
                 for i, (yo, xo, dbp) in enumerate(((0, 0, db32), (0, 2 * k_in, None), (2 * n_out, 0, db32))):
                     check(lib.hs_linear_wgrad_ld(ptr(dy3), 3 * n_out, yo, ptr(x3), 3 * k_in, xo, ptr(dw32), ptr(dbp), ptr(ws), rows,

@@ -130,15 +130,58 @@ def test_bf16x3_policy_and_legality_helpers():
     class T:  # shape / dtype / device stand-in (the helpers never touch data)
         def __init__(self, k, dtype=torch.float32, cuda=True):
             self.shape, self.dtype, self.is_cuda = (4, k), dtype, cuda
-    prev = ops.FP32_GEMM
+    prev, prev_probe = ops.FP32_GEMM, ops._MM_OUT_DTYPE[0]
     try:
         ops.FP32_GEMM = "bf16x3"
+        ops._MM_OUT_DTYPE[0] = False  # a PyTorch build without mm(out_dtype=): every product stays exact fp32 instead of raising later
+        assert not ops._bf16x3_ok(T(512), 2048, 512)
+        ops._MM_OUT_DTYPE[0] = True
         assert ops._bf16x3_ok(T(512), 2048, 512) and ops._bf16x3_ok(T(512), 512, 512)   # stage 2 of HEAL-SWIN-B: MFMA-bound in fp32
         assert not ops._bf16x3_ok(T(128), 384, 128) and not ops._bf16x3_ok(T(96), 288, 96)  # stage 0: HBM-bound, stays exact fp32
         assert not ops._bf16x3_ok(T(512, torch.bfloat16), 2048, 512) and not ops._bf16x3_ok(T(516), 2048, 516)
         ops.FP32_GEMM = "strict"
         assert not ops._bf16x3_ok(T(512), 2048, 512)
     finally:
-        ops.FP32_GEMM = prev
+        ops.FP32_GEMM, ops._MM_OUT_DTYPE[0] = prev, prev_probe
     assert ops.own_gemm_legal(128, 512, torch.bfloat16) and not ops.own_gemm_legal(12, 128, torch.bfloat16)
     assert not ops.own_gemm_legal(128, 512, torch.float32)
+
+
+def test_weight_split_cache_hits_for_fresh_views_and_follows_the_weight_epoch(monkeypatch):
+    """callers pass `w.view(n, k)` / `w.reshape(...)` -- a new tensor object per call -- so an identity check
+    never hit.  The entry is now found by the storage it views; it is dropped when the parameter's version OR the weight epoch
+    (every grad-enabled forward: fused optimizers do not bump versions) has moved."""
+    from heal_swin_amd import ops
+    launches = []
+
+    class FakeLib:
+        def hs_split_bf16x3(self, *a):
+            launches.append(a)
+            return 0
+    monkeypatch.setattr(ops, "lib", FakeLib())
+    monkeypatch.setattr(ops, "ptr", lambda t: 0)
+    monkeypatch.setattr(ops, "stream_ptr", lambda d: 0)
+    ops._WSPLIT.clear()
+    w = torch.nn.Parameter(torch.randn(16, 8))
+    a = ops._weight_split(w.view(16, 8), False)
+    b = ops._weight_split(w.reshape(16, 8), False)      # another view object of the same storage: a hit
+    assert a is b and len(launches) == 1
+    t1 = ops._weight_split(w.view(16, 8), True)
+    t2 = ops._weight_split(w.detach().view(16, 8), True)
+    assert t1 is t2 and t1 is not a and len(launches) == 2
+    with torch.no_grad():
+        w.add_(1.0)                                      # a non-fused optimizer step bumps the shared version counter
+    assert ops._weight_split(w.view(16, 8), False) is not a and len(launches) == 3
+    n = len(launches)
+    ops.note_forward(True)                               # a training forward: parameters may have been stepped silently
+    ops._weight_split(w.view(16, 8), False)
+    assert len(launches) == n + 1
+    ops.note_forward(False)                              # first evaluation after training: one more epoch ...
+    ops._weight_split(w.view(16, 8), False)
+    ops.note_forward(False)                              # ... later evaluations re-use the operand
+    ops._weight_split(w.view(16, 8), False)
+    assert len(launches) == n + 2
+    for i in range(ops._WSPLIT_CAPACITY + 8):            # bounded: dead models do not pin their weights forever
+        ops._weight_split(torch.zeros(8, 8), False)
+    assert len(ops._WSPLIT) <= ops._WSPLIT_CAPACITY
+    ops._WSPLIT.clear()
