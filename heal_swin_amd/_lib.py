@@ -16,6 +16,7 @@ HS_ATTN_FORCE_VALU = 2
 HS_ATTN_RESIDUAL = 4
 HS_ATTN_OVERWRITE_GRADS = 8
 HS_EPI_BIAS, HS_EPI_GELU, HS_EPI_DGELU, HS_EPI_RESID = 0, 1, 2, 3
+HS_ACC_DEFER = 2
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
@@ -58,6 +59,7 @@ _SIGNATURES = {
     "hs_gelu_bwd": [c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_residual_drop": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
+    "hs_reduce_flush": [c_ptr],
     "hs_split_bf16x3": [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
     "hs_gelu_split3": [c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.c_float, ctypes.c_uint64, c_ptr],
     "hs_linear_wgrad_ld": [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
@@ -103,6 +105,7 @@ _OTHER = {
     "hs_status_string": ([c_int], ctypes.c_char_p),
     "hs_device_count": ([], c_int),
     "hs_get_reserved_cus": ([], c_int),
+    "hs_reduce_pending": ([c_ptr], c_int),
     "hs_layernorm_bwd_workspace": ([c_i64, c_int], c_i64),
     "hs_seg_ce_partials": ([c_i64, c_i64], c_i64),
     "hs_ln_head_partials": ([c_i64], c_i64),

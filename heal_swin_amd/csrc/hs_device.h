@@ -84,6 +84,11 @@ inline int hip_fail(hipError_t e, const char* what) {
     return fail(HS_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+// csrc/reduce_many.hip: queue the record-wise sum of `slices` partial records (count floats each, stride in_stride; the first n_w
+// go to dw, the rest to db) for the next hs_reduce_flush on stream s, instead of launching it now
+int reduce_defer(const float* part, int64_t in_stride, int slices, int64_t n_w, int64_t count, float* dw, float* db, int accumulate,
+                 hipStream_t s);
+
 }  // namespace hs
 
 #define HS_HIP_CHECK(expr)                                   \

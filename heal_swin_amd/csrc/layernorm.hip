@@ -770,6 +770,9 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in, dadd_out,
                        ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed, v1_mode);
     HS_LAUNCH_CHECK("layernorm_bwd");
+    if ((accumulate & HS_ACC_DEFER) && width % 4 == 0)  // the parameter reduce joins the stream's deferred queue (csrc/reduce_many.hip)
+        return reduce_defer(ws, 2 * width, blocks, width, 2 * width, dgamma, dbeta, accumulate & 1, s);
+    accumulate &= 1;
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(1024), 0, s, ws, dgamma, dbeta, blocks, width,
                        accumulate);
     HS_LAUNCH_CHECK("layernorm_param_reduce");
@@ -820,6 +823,9 @@ int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mea
     if (blocks > by_rows) blocks = by_rows;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in);
     HS_LAUNCH_CHECK("layernorm_bwd_fast");
+    if ((accumulate & HS_ACC_DEFER) && width % 4 == 0)
+        return reduce_defer(ws, 2 * width, (int)blocks, width, 2 * width, dgamma, dbeta, accumulate & 1, s);
+    accumulate &= 1;
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(1024), 0, s, ws, dgamma, dbeta, (int)blocks,
                        width, accumulate);
     HS_LAUNCH_CHECK("layernorm_param_reduce");

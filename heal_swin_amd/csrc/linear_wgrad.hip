@@ -799,6 +799,9 @@ int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, fl
         hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g);
     HS_LAUNCH_CHECK("linear_wgrad");
     const int64_t count = dbias ? rec : n;  // without a bias the tail of each record is never written nor read
+    if (accumulate & HS_ACC_DEFER)  // the slice sum joins the stream's queue of deferred reductions (csrc/reduce_many.hip)
+        return reduce_defer(part_w, rec, g.slices, n, count, dw, dbias, accumulate & 1, s);
+    accumulate &= 1;
     const unsigned bx = (unsigned)((count / 4 + 255) / 256);
     if (g.chunks > 1) {
         hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, g.chunks), dim3(256), 0, s, part_w, rec, mid, nullptr, nullptr, g.slices,

@@ -4,6 +4,7 @@ PyTorch owns the memory (caching allocator), the stream and the autograd graph; 
 below runs in the HIP library.  All ops require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
 """
 import contextlib
+import ctypes
 import math
 import os
 import weakref
@@ -406,6 +407,43 @@ def _sink_buffer(p):
     return None if (sink is None or p is None) else sink.grad_buffer(p)
 
 
+# Deferred parameter-gradient reductions (csrc/reduce_many.hip, include/healswin.h: HS_ACC_DEFER).  A kernel that deposits into the
+# gradient sink's buffers queues its final "sum the partial records" step instead of launching it; the sink flushes the queue --
+# ONE launch for up to 44 sums -- before it exchanges a bucket and at the end of the pass (GradBucketAllReduce._launch / finish).
+# The partial records live in the call's workspace, which therefore stays referenced here until the flush.
+DEFER_REDUCTIONS = os.environ.get("HS_DEFER_REDUCE", "1") != "0"
+_DEFER_KEEP = {}   # stream handle -> workspaces of the queued sums
+_DEFER_FLUSH_AT = 32
+
+
+def _defer_flag(device):
+    """HS_ACC_DEFER if a direct-deposit call on `device`'s current stream may queue its reduction, else 0: a sink that flushes is
+    installed, and the weight-gradient kernels are not on a side stream."""
+    sink = RT.grad_sink
+    ok = DEFER_REDUCTIONS and sink is not None and RT.async_wgrad is None and getattr(sink, "flushes_reductions", False)
+    return _lib.HS_ACC_DEFER if ok else 0
+
+
+def _defer_keep(device, *workspaces):
+    s = torch.cuda.current_stream(device).cuda_stream
+    keep = _DEFER_KEEP.setdefault(s, [])
+    keep.extend(workspaces)
+    if int(lib.hs_reduce_pending(ctypes.c_void_p(s))) >= _DEFER_FLUSH_AT:
+        flush_reductions(device)
+
+
+def flush_reductions(device=None):
+    """Launch every queued parameter-gradient sum of the current stream (of `device`, default: the current device) and release
+    the workspaces they read.  Cheap when nothing is queued (no launch)."""
+    if not torch.cuda.is_available():
+        return
+    s = torch.cuda.current_stream(device).cuda_stream
+    check(lib.hs_reduce_flush(ctypes.c_void_p(s)), "hs_reduce_flush")
+    keep = _DEFER_KEEP.get(s)
+    if keep:
+        keep.clear()
+
+
 def _norm_param_grads(weight, bias, width, device, want):
     """Buffers the LayerNorm backward writes dgamma / dbeta to: under a RT.grad_sink that knows both parameters their fp32
     gradient buffers (the kernel ADDS, autograd sees no gradient and launches no AccumulateGrad kernels), otherwise fresh
@@ -494,18 +532,21 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma, dbeta, direct = _norm_param_grads(weight, bias, width, x.device, ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=x.device)
+        acc = (1 | _defer_flag(x.device)) if direct else 0
         if dx_alias is not None:
             check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(dx_alias.contiguous()), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx),
-                                           ptr(dgamma), ptr(dbeta), ptr(ws), int(direct), rows, width, dt, stream_ptr(x.device)),
+                                           ptr(dgamma), ptr(dbeta), ptr(ws), acc, rows, width, dt, stream_ptr(x.device)),
                   "hs_add_layernorm_bwd")
         elif extras is None:
             check(lib.hs_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                       int(direct), rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
+                                       acc, rows, width, dt, stream_ptr(x.device)), "hs_layernorm_bwd")
         else:
             _, rps, p, seed = extras
             check(lib.hs_layernorm_drop_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
-                                            ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
+                                            ptr(ws), acc, ptr(rs), rps, p, seed, rows, width, dt, stream_ptr(x.device)),
                   "hs_layernorm_drop_bwd")
+        if acc & _lib.HS_ACC_DEFER:
+            _defer_keep(x.device, ws)
         dw, db = _norm_param_result(weight, bias, dgamma, dbeta, direct)
         return dx, dw, db, (dy if has_res else None), None, None, None, None, None
 
@@ -586,17 +627,20 @@ class AddLayerNormFn(torch.autograd.Function):
         da = torch.empty_like(s)
         dgamma, dbeta, direct = _norm_param_grads(weight, bias, width, s.device, ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, width)), dtype=torch.float32, device=s.device)
+        acc = (1 | _defer_flag(s.device)) if direct else 0
         if extras is None:
             check(lib.hs_add_layernorm_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(da), ptr(dgamma),
-                                           ptr(dbeta), ptr(ws), int(direct), rows, width, dt, stream_ptr(s.device)),
+                                           ptr(dbeta), ptr(ws), acc, rows, width, dt, stream_ptr(s.device)),
                   "hs_add_layernorm_bwd")
             db = da
         else:
             _, rps, p, seed = extras
             db = torch.empty_like(s)
             check(lib.hs_add_layernorm_drop_bwd(ptr(dy), ptr(ds_c), ptr(s), ptr(g), ptr(mean), ptr(rstd), ptr(da), ptr(db),
-                                                ptr(dgamma), ptr(dbeta), ptr(ws), int(direct), ptr(rs), rps, p, seed, rows, width,
+                                                ptr(dgamma), ptr(dbeta), ptr(ws), acc, ptr(rs), rps, p, seed, rows, width,
                                                 dt, stream_ptr(s.device)), "hs_add_layernorm_drop_bwd")
+        if acc & _lib.HS_ACC_DEFER:
+            _defer_keep(s.device, ws)
         dw, dbias = _norm_param_result(weight, bias, dgamma, dbeta, direct)
         return da, db, dw, dbias, None, None, None
 
@@ -1134,11 +1178,14 @@ class LinearFn(torch.autograd.Function):
         rows = dy2.shape[0]
         dev = dy2.device
         accumulate = 1 if dw_out is not None else 0
+        # deposits into the gradient sink's buffers queue their slice sums (one launch per ~32 layers, ops.flush_reductions)
+        defer = _defer_flag(dev) if (dw_out is not None and (db_out is not None or not want_b)) else 0
         dw32 = dw_out if dw_out is not None else torch.empty((n_out, k_in), dtype=torch.float32, device=dev)
         db32 = None
         if want_b:
             db32 = db_out if db_out is not None else torch.empty(n_out, dtype=torch.float32, device=dev)
-        ws = torch.empty(int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in)), dtype=torch.float32, device=dev)
+        nws = int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in))
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
         if x3 is not None or (_bf16x3_ok(x2, n_out, k_in) and n_out % 8 == 0 and x2.dtype == dy2.dtype):
             # dW = dY^T X as three bf16 weight-gradient products over the hi / lo column blocks of the [hi | hi | lo] splits
             # (the split of dY is shared with the input-gradient product): hi^T hi + hi^T lo + lo^T hi; the bias gradient takes
@@ -1153,12 +1200,18 @@ class LinearFn(torch.autograd.Function):
                 x3.record_stream(aw.stream)
             with _timed("linear_wgrad bf16x3", dev, 3 * 2 * rows * (n_out + k_in), 6 * rows * n_out * k_in):
                 for i, (yo, xo, dbp) in enumerate(((0, 0, db32), (0, 2 * k_in, None), (2 * n_out, 0, db32))):
+                    if defer and i:  # (a queued sum reads its partial records at the flush: one workspace per product)
+                        ws = torch.empty(nws, dtype=torch.float32, device=dev)
                     check(lib.hs_linear_wgrad_ld(ptr(dy3), 3 * n_out, yo, ptr(x3), 3 * k_in, xo, ptr(dw32), ptr(dbp), ptr(ws), rows,
-                                                 n_out, k_in, 1 if (accumulate or i) else 0, stream_ptr(dev)), "hs_linear_wgrad_ld")
+                                                 n_out, k_in, (1 if (accumulate or i) else 0) | defer, stream_ptr(dev)), "hs_linear_wgrad_ld")
+                    if defer:
+                        _defer_keep(dev, ws)
             return dw32, db32
         with _timed("linear_wgrad", dev, x2.element_size() * rows * (n_out + k_in), 2 * rows * n_out * k_in):
-            check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate,
+            check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate | defer,
                                       _lib.dtype_code(x2.dtype), stream_ptr(dev)), "hs_linear_wgrad")
+        if defer:
+            _defer_keep(dev, ws)
         return dw32, db32
 
     @staticmethod

@@ -137,6 +137,8 @@ class GradBucketAllReduce:
         checkpointing) and `loss1.backward(retain_graph=True); loss2.backward()` need finish() in between or no_sync()."""
         for _, w in getattr(self, "_works", []):
             w.wait()
+        if getattr(self, "_direct", False):
+            self._flush_reductions()  # (sums an aborted pass left queued must not land on the zeroed buckets)
         for flat in self.buckets:
             flat.zero_()
         for p, view in self._views.items():
@@ -251,8 +253,18 @@ class GradBucketAllReduce:
         if self._pending[b] == 0 and self._sync and self._exchange:
             self._launch(b)
 
+    flushes_reductions = True  # (ops._defer_flag) this sink launches the queued parameter-gradient sums before it reads a bucket
+
+    @staticmethod
+    def _flush_reductions():
+        if torch.cuda.is_available():
+            from . import ops
+            ops.flush_reductions()
+
     def _launch(self, b):
         flat = self.buckets[b]
+        if self._direct:
+            self._flush_reductions()  # kernels may have QUEUED their final sums into this bucket (ops.flush_reductions)
         if self.async_wgrad is not None:
             self.async_wgrad.sync()  # gradients deposited from the side stream must have landed before the exchange
         buf = flat
@@ -275,6 +287,8 @@ class GradBucketAllReduce:
         has launched); call after backward(), before optimizer.step()."""
         if self.async_wgrad is not None:
             self.async_wgrad.sync()
+        if self._direct:
+            self._flush_reductions()
         if self._exchange and self._sync:
             for b, left in enumerate(self._pending):
                 if self._launched[b]:

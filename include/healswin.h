@@ -318,6 +318,20 @@ int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, floa
                     int64_t rows, int n_out, int k_in, int accumulate, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Deferred parameter-gradient reductions.  hs_linear_wgrad / hs_linear_wgrad_ld and the four LayerNorm backward entry points
+ * (hs_layernorm_bwd, hs_add_layernorm_bwd, hs_layernorm_drop_bwd, hs_add_layernorm_drop_bwd) end in a small "sum the
+ * per-workgroup partial records into dw / dbias (dgamma / dbeta)" launch.  With HS_ACC_DEFER or-ed into `accumulate` that sum is
+ * QUEUED on the call's stream instead of launched; hs_reduce_flush(stream) folds every queued sum of that stream in ONE launch
+ * (deterministic order; the queue also flushes itself when it is full).  Contract of a deferring caller: the call's `workspace`
+ * stays allocated and untouched until the flush, and nobody reads the gradient buffers before it.  The reference has no
+ * counterpart (autograd of nn.Linear / nn.LayerNorm, models_torch/swin_hp_transformer.py:33-35, :116-118, :256-262): this is
+ * how 340 launches per HEAL-SWIN-B training step become about 10.
+ * ---------------------------------------------------------------------------------------------- */
+#define HS_ACC_DEFER 2 /* or-ed into `accumulate` (bit 0: add to the existing contents) */
+int hs_reduce_pending(void* stream); /* queued sums of that stream */
+int hs_reduce_flush(void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused WindowAttention MODULE forward (inference form here, training form and the module backward below): the whole of WindowAttention.forward,
  * models_torch/swin_hp_transformer.py:124-174 -- qkv Linear, head split, (cosine | scaled) scores, relative-position bias,
  * shift mask, softmax, P V, head merge, proj Linear -- with the shift / window partition / reverse / shift back of
