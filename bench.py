@@ -331,6 +331,8 @@ def main():
                     help="(maintenance) run PyTorch TunableOp tuning over this workload's library GEMMs during the warm-up and "
                          "write the results file CSV (copy it to heal_swin_amd/tuning/); the timed numbers of such a run are not a benchmark")
     ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="step torch.optim.Adam(fused=True) instead of heal_swin_amd.optim.FlatAdam (same arithmetic; A/B runs)")
     ap.add_argument("--reserved-cus", default="auto",
                     help="compute units the chip-filling launches leave free for RCCL (multiple of 8; auto: 16 when N > 1, else 0)")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient buckets")
@@ -446,6 +448,7 @@ def main():
             "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}",
                        "step": "fwd + CE loss + bwd + grad all-reduce + Adam" + ("" if args.unfused_loss else " (loss fused into the decoder tail: model.forward_seg_loss)"),
+                       "optimizer": "torch.optim.Adam(fused=True)" if args.torch_adam else "heal_swin_amd.optim.FlatAdam (torch.optim.Adam arithmetic on flat buffers)",
                        "launch": "hip graph replay" if args.graph else "eager",
                        "params_M": res.params_m, "final_loss": res.loss, "peak_device_memory_GB": res.peak_gb,
                        "library_gemm_selection": gemm_selection},
@@ -714,7 +717,13 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
     dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad,
                              reserved_cus=args.reserved_cus if args.reserved_cus == "auto" else int(args.reserved_cus),
                              comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else None)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=args.graph)  # ref: training/optimizer.py:57-66
+    if args.torch_adam:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=args.graph)  # ref: training/optimizer.py:57-66
+    else:
+        # the same Adam on flat parameter / moment buffers laid out like the gradient buckets: one launch per bucket, which also
+        # writes the bf16 parameter copies the next forward reads (heal_swin_amd/optim.py, csrc/adam.hip)
+        from heal_swin_amd.optim import FlatAdam
+        opt = FlatAdam(model.parameters(), dp, lr=1e-4, model=model if dtype_name == "bf16" else None)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     imgs = torch.randint(0, 256, (batch, 3, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)

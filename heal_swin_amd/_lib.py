@@ -22,6 +22,7 @@ c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
 c_uint = ctypes.c_uint
 c_ptr = ctypes.c_void_p
+c_float = ctypes.c_float
 
 # name -> argtypes; every function returns int status unless listed in _OTHER_RESTYPE
 _SIGNATURES = {
@@ -60,6 +61,8 @@ _SIGNATURES = {
     "hs_residual_drop": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     "hs_reduce_flush": [c_ptr],
+    "hs_adam_step": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_float, c_ptr, c_float, c_float, c_float, c_float, c_int, c_ptr, c_ptr],
+    "hs_adam_advance": [c_ptr, c_ptr],
     "hs_split_bf16x3": [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],
     "hs_gelu_split3": [c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.c_float, ctypes.c_uint64, c_ptr],
     "hs_linear_wgrad_ld": [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],

@@ -844,7 +844,7 @@ class SwinHPTransformerSys(nn.Module):
         params = [p for m in self.modules() if isinstance(m, HSLinear) for p in (m.weight, m.bias) if p is not None]
         if (cache is None or cache.dtype != dt or len(cache.params) != len(params) or any(a is not b for a, b in zip(cache.params, params))
                 or any(sh.device != p.device for sh, p in zip(cache.shadows[:1], params[:1]))):
-            cache = ops.ParamCastCache(params, dt)
+            cache = ops.ParamCastCache(params, dt, shadow_of=self.__dict__.get("_shadow_provider"))  # (optim.FlatAdam)
             self.__dict__["_cast_cache"] = cache  # not a module attribute: stays out of state_dict / .to()
         cache.refresh(force=torch.is_grad_enabled())  # (fused optimizers do not bump parameter versions: see ops.ParamCastCache)
         return cache

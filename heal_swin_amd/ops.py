@@ -759,10 +759,15 @@ class ParamCastCache:
 
     always_refresh = False
 
-    def __init__(self, params, dtype):
+    def __init__(self, params, dtype, shadow_of=None):
+        """shadow_of(p, dtype) -> tensor | None: storage for p's copy owned by someone who keeps it current (optim.FlatAdam writes
+        the bf16 parameters from its step kernel and calls mark_refreshed_externally(): no copy pass at the next forward)."""
         self.params = [p for p in params if p.dtype != dtype]
         self.dtype = dtype
-        self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
+        ext = [None if shadow_of is None else shadow_of(p, dtype) for p in self.params]
+        self.all_external = bool(ext) and all(e is not None and e.shape == p.shape and e.device == p.device for e, p in zip(ext, self.params))
+        self.shadows = ext if self.all_external else [torch.empty_like(p, dtype=dtype) for p in self.params]
+        self.external_fresh = False
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.versions = None
         self.dirty = False    # a grad-enabled forward has run since the last refresh: the parameters are about to change
@@ -772,8 +777,17 @@ class ParamCastCache:
     def invalidate(self):
         self.versions = None
 
+    def mark_refreshed_externally(self):
+        """The owner of the shadows (optim.FlatAdam.step) has just written every one of them from the updated parameters."""
+        if self.all_external:
+            self.versions = [(p.data_ptr(), p._version) for p in self.params]  # (a new list: the transposed copies are re-made)
+            self.external_fresh = True
+
     def refresh(self, force=False):
         versions = [(p.data_ptr(), p._version) for p in self.params]
+        if self.external_fresh and versions == self.versions and not self.always_refresh:
+            self.dirty = False  # the optimizer that steps these parameters keeps the copies current: nothing to do
+            return
         if force or self.dirty or self.always_refresh or versions != self.versions:
             with torch.no_grad():
                 torch._foreach_copy_(self.shadows, self.params)

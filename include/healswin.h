@@ -332,6 +332,19 @@ int hs_reduce_pending(void* stream); /* queued sums of that stream */
 int hs_reduce_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimizer step over flat buffers: torch.optim.Adam / AdamW (the reference's training/optimizer.py:57-66; amsgrad = False,
+ * maximize = False) on n consecutive fp32 parameters p with gradients g and moments m, v, all [dev] f32[n], 16-byte aligned:
+ *     g += wd p (decoupled == 0)  |  p *= 1 - lr wd (decoupled != 0: AdamW)
+ *     m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ *   t = *step + 1 with step [dev] int64 (the steps taken so far; hs_adam_advance adds 1 after the last buffer of a step);
+ *   lr_dev [dev] f32[1] overrides lr when non-NULL; p_bf16 [dev] bf16[n] (may be NULL) receives the updated parameters rounded to
+ *   bf16 -- the copy the next forward's GEMMs read, written from the registers that hold the new value.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, const float* lr_dev, float beta1,
+                 float beta2, float eps, float weight_decay, int decoupled, const int64_t* step, void* stream);
+int hs_adam_advance(int64_t* step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused WindowAttention MODULE forward (inference form here, training form and the module backward below): the whole of WindowAttention.forward,
  * models_torch/swin_hp_transformer.py:124-174 -- qkv Linear, head split, (cosine | scaled) scores, relative-position bias,
  * shift mask, softmax, P V, head merge, proj Linear -- with the shift / window partition / reverse / shift back of
