@@ -88,6 +88,9 @@ inline int hip_fail(hipError_t e, const char* what) {
 // go to dw, the rest to db) for the next hs_reduce_flush on stream s, instead of launching it now
 int reduce_defer(const float* part, int64_t in_stride, int slices, int64_t n_w, int64_t count, float* dw, float* db, int accumulate,
                  hipStream_t s);
+// ... or launch it at once (same kernel, same summation order)
+int reduce_now(const float* part, int64_t in_stride, int slices, int64_t n_w, int64_t count, float* dw, float* db, int accumulate,
+               hipStream_t s);
 
 }  // namespace hs
 

@@ -772,6 +772,7 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     HS_LAUNCH_CHECK("layernorm_bwd");
     if ((accumulate & HS_ACC_DEFER) && width % 4 == 0)  // the parameter reduce joins the stream's deferred queue (csrc/reduce_many.hip)
         return reduce_defer(ws, 2 * width, blocks, width, 2 * width, dgamma, dbeta, accumulate & 1, s);
+    if (width % 4 == 0) return reduce_now(ws, 2 * width, blocks, width, 2 * width, dgamma, dbeta, accumulate & 1, s);
     accumulate &= 1;
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(1024), 0, s, ws, dgamma, dbeta, blocks, width,
                        accumulate);
@@ -825,6 +826,7 @@ int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mea
     HS_LAUNCH_CHECK("layernorm_bwd_fast");
     if ((accumulate & HS_ACC_DEFER) && width % 4 == 0)
         return reduce_defer(ws, 2 * width, (int)blocks, width, 2 * width, dgamma, dbeta, accumulate & 1, s);
+    if (width % 4 == 0) return reduce_now(ws, 2 * width, (int)blocks, width, 2 * width, dgamma, dbeta, accumulate & 1, s);
     accumulate &= 1;
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * width + 15) / 16), dim3(1024), 0, s, ws, dgamma, dbeta, (int)blocks,
                        width, accumulate);

@@ -693,36 +693,6 @@ __global__ void __launch_bounds__(256, 3) wgrad_dma_f32_kernel(const float* __re
 #endif
 }
 
-// Sums the slices of chunk blockIdx.y of the partial records part[s * in_stride + 0..count) (n_w weight entries followed
-// by bias entries).  Intermediate pass (final_pass == 0): out[chunk * count + 0..count).  Final pass: weights to dw, bias
-// to db (skipped if null), added to the existing contents when accumulate != 0.
-__global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int64_t in_stride,
-                                                            float* __restrict__ out, float* __restrict__ dw,
-                                                            float* __restrict__ db, int slices, int64_t n_w, int64_t count,
-                                                            int final_pass, int accumulate) {
-    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;  // n_w and count are multiples of 4
-    if (e >= count) return;
-    const int per = (slices + gridDim.y - 1) / gridDim.y;
-    const int s_begin = blockIdx.y * per;
-    const int s_end = s_begin + per < slices ? s_begin + per : slices;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int s = s_begin; s < s_end; ++s) {  // unrolled: independent loads in flight, same summation order
-        const float4 v = *(const float4*)(part + (int64_t)s * in_stride + e);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    float* dst;
-    if (!final_pass) dst = out + (int64_t)blockIdx.y * count + e;
-    else if (e < n_w) dst = dw + e;
-    else if (db) dst = db + (e - n_w);
-    else return;
-    if (final_pass && accumulate) {
-        const float4 o = *(const float4*)dst;
-        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
-    }
-    *(float4*)dst = acc;
-}
-
 }  // namespace
 }  // namespace hs
 
@@ -779,7 +749,6 @@ int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, fl
     const int64_t n = (int64_t)n_out * k_in, rec = n + n_out;
     float* part_w = workspace;
     float* part_b = dbias ? workspace + n : nullptr;  // bias partials live behind each slice's weight partial
-    float* mid = workspace + (int64_t)g.slices * rec;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(8 * g.per_xcd));
     const uint16_t* dyp = (const uint16_t*)dy;
@@ -801,20 +770,7 @@ int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, fl
     const int64_t count = dbias ? rec : n;  // without a bias the tail of each record is never written nor read
     if (accumulate & HS_ACC_DEFER)  // the slice sum joins the stream's queue of deferred reductions (csrc/reduce_many.hip)
         return reduce_defer(part_w, rec, g.slices, n, count, dw, dbias, accumulate & 1, s);
-    accumulate &= 1;
-    const unsigned bx = (unsigned)((count / 4 + 255) / 256);
-    if (g.chunks > 1) {
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, g.chunks), dim3(256), 0, s, part_w, rec, mid, nullptr, nullptr, g.slices,
-                           n, count, 0, 0);
-        HS_LAUNCH_CHECK("linear_wgrad reduce 1");
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, mid, count, nullptr, dw, dbias, g.chunks, n, count,
-                           1, accumulate);
-    } else {
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, 1), dim3(256), 0, s, part_w, rec, nullptr, dw, dbias, g.slices, n, count,
-                           1, accumulate);
-    }
-    HS_LAUNCH_CHECK("linear_wgrad reduce");
-    return HS_OK;
+    return reduce_now(part_w, rec, g.slices, n, count, dw, dbias, accumulate & 1, s);
 }
 }  // namespace
 

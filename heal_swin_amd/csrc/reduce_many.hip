@@ -30,7 +30,7 @@ struct ReduceJob {
     int64_t count;
     int slices;
     int accumulate;
-    int phases;      // 1, 4 or 16
+    int phases;      // 1, 4, 16 or 64
     int first_block;
 };
 
@@ -88,6 +88,10 @@ __global__ void __launch_bounds__(256) reduce_many_kernel(const ReduceTable t) {
     *(float4*)dst = acc;
 }
 
+// row phases per record stack: one thread per column for short stacks, up to 64 rows walked side by side for tall ones (the 2048
+// partial rows of a LayerNorm backward: 64 workgroups x 32 rows per thread, as the dedicated kernel this replaced)
+int reduce_phases(int slices) { return slices <= 8 ? 1 : (slices <= 64 ? 4 : (slices <= 256 ? 16 : 64)); }
+
 }  // namespace
 
 static int flush_locked(hipStream_t s) {
@@ -129,11 +133,35 @@ int reduce_defer(const float* part, int64_t in_stride, int slices, int64_t n_w, 
     q.count = count;
     q.slices = slices;
     q.accumulate = accumulate ? 1 : 0;
-    q.phases = slices <= 8 ? 1 : (slices <= 64 ? 4 : 16);
+    q.phases = reduce_phases(slices);
     q.first_block = t.total_blocks;
     const int cols = 256 / q.phases;
     t.total_blocks += (int)((count / 4 + cols - 1) / cols);
     ++t.n;
+    return HS_OK;
+}
+
+// The same sum launched at once (a one-job table): the immediate and the deferred form of a reduction share kernel and summation
+// order, so a gradient does not depend on whether its sum was queued.
+int reduce_now(const float* part, int64_t in_stride, int slices, int64_t n_w, int64_t count, float* dw, float* db, int accumulate,
+               hipStream_t s) {
+    ReduceTable t{};
+    ReduceJob& q = t.job[0];
+    q.part = part;
+    q.dw = dw;
+    q.db = db;
+    q.in_stride = in_stride;
+    q.n_w = n_w;
+    q.count = count;
+    q.slices = slices;
+    q.accumulate = accumulate ? 1 : 0;
+    q.phases = reduce_phases(slices);
+    q.first_block = 0;
+    const int cols = 256 / q.phases;
+    t.n = 1;
+    t.total_blocks = (int)((count / 4 + cols - 1) / cols);
+    hipLaunchKernelGGL(reduce_many_kernel, dim3((unsigned)t.total_blocks), dim3(256), 0, s, t);
+    HS_LAUNCH_CHECK("reduce_now");
     return HS_OK;
 }
 
