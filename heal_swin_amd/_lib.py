@@ -61,6 +61,10 @@ _SIGNATURES = {
     "hs_residual_drop": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     "hs_reduce_flush": [c_ptr],
+    "hs_mlp_fused_supported": [c_int, c_int, c_int],
+    "hs_mlp_fused_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_uint,
+                         c_int, c_ptr],
+    "hs_mlp_fused_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_adam_step": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_float, c_ptr, c_float, c_float, c_float, c_float, c_int, c_ptr, c_ptr],
     "hs_adam_advance": [c_ptr, c_ptr],
     "hs_split_bf16x3": [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],

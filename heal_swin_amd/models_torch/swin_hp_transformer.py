@@ -318,6 +318,16 @@ class SwinTransformerBlock(nn.Module):
         """per-sample DropPath factor of one branch ([B] tensor) or None"""
         return self.drop_path.sample_scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
 
+    def _fused_mlp(self, x1):
+        """x1 + mlp(norm2(x1)) by the one-launch Mlp block kernel (ops.fused_mlp_block) where it applies: HIP norms, exact GELU,
+        hidden = 4 C at C = 96 / 128, nothing stochastic on the branch; else None."""
+        m = self.mlp
+        if (isinstance(self.norm2, HSLayerNorm) and isinstance(m.fc1, HSLinear) and isinstance(m.fc2, HSLinear) and
+                isinstance(m.act, nn.GELU) and getattr(m.act, "approximate", "none") == "none" and not self._stochastic() and
+                not (self.training and m.drop.p > 0) and ops.fused_mlp_ok(x1, m.fc1.weight.shape[0]) and m.fc2.weight.shape[0] == self.dim):
+            return ops.fused_mlp_block(x1, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+        return None
+
     def can_defer(self):
         """v1 placement with the HIP norms: both residual adds -- together with the dropout / DropPath on the added branch --
         ride on the LayerNorm kernel that consumes the sum."""
@@ -343,6 +353,9 @@ class SwinTransformerBlock(nn.Module):
             xs = self.resolve_pending(x, pending)
             idx, roll, labels = self._shift_args(xs)
             x1 = self.attn.fused_module(xs, self.window_size, idx, roll, labels, norm=self.norm1, residual=True)
+            x2 = self._fused_mlp(x1)  # ... and x2 = x1 + mlp(norm2(x1)) as a second one
+            if x2 is not None:
+                return x2, None, None
             m = self.mlp(self.norm2(x1), apply_out_drop=False)
             return x1, (m, None, 0.0), None
         if ops.RESID_EPILOGUE and x.dtype == torch.bfloat16 and not comp and x_lo is None and not self._stochastic():
@@ -360,6 +373,9 @@ class SwinTransformerBlock(nn.Module):
                     n2, x1 = self.attn.fused_module_train(x, self.window_size, idx, roll, labels, self.norm1, norm2=self.norm2)
                 else:
                     x1 = self.attn.fused_module_train(x, self.window_size, idx, roll, labels, self.norm1)
+                    x2 = self._fused_mlp(x1)  # norm2 -> fc1 -> GELU -> fc2 -> residual add in one launch as well
+                    if x2 is not None:
+                        return x2, None, None
                     n2, x1 = ops.layer_norm_passthrough(x1, self.norm2.weight, self.norm2.bias)
                 if fc2_own:
                     return self.mlp(n2, apply_out_drop=False, residual=x1), None, None
@@ -372,6 +388,9 @@ class SwinTransformerBlock(nn.Module):
                     xs, n1 = ops.add_layer_norm(x, t, self.norm1.weight, self.norm1.bias, row_scale=rs, drop_p=dp)
                 if proj_own:
                     x1 = self._attention_branch(n1, apply_proj_drop=False, residual=xs)
+                    x2 = self._fused_mlp(x1)
+                    if x2 is not None:
+                        return x2, None, None
                     n2, x1 = ops.layer_norm_passthrough(x1, self.norm2.weight, self.norm2.bias)
                 else:
                     x1, n2 = ops.add_layer_norm(xs, self._attention_branch(n1, apply_proj_drop=False), self.norm2.weight, self.norm2.bias)

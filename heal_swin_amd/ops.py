@@ -1632,6 +1632,91 @@ def mlp(x, w1, b1, w2, b2, drop_p=0.0, seed=None, passthrough=False, residual=No
     return MlpFn.apply(x, w1, b1, w2, b2, float(drop_p), int(seed or 0), bool(passthrough), residual)
 
 
+# ----------------------------------------------------------------------------- fused Mlp block (HBM-bound stages)
+FUSED_MLP = os.environ.get("HS_FUSED_MLP", "1") != "0"  # A/B switch: off = LayerNorm -> hs_gemm_nt(GELU) -> hs_gemm_nt(residual)
+
+
+def fused_mlp_ok(x, hidden):
+    """Whether `fused_mlp_block` (hs_mlp_fused_fwd / _bwd, csrc/mlp_fused.hip) covers this block: bf16 rows on the GPU, C = 96 / 128,
+    hidden = 4 C, a row count that is a multiple of 32."""
+    c = x.shape[-1]
+    return bool(FUSED_MLP and x.is_cuda and x.dtype == torch.bfloat16 and (x.numel() // c) % 32 == 0 and
+                lib.hs_mlp_fused_supported(int(c), int(hidden), _lib.HS_BF16))
+
+
+class FusedMlpBlockFn(torch.autograd.Function):
+    """x + fc2(gelu(fc1(LayerNorm(x)))) -- the block's second residual branch (reference swin_hp_transformer.py:337-338 around
+    Mlp.forward :38-44) -- as ONE forward kernel that also writes what the backward reads (LayerNorm(x) with its statistics, h,
+    gelu(h)), and ONE backward kernel for the two input-gradient products around gelu'; the weight / bias gradients come from
+    `hs_linear_wgrad`, the LayerNorm backward (with the residual gradient folded in) from `hs_add_layernorm_bwd`."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2):
+        _require_gpu(x, ln_w, ln_b, w1, b1, w2, b2)
+        C, hid = x.shape[-1], w1.shape[0]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        dev = x.device
+        need = any(ctx.needs_input_grad)
+        w1c, w2c = _cast_param(w1, torch.bfloat16).contiguous(), _cast_param(w2, torch.bfloat16).contiguous()
+        g, b = _f32(ln_w), _f32(ln_b)
+        out = torch.empty_like(x2)
+        n = torch.empty_like(x2) if need else None
+        mean = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
+        h = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
+        act = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
+        # algorithmic traffic: x in, out (+ n, h, gelu(h) kept for the backward); flops: the two products
+        with _timed("mlp_fused_fwd", dev, 2 * rows * ((3 if need else 2) * C + (2 * hid if need else 0)), 4 * rows * C * hid):
+            check(lib.hs_mlp_fused_fwd(ptr(x2), ptr(g), ptr(b), ptr(w1c), ptr(_f32(b1)), ptr(w2c), ptr(_f32(b2)), ptr(n), ptr(mean), ptr(rstd),
+                                       ptr(h), ptr(act), ptr(out), rows, C, hid, _lib.HS_ATTN_RESIDUAL, _lib.HS_BF16, stream_ptr(dev)),
+                  "hs_mlp_fused_fwd")
+        ctx.save_for_backward(x2, n, mean, rstd, h, act, g, w1, w2)
+        ctx.params = (ln_w, ln_b, b1, b2)
+        ctx.cast_cache = RT.cast_cache
+        ctx.x_shape = x.shape
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, n, mean, rstd, h, act, g, w1, w2 = ctx.saved_tensors
+        ln_w, ln_b, b1, b2 = ctx.params
+        rows, C = x2.shape
+        hid = w1.shape[0]
+        dev = x2.device
+        dy2 = dout.reshape(rows, C)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        w2t = _cast_param_t(w2, torch.bfloat16, ctx.cast_cache)  # [4C, C]
+        w1t = _cast_param_t(w1, torch.bfloat16, ctx.cast_cache)  # [C, 4C]
+        ctx.cast_cache = None
+        dh = torch.empty_like(h)
+        dn = torch.empty_like(x2)
+        with _timed("mlp_fused_bwd", dev, 2 * rows * (2 * C + 2 * hid), 4 * rows * C * hid):
+            check(lib.hs_mlp_fused_bwd(ptr(dy2), ptr(h), ptr(w2t), ptr(w1t), ptr(dh), ptr(dn), rows, C, hid, _lib.HS_BF16, stream_ptr(dev)),
+                  "hs_mlp_fused_bwd")
+        dw2, db2 = _param_grads(dy2, act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6])
+        dw1, db1 = _param_grads(dh, n, w1, b1, ctx.needs_input_grad[3], b1 is not None and ctx.needs_input_grad[4])
+        # norm2 backward with the residual gradient (dy itself) added inside the kernel
+        dx = torch.empty_like(x2)
+        dgamma, dbeta, direct = _norm_param_grads(ln_w, ln_b, C, dev, ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
+        ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, C)), dtype=torch.float32, device=dev)
+        acc = (1 | _defer_flag(dev)) if direct else 0
+        check(lib.hs_add_layernorm_bwd(ptr(dn), ptr(dy2), ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                       acc, rows, C, _lib.HS_BF16, stream_ptr(dev)), "hs_add_layernorm_bwd")
+        if acc & _lib.HS_ACC_DEFER:
+            _defer_keep(dev, ws)
+        dlw, dlb = _norm_param_result(ln_w, ln_b, dgamma, dbeta, direct)
+        return dx.view(ctx.x_shape), dlw, dlb, dw1, db1, dw2, db2
+
+
+def fused_mlp_block(x, ln_w, ln_b, w1, b1, w2, b2):
+    """x + fc2(gelu(fc1(LayerNorm(x)))) in one launch (see FusedMlpBlockFn; use fused_mlp_ok first)."""
+    return FusedMlpBlockFn.apply(x, ln_w, ln_b, w1, b1, w2, b2)
+
+
 class ConcatLinearFn(torch.autograd.Function):
     """y = cat([x, skip], -1) W^T + b without materialising the concatenation (the decoder's skip connection,
     swin_hp_transformer.py:772-775): W = [Wa | Wb] by columns, y = x Wa^T + skip Wb^T + b.  Saves the concat copy in the

@@ -332,6 +332,27 @@ int hs_reduce_pending(void* stream); /* queued sums of that stream */
 int hs_reduce_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused Mlp block of the HBM-bound stages (C = 96 / 128, hidden = 4 C; csrc/mlp_fused.hip): replaces, in ONE launch per direction,
+ *   forward   the block's second residual branch  out = x + fc2(gelu(fc1(LayerNorm(x))))
+ *             (models_torch/swin_hp_transformer.py:337-338 with Mlp.forward :38-44 and norm2 :262; v1 norm placement)
+ *   backward  the input-gradient half of Mlp's autograd:  dh = (dy W2) * gelu'(h),  dn = dh W1
+ * hs_mlp_fused_fwd: x, out [dev] bf16[rows, C]; ln_gamma, ln_beta [dev] f32[C] (both NULL: no LayerNorm in front);
+ *   w1 [dev] bf16[4C, C], b1 f32[4C] | NULL, w2 [dev] bf16[C, 4C], b2 f32[C] | NULL (nn.Linear layouts);
+ *   saved for the backward, each may be NULL (not kept): n_out bf16[rows, C] = LayerNorm(x), mean_out / rstd_out f32[rows],
+ *   h_out bf16[rows, 4C] = fc1 output, act_out bf16[rows, 4C] = gelu(h);  flags: HS_ATTN_RESIDUAL adds x to the result.
+ * hs_mlp_fused_bwd: dy [dev] bf16[rows, C], h [dev] bf16[rows, 4C] (saved), w2_t [dev] bf16[4C, C] and w1_t [dev] bf16[C, 4C] = the
+ *   TRANSPOSED weights; writes dh [dev] bf16[rows, 4C] (operand of fc1's weight gradient) and dn [dev] bf16[rows, C] (gradient of
+ *   LayerNorm(x)).  Weight / bias / LayerNorm gradients: hs_linear_wgrad(dy, gelu(h)), hs_linear_wgrad(dh, n), hs_add_layernorm_bwd.
+ * rows: a multiple of 32.  HS_ERR_UNSUPPORTED outside hs_mlp_fused_supported (the weights live in registers: C <= 128).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_mlp_fused_supported(int channels, int hidden, int dtype);
+int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1, const void* w2,
+                     const float* b2, void* n_out, float* mean_out, float* rstd_out, void* h_out, void* act_out, void* out, int64_t rows,
+                     int channels, int hidden, unsigned flags, int dtype, void* stream);
+int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, void* dh, void* dn, int64_t rows, int channels,
+                     int hidden, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer step over flat buffers: torch.optim.Adam / AdamW (the reference's training/optimizer.py:57-66; amsgrad = False,
  * maximize = False) on n consecutive fp32 parameters p with gradients g and moments m, v, all [dev] f32[n], 16-byte aligned:
  *     g += wd p (decoupled == 0)  |  p *= 1 - lr wd (decoupled != 0: AdamW)

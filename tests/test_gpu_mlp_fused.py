@@ -1,0 +1,170 @@
+"""hs_mlp_fused_fwd / hs_mlp_fused_bwd (csrc/mlp_fused.hip): the block's second residual branch
+    x + fc2(gelu(fc1(LayerNorm(x))))        (reference swin_hp_transformer.py:337-338, Mlp.forward :38-44, norm2 :262)
+in one launch per direction.  Checked through the C ABI against the oracle's formulas (oracle.model.layer_norm / linear / gelu,
+evaluated in float64 on the same bf16-rounded inputs), output and every tensor saved for the backward; the autograd node against
+the oracle's autograd on the same formulas, and against the three-kernel composition it replaces."""
+import ctypes
+
+import pytest
+import torch
+
+from _util import GRAD_TOL, TOL, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _L():
+    from heal_swin_amd import _lib
+    return _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _case(C, rows, seed, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    H = 4 * C
+    t = dict(
+        x=(torch.randn((rows, C), generator=g, device=DEV) * 2 + torch.randn((rows, 1), generator=g, device=DEV)).to(BF),
+        ln_w=torch.rand(C, generator=g, device=DEV) + 0.5, ln_b=torch.randn(C, generator=g, device=DEV) * 0.2,
+        w1=(torch.randn((H, C), generator=g, device=DEV) * scale / C ** 0.5).to(BF), b1=torch.randn(H, generator=g, device=DEV) * 0.3,
+        w2=(torch.randn((C, H), generator=g, device=DEV) * scale / H ** 0.5).to(BF), b2=torch.randn(C, generator=g, device=DEV) * 0.3)
+    return t
+
+
+def _oracle_fwd(t, ln=True, residual=True):
+    """float64 evaluation of the oracle's formulas with the kernel's rounding points: LayerNorm(x) -> bf16, h -> bf16 for storage
+    (gelu takes the unrounded h, as hs_gemm_nt's epilogue does), gelu(h) -> bf16 (the operand of fc2)."""
+    from oracle import model as OM
+    x = t["x"].double()
+    n = OM.layer_norm(x, t["ln_w"].double(), t["ln_b"].double()) if ln else x
+    n_r = n.to(BF).double()
+    h = OM.linear(n_r, t["w1"].double(), t["b1"].double())
+    act = OM.gelu(h)
+    y = OM.linear(act.to(BF).double(), t["w2"].double(), t["b2"].double())
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    return dict(n=n, h=h, act=act, out=(x + y) if residual else y, mean=mean, rstd=rstd)
+
+
+@pytest.mark.parametrize("C", [96, 128])
+@pytest.mark.parametrize("rows", [32, 96, 8192 + 64])
+@pytest.mark.parametrize("ln,residual,keep", [(True, True, True), (True, True, False), (False, False, True)])
+def test_mlp_fused_forward_vs_oracle(C, rows, ln, residual, keep):
+    L = _L()
+    lib, ptr = L.lib, L.ptr
+    t = _case(C, rows, 7 * C + rows)
+    H = 4 * C
+    out = torch.full((rows, C), 7.0, device=DEV, dtype=BF)
+    n = torch.full((rows, C), 7.0, device=DEV, dtype=BF) if (keep and ln) else None
+    mean = torch.empty(rows, device=DEV) if (keep and ln) else None
+    rstd = torch.empty(rows, device=DEV) if (keep and ln) else None
+    h = torch.full((rows, H), 7.0, device=DEV, dtype=BF) if keep else None
+    act = torch.full((rows, H), 7.0, device=DEV, dtype=BF) if keep else None
+    L.check(lib.hs_mlp_fused_fwd(ptr(t["x"]), ptr(t["ln_w"] if ln else None), ptr(t["ln_b"] if ln else None), ptr(t["w1"]), ptr(t["b1"]),
+                                 ptr(t["w2"]), ptr(t["b2"]), ptr(n), ptr(mean), ptr(rstd), ptr(h), ptr(act), ptr(out), rows, C, H,
+                                 L.HS_ATTN_RESIDUAL if residual else 0, L.HS_BF16, _stream()), "hs_mlp_fused_fwd")
+    ref = _oracle_fwd(t, ln, residual)
+    tag = f"mlp_fused fwd C={C} rows={rows}"
+    checks = [(out, ref["out"], TOL[BF], "out")]
+    if keep:
+        checks += [(h, ref["h"], TOL[BF], "h"), (act, ref["act"], TOL[BF], "gelu(h)")]
+        if ln:
+            checks += [(n, ref["n"], TOL[BF], "LayerNorm(x)"), (mean, ref["mean"], 1e-5, "mean"), (rstd, ref["rstd"], 1e-5, "rstd")]
+    bad = []
+    for a, b, tol, what in checks:  # (every tensor is judged before the test fails: the message names all that are off)
+        try:
+            assert_close(a, b, tol, f"{tag} {what}")
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("C", [96, 128])
+@pytest.mark.parametrize("rows", [32, 4096 + 32])
+def test_mlp_fused_backward_vs_oracle(C, rows):
+    """dh = (dy W2) * gelu'(h), dn = dh W1 against the oracle's autograd through linear / gelu on the same saved h."""
+    from oracle import model as OM
+    L = _L()
+    lib, ptr = L.lib, L.ptr
+    t = _case(C, rows, 11 * C + rows)
+    H = 4 * C
+    g = torch.Generator(device=DEV).manual_seed(5)
+    dy = torch.randn((rows, C), generator=g, device=DEV).to(BF)
+    h = (torch.randn((rows, H), generator=g, device=DEV) * 1.5).to(BF)
+    w2t, w1t = t["w2"].t().contiguous(), t["w1"].t().contiguous()
+    dh = torch.full((rows, H), 7.0, device=DEV, dtype=BF)
+    dn = torch.full((rows, C), 7.0, device=DEV, dtype=BF)
+    L.check(lib.hs_mlp_fused_bwd(ptr(dy), ptr(h), ptr(w2t), ptr(w1t), ptr(dh), ptr(dn), rows, C, H, L.HS_BF16, _stream()), "hs_mlp_fused_bwd")
+    hd = h.double().requires_grad_(True)
+    act = OM.gelu(hd)
+    (dact,) = [dy.double() @ t["w2"].double()]
+    (dh_ref,) = torch.autograd.grad(act, hd, dact)
+    dn_ref = dh_ref.to(BF).double() @ t["w1"].double()
+    tag = f"mlp_fused bwd C={C} rows={rows}"
+    assert_close(dh, dh_ref, TOL[BF], tag + " dh")
+    assert_close(dn, dn_ref, TOL[BF], tag + " dn")
+
+
+@pytest.mark.parametrize("C", [96, 128])
+def test_fused_mlp_block_autograd_vs_oracle_and_composition(C):
+    """ops.fused_mlp_block: output and EVERY gradient (x, norm2, fc1, fc2) against the oracle's autograd over its own formulas in
+    float64, and against LayerNorm -> hs_gemm_nt(GELU) -> hs_gemm_nt(residual) -- the composition the block ran before."""
+    from heal_swin_amd import ops
+    from oracle import model as OM
+    rows = 2048
+    t = _case(C, rows, 3 * C)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    dy = torch.randn((rows, C), generator=g, device=DEV).to(BF)
+    names = ("ln_w", "ln_b", "w1", "b1", "w2", "b2")
+
+    def leaves():
+        x = t["x"].clone().requires_grad_(True)
+        ps = {k: t[k].float().clone().requires_grad_(True) for k in names}
+        return x, ps
+
+    assert ops.fused_mlp_ok(t["x"], 4 * C)
+    x, ps = leaves()
+    out = ops.fused_mlp_block(x, ps["ln_w"], ps["ln_b"], ps["w1"], ps["b1"], ps["w2"], ps["b2"])
+    out.backward(dy)
+    fused = dict(out=out.detach(), x=x.grad, **{k: ps[k].grad for k in names})
+
+    # oracle: float64 autograd on the bf16-rounded inputs (no intermediate rounding)
+    xo = t["x"].double().requires_grad_(True)
+    po = {k: t[k].double().requires_grad_(True) for k in names}
+    yo = xo + OM.linear(OM.gelu(OM.linear(OM.layer_norm(xo, po["ln_w"], po["ln_b"]), po["w1"], po["b1"])), po["w2"], po["b2"])
+    yo.backward(dy.double())
+    assert_close(fused["out"], yo.detach(), TOL[BF], f"fused_mlp_block C={C} out")
+    assert_close(fused["x"], xo.grad, GRAD_TOL[BF], f"fused_mlp_block C={C} dx")
+    for k in names:
+        assert_close(fused[k], po[k].grad, GRAD_TOL[BF], f"fused_mlp_block C={C} d{k}")
+
+    # the composition it replaces (same kernels for the parameter gradients): agreement well inside the bf16 bound
+    prev = ops.FUSED_MLP
+    try:
+        ops.FUSED_MLP = False
+        x2, p2 = leaves()
+        n2, xa = ops.layer_norm_passthrough(x2, p2["ln_w"], p2["ln_b"])
+        out2 = ops.mlp(n2, p2["w1"], p2["b1"], p2["w2"], p2["b2"], residual=xa)
+        out2.backward(dy)
+    finally:
+        ops.FUSED_MLP = prev
+    assert_close(fused["out"], out2.detach(), 1e-2, f"fused vs composed C={C} out")
+    assert_close(fused["x"], x2.grad, 2e-2, f"fused vs composed C={C} dx")
+    for k in names:
+        assert_close(fused[k], p2[k].grad, 2e-2, f"fused vs composed C={C} d{k}")
+
+
+def test_fused_mlp_rejects_unsupported_shapes():
+    L = _L()
+    assert L.lib.hs_mlp_fused_supported(128, 512, L.HS_BF16) and L.lib.hs_mlp_fused_supported(96, 384, L.HS_BF16)
+    assert not L.lib.hs_mlp_fused_supported(256, 1024, L.HS_BF16) and not L.lib.hs_mlp_fused_supported(128, 256, L.HS_BF16)
+    assert not L.lib.hs_mlp_fused_supported(128, 512, L.HS_F32)
+    x = torch.zeros((48, 128), device=DEV, dtype=BF)  # rows not a multiple of 32
+    w = torch.zeros((512, 128), device=DEV, dtype=BF)
+    with pytest.raises(AssertionError):
+        L.check(L.lib.hs_mlp_fused_fwd(L.ptr(x), None, None, L.ptr(w), None, L.ptr(w), None, None, None, None, None, None, L.ptr(x), 48, 128, 512,
+                                       0, L.HS_BF16, _stream()), "hs_mlp_fused_fwd")

@@ -18,6 +18,9 @@ def family(n):
     if "gather_rows" in n: return "hs gather_rows"
     if "wgrad" in n: return "hs linear_wgrad"
     if "reduce_slices" in n: return "hs linear_wgrad slice reduce"
+    if "reduce_many" in n: return "hs parameter-gradient sums (batched)"
+    if "adam_" in n: return "optimizer"
+    if "transpose_many" in n: return "hs weight transposes"
     if "gemm_nt" in n: return "hs gemm_nt (own GEMM + epilogues)"
     if "gelu" in n: return "hs gelu fwd/bwd"
     if "hs::" in n: return "hs other"
