@@ -17,6 +17,7 @@ HS_ATTN_RESIDUAL = 4
 HS_ATTN_OVERWRITE_GRADS = 8
 HS_EPI_BIAS, HS_EPI_GELU, HS_EPI_DGELU, HS_EPI_RESID = 0, 1, 2, 3
 HS_ACC_DEFER = 2
+HS_MLP_NORM_AFTER = 16
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
@@ -64,7 +65,7 @@ _SIGNATURES = {
     "hs_mlp_fused_supported": [c_int, c_int, c_int],
     "hs_mlp_fused_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_uint,
                          c_int, c_ptr],
-    "hs_mlp_fused_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
+    "hs_mlp_fused_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_adam_step": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_float, c_ptr, c_float, c_float, c_float, c_float, c_int, c_ptr, c_ptr],
     "hs_adam_advance": [c_ptr, c_ptr],
     "hs_split_bf16x3": [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],

@@ -63,6 +63,10 @@ struct MlpParams {
     uint16_t* out;        // forward: x + mlp(LayerNorm(x)) [M, C];  backward: dn [M, C]
     int64_t tiles;        // M / 32
     int residual;         // forward: add x to the result
+    // v2 norm placement (reference :334-335): out = x + LayerNorm(mlp(x)) -- the LayerNorm sits BEHIND product 2
+    int ln_after;         // forward: ln_g / ln_b apply to the product-2 rows (no LayerNorm in front)
+    uint16_t* m_out;      // forward, ln_after: the un-normalised rows mlp(x) [M, C] (input of the LayerNorm backward; null: not kept)
+    const uint16_t* res_in;  // backward: rows [M, C] added to dn (the residual path's gradient), or null
 };
 
 __device__ __forceinline__ u32x4 ld128(uint32_t addr) {
@@ -74,6 +78,29 @@ __device__ __forceinline__ u32x2v ld64(uint32_t addr) {
     u32x2v v;
     asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
     return v;
+}
+// Loads that are consumed at once are ONE asm statement with their wait: between a separate load asm and its wait asm the compiler
+// is free to copy the destination registers (it believes the value is there) -- and did, for the residual rows: `raw = v` was
+// emitted between the ds_read and the s_waitcnt, i.e. it copied registers the LDS had not written yet.
+__device__ __forceinline__ u32x4 ld128_now(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld128x2_now(uint32_t a0, uint32_t a1, u32x4& v0, u32x4& v1) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void ld128x4_now(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, u32x4& v0, u32x4& v1, u32x4& v2, u32x4& v3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                 : "memory");
+}
+__device__ __forceinline__ void ld64x4_now(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, u32x2v& v0, u32x2v& v1, u32x2v& v2, u32x2v& v3) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                 : "memory");
 }
 __device__ __forceinline__ void st64(uint32_t addr, uint32_t a, uint32_t b) {
     const u32x2v v = {a, b};
@@ -103,15 +130,17 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
     constexpr int X_OFF = 0, A_OFF = 2 * kT * XPITCH, Y_OFF = A_OFF + kT * APITCH, P_OFF = Y_OFF + kT * YPITCH;
     constexpr int P_BA = 0, P_BB = H, P_LNG = H + 128, P_LNB = H + 256;  // float offsets into the parameter block
     constexpr int HB_OFF = P_OFF + (H + 384) * 4;
-    constexpr int SMEM = BWD ? HB_OFF + 2 * kT * APITCH : HB_OFF;
+    constexpr int SMEM = BWD ? HB_OFF + 2 * kT * APITCH : HB_OFF + kT * APITCH;  // backward: two saved-h tiles; forward: the h tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31, l15 = lane & 15, q4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int64_t)blockIdx.x >= p.tiles) return;
-    const bool has_ln = !BWD && p.ln_g != nullptr;
+    const bool has_ln = !BWD && p.ln_g != nullptr && !p.ln_after;
+    const bool ln_post = !BWD && p.ln_g != nullptr && p.ln_after;
     const bool keep_raw = !BWD && p.residual;
+    const bool add_res = BWD && p.res_in != nullptr;
 
     // tile offsets: [token][16-byte chunk] with the chunk index xor-ed by (row & 15) inside its aligned group of 16
     auto aoff = [](int row, int chunk) { return (uint32_t)(row * APITCH + ((chunk ^ (row & 15)) << 4)); };
@@ -159,8 +188,8 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
         for (int i = tid; i < H; i += NW * 64) ps[P_BA + i] = p.ba ? p.ba[i] : 0.f;
         for (int i = tid; i < C; i += NW * 64) {
             ps[P_BB + i] = p.bb ? p.bb[i] : 0.f;
-            ps[P_LNG + i] = has_ln ? p.ln_g[i] : 1.f;
-            ps[P_LNB + i] = has_ln ? p.ln_b[i] : 0.f;
+            ps[P_LNG + i] = (has_ln || ln_post) ? p.ln_g[i] : 1.f;
+            ps[P_LNB + i] = (has_ln || ln_post) ? p.ln_b[i] : 0.f;
         }
     }
     bf16x8 wa[2][KS1], wb[KS2];
@@ -189,15 +218,49 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
             if (pc < 8) {
                 const int row = 4 * pc + q4, lc = l15 ^ (row & 15);
                 const int lcc = lc < NCH ? lc : 0;
-                u32x4 y0 = ld128(ybase + yoff(row, 2 * lcc)), y1 = ld128(ybase + yoff(row, 2 * lcc + 1));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0), "+v"(y1));
+                u32x4 y0, y1;
+                ld128x2_now(ybase + yoff(row, 2 * lcc), ybase + yoff(row, 2 * lcc + 1), y0, y1);
                 float f[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     f[e] = __uint_as_float(y0[e]);
                     f[4 + e] = __uint_as_float(y1[e]);
                 }
-                if (keep_raw) {
+                const bool valid = lc < NCH;
+                const int64_t grow = tp * kT + row;
+                if (ln_post) {
+                    // v2 placement: LayerNorm of the row just formed, on its bf16 rounding (what the composed path's LayerNorm
+                    // kernel reads, and what the LayerNorm backward will read from m_out); 16 lanes per row as in the prologue form
+                    const u32x4 mw = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+                    if (valid && p.m_out) *(u32x4*)(p.m_out + grow * C + lc * 8) = mw;
+                    const uint32_t ga = pbase + (P_LNG + lcc * 8) * 4, ba = pbase + (P_LNB + lcc * 8) * 4;
+                    u32x4 g0, g1, b0, b1;
+                    ld128x4_now(ga, ga + 16, ba, ba + 16, g0, g1, b0, b1);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[2 * e] = valid ? lo_f(mw[e]) : 0.f;
+                        f[2 * e + 1] = valid ? hi_f(mw[e]) : 0.f;
+                        s1 += f[2 * e] + f[2 * e + 1];
+                    }
+                    const float mean = row16_sum(s1) * (1.f / C);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = valid ? f[e] - mean : 0.f;
+                        s2 = fmaf(f[e], f[e], s2);
+                    }
+                    const float rstd = rsqrtf(row16_sum(s2) * (1.f / C) + kLnEps);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[e] = fmaf(f[e] * rstd, __uint_as_float(g0[e]), __uint_as_float(b0[e]));
+                        f[4 + e] = fmaf(f[4 + e] * rstd, __uint_as_float(g1[e]), __uint_as_float(b1[e]));
+                    }
+                    if ((lane_o & 15) == 0 && p.mean_out) {
+                        p.mean_out[grow] = mean;
+                        p.rstd_out[grow] = rstd;
+                    }
+                }
+                if (keep_raw || add_res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         f[2 * e] += lo_f(res[j][e]);
@@ -205,7 +268,7 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
                     }
                 }
                 const u32x4 o = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
-                if (lc < NCH) *(u32x4*)(p.out + (tp * kT + row) * C + lc * 8) = o;
+                if (valid) *(u32x4*)(p.out + grow * C + lc * 8) = o;
             }
         }
     };
@@ -218,9 +281,9 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
         const bool more = ti_next < p.tiles;
         // ------------------------------------------------------------ own rows of the x tile: residual copy, LayerNorm in place
         // (this wave's pieces landed before the previous iteration's row stores: vmcnt(0) below)
-        if constexpr (!BWD) {
 #pragma unroll
-            for (int j = 0; j < XP; ++j) raw_prev[j] = raw[j];
+        for (int j = 0; j < XP; ++j) raw_prev[j] = raw[j];
+        if constexpr (!BWD) {
             if (has_ln || keep_raw) {
 #pragma unroll
                 for (int j = 0; j < XP; ++j) {
@@ -230,17 +293,13 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
                         const int row = 4 * pc + q4, lc = l15 ^ (row & 15);
                         const bool valid = lc < NCH;
                         const uint32_t addr = xbase + pc * 1024 + lane_o * 16;
-                        u32x4 v = ld128(addr);
-                        if (!has_ln) {
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
-                            raw[j] = v;
-                            continue;
-                        }
+                        const u32x4 v = ld128_now(addr);
+                        raw[j] = v;
+                        if (!has_ln) continue;
                         const int lcc = valid ? lc : 0;
                         const uint32_t ga = pbase + (P_LNG + lcc * 8) * 4, ba = pbase + (P_LNB + lcc * 8) * 4;
-                        u32x4 g0 = ld128(ga), g1 = ld128(ga + 16), b0 = ld128(ba), b1 = ld128(ba + 16);
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v), "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1));
-                        raw[j] = v;
+                        u32x4 g0, g1, b0, b1;
+                        ld128x4_now(ga, ga + 16, ba, ba + 16, g0, g1, b0, b1);
                         float f[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -281,21 +340,33 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
             issue_h(ti_next, buf ^ 1);
         }
         if (ti_prev >= 0) epilogue(ti_prev, raw_prev);
+        if constexpr (BWD) {
+            // the residual-path rows of THIS tile (added in the next iteration's epilogue): requested here, claimed by the vmcnt(0)
+            // in front of the row stores below.  Inline asm, so that the compiler does not put a wait of its own in front of their
+            // use -- it would stand right behind the next tile's DMA
+            if (add_res) {
+                const int l15o = lane_o & 15, q4o = lane_o >> 4;
+#pragma unroll
+                for (int j = 0; j < XP; ++j) {
+                    const int pc = wave + NW * j;
+                    const int row = 4 * (pc < 8 ? pc : 0) + q4o, lc = l15o ^ (row & 15);
+                    const uint16_t* src = p.res_in + (ti * kT + row) * C + (lc < NCH ? lc : 0) * 8;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[j]) : "v"(src) : "memory");
+                }
+            }
+        }
 
         // ------------------------------------------------------------ product 1, transposed: D[hidden 64 w + 32 i + ..][token]
         f32x16 acc[2];
         if constexpr (!BWD) {
-            u32x4 bv[2][4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                u32x4 bv[4];
+                const uint32_t a = pbase + (P_BA + 64 * wave + 32 * i + 4 * half) * 4;
+                ld128x4_now(a, a + 32, a + 64, a + 96, bv[0], bv[1], bv[2], bv[3]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bv[i][g] = ld128(pbase + (P_BA + 64 * wave + 32 * i + 8 * g + 4 * half) * 4);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]), "+v"(bv[1][0]), "+v"(bv[1][1]), "+v"(bv[1][2]), "+v"(bv[1][3]));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = __uint_as_float(bv[i][r >> 2][r & 3]);
+                for (int r = 0; r < 16; ++r) acc[i][r] = __uint_as_float(bv[r >> 2][r & 3]);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -323,28 +394,26 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
         // ------------------------------------------------------------ elementwise, lane-local (lane = token, 4 hidden units per group)
         // The first result (forward: h, backward: dh) goes to the LDS tile [token][hidden] as it is formed -- 8 bytes per lane and
         // register group; the tile is free since barrier A -- so only gelu(h) stays in registers (16) across the step.
-        uint32_t w2[2][4][2];
         u32x2v hw[2][4];  // backward: the saved h of this lane's 32 accumulator positions
+        const uint32_t h2base = lds0 + HB_OFF;  // forward: h goes to a tile of its own, gelu(h) to the tile product 2 reads
         if constexpr (BWD) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) hw[i][g] = ld64(hbase + aoff(l31, 8 * wave + 4 * i + g) + 8 * half);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(hw[0][0]), "+v"(hw[0][1]), "+v"(hw[0][2]), "+v"(hw[0][3]), "+v"(hw[1][0]), "+v"(hw[1][1]), "+v"(hw[1][2]), "+v"(hw[1][3]));
+                ld64x4_now(hbase + aoff(l31, 8 * wave + 4 * i + 0) + 8 * half, hbase + aoff(l31, 8 * wave + 4 * i + 1) + 8 * half,
+                           hbase + aoff(l31, 8 * wave + 4 * i + 2) + 8 * half, hbase + aoff(l31, 8 * wave + 4 * i + 3) + 8 * half, hw[i][0],
+                           hw[i][1], hw[i][2], hw[i][3]);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x2 v[2] = {f32x2{acc[i][4 * g], acc[i][4 * g + 1]}, f32x2{acc[i][4 * g + 2], acc[i][4 * g + 3]}};
-                const uint32_t dst = abase + aoff(l31, 8 * wave + 4 * i + g) + 8 * half;
+                const uint32_t off = aoff(l31, 8 * wave + 4 * i + g) + 8 * half, dst = abase + off;
                 if constexpr (!BWD) {
-                    st64(dst, pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y));
+                    st64(h2base + off, pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y));
                     v[0] = gelu2(v[0]);
                     v[1] = gelu2(v[1]);
-                    w2[i][g][0] = pack_bf16x2(v[0].x, v[0].y);
-                    w2[i][g][1] = pack_bf16x2(v[1].x, v[1].y);
+                    st64(dst, pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y));
                 } else {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -356,30 +425,26 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
             }
         // the NEXT tile's rows (requested behind barrier A) have landed -- waited for here, in front of this tile's row stores,
         // because vmcnt counts loads and stores together
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (BWD && XP == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0])::"memory");
+        else if constexpr (BWD) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[XP - 1])::"memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ------------------------------------------------------------ own column block of the tile back out as whole row segments
-        auto stage = [&](const uint32_t (&w)[2][4][2]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) st64(abase + aoff(l31, 8 * wave + 4 * i + g) + 8 * half, w[i][g][0], w[i][g][1]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        auto rows_out = [&](uint16_t* dst) {  // 32 rows x 128 bytes of this wave's block: 4 instructions of 8 rows x 8 chunks
+        auto rows_out = [&](uint32_t tile, uint16_t* dst) {  // 32 rows x 128 bytes of this wave's block: 4 instructions of 8 rows x 8 chunks
             u32x4 pc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pc[j] = ld128(abase + aoff(8 * j + (lane_o >> 3), 8 * wave + (lane_o & 7)));
+            for (int j = 0; j < 4; ++j) pc[j] = ld128(tile + aoff(8 * j + (lane_o >> 3), 8 * wave + (lane_o & 7)));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(pc[j]) : "n"(3 - j));
                 *(u32x4*)(dst + (ti * kT + 8 * j + (lane_o >> 3)) * H + 64 * wave + 8 * (lane_o & 7)) = pc[j];
             }
         };
-        if (p.h_out) rows_out(p.h_out);
         if constexpr (!BWD) {
-            stage(w2);
-            if (p.act_out) rows_out(p.act_out);
+            if (p.h_out) rows_out(h2base, p.h_out);
+            if (p.act_out) rows_out(abase, p.act_out);
+        } else {
+            rows_out(abase, p.h_out);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // B: the tile is complete; everybody is done with the x tile and the staged previous result
@@ -387,8 +452,7 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
         // ------------------------------------------------------------ product 2: D[channel 16 w + ..][token], K = 4 C
         f32x4 y[2];
         {
-            u32x4 bbv = ld128(pbase + (P_BB + 16 * wave + 4 * q4) * 4);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bbv));
+            const u32x4 bbv = ld128_now(pbase + (P_BB + 16 * wave + 4 * q4) * 4);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -428,10 +492,8 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (!BWD) {
 #pragma unroll
-        for (int j = 0; j < XP; ++j) raw_prev[j] = raw[j];
-    }
+    for (int j = 0; j < XP; ++j) raw_prev[j] = raw[j];
     epilogue(ti_prev, raw_prev);
 #endif
 }
@@ -462,6 +524,7 @@ int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta,
                      int channels, int hidden, unsigned flags, int dtype, void* stream) {
     using namespace hs;
     HS_CHECK_ARG(x && w1 && w2 && out, "hs_mlp_fused_fwd: null pointer");
+    HS_CHECK_ARG(!(flags & HS_MLP_NORM_AFTER) || ln_gamma, "hs_mlp_fused_fwd: HS_MLP_NORM_AFTER needs ln_gamma / ln_beta");
     HS_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "hs_mlp_fused_fwd: ln_gamma and ln_beta go together");
     HS_CHECK_ARG((mean_out == nullptr) == (rstd_out == nullptr), "hs_mlp_fused_fwd: mean_out and rstd_out go together");
     HS_CHECK_ARG(rows > 0 && rows % kT == 0, "hs_mlp_fused_fwd: rows must be a positive multiple of 32");
@@ -474,7 +537,10 @@ int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta,
         MlpParams p{};
         p.x = (const uint16_t*)x + r0 * channels;
         p.wa = (const uint16_t*)w1; p.wb = (const uint16_t*)w2; p.ba = b1; p.bb = b2; p.ln_g = ln_gamma; p.ln_b = ln_beta;
-        p.n_out = n_out ? (uint16_t*)n_out + r0 * channels : nullptr;
+        p.ln_after = (flags & HS_MLP_NORM_AFTER) ? 1 : 0;
+        // (v2 placement: the kept [rows, C] tensor is the LayerNorm's INPUT mlp(x); v1: its output LayerNorm(x))
+        p.n_out = (n_out && !p.ln_after) ? (uint16_t*)n_out + r0 * channels : nullptr;
+        p.m_out = (n_out && p.ln_after) ? (uint16_t*)n_out + r0 * channels : nullptr;
         p.mean_out = mean_out ? mean_out + r0 : nullptr;
         p.rstd_out = rstd_out ? rstd_out + r0 : nullptr;
         p.h_out = h_out ? (uint16_t*)h_out + r0 * hidden : nullptr;
@@ -488,8 +554,8 @@ int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta,
     return HS_OK;
 }
 
-int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, void* dh, void* dn, int64_t rows, int channels,
-                     int hidden, int dtype, void* stream) {
+int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn, int64_t rows,
+                     int channels, int hidden, int dtype, void* stream) {
     using namespace hs;
     HS_CHECK_ARG(dy && h && w2_t && w1_t && dh && dn, "hs_mlp_fused_bwd: null pointer");
     HS_CHECK_ARG(rows > 0 && rows % kT == 0, "hs_mlp_fused_bwd: rows must be a positive multiple of 32");
@@ -503,6 +569,7 @@ int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void
         p.wa = (const uint16_t*)w2_t; p.wb = (const uint16_t*)w1_t;
         p.hin = (const uint16_t*)h + r0 * hidden;
         p.h_out = (uint16_t*)dh + r0 * hidden;
+        p.res_in = dres ? (const uint16_t*)dres + r0 * channels : nullptr;
         p.out = (uint16_t*)dn + r0 * channels;
         p.tiles = n / kT;
         const int rc = channels == 128 ? launch_mlp<128>(p, true, (hipStream_t)stream) : launch_mlp<96>(p, true, (hipStream_t)stream);

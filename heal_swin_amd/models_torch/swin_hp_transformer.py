@@ -318,14 +318,16 @@ class SwinTransformerBlock(nn.Module):
         """per-sample DropPath factor of one branch ([B] tensor) or None"""
         return self.drop_path.sample_scale(x.shape[0], x.device) if isinstance(self.drop_path, DropPath) else None
 
-    def _fused_mlp(self, x1):
-        """x1 + mlp(norm2(x1)) by the one-launch Mlp block kernel (ops.fused_mlp_block) where it applies: HIP norms, exact GELU,
-        hidden = 4 C at C = 96 / 128, nothing stochastic on the branch; else None."""
+    def _fused_mlp(self, x1, post_norm=False):
+        """x1 + mlp(norm2(x1)) -- post_norm (v2 placement): x1 + norm2(mlp(x1)) -- by the one-launch Mlp block kernel
+        (ops.fused_mlp_block) where it applies: HIP norms, exact GELU, hidden = 4 C at C = 96 / 128, nothing stochastic on the
+        branch; else None."""
         m = self.mlp
         if (isinstance(self.norm2, HSLayerNorm) and isinstance(m.fc1, HSLinear) and isinstance(m.fc2, HSLinear) and
                 isinstance(m.act, nn.GELU) and getattr(m.act, "approximate", "none") == "none" and not self._stochastic() and
                 not (self.training and m.drop.p > 0) and ops.fused_mlp_ok(x1, m.fc1.weight.shape[0]) and m.fc2.weight.shape[0] == self.dim):
-            return ops.fused_mlp_block(x1, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+            return ops.fused_mlp_block(x1, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                       post_norm=post_norm)
         return None
 
     def can_defer(self):
@@ -456,6 +458,9 @@ class SwinTransformerBlock(nn.Module):
             # that Linear's input-gradient GEMM, not by a separate elementwise kernel
             a, xr = self._attention_branch(x, apply_proj_drop=False, residual_alias=True)
             x = self.norm1(a, residual=xr, row_scale=self._path_scale(x), drop_p=self.attn.proj_drop.p if train else 0.0)
+            x2 = self._fused_mlp(x, post_norm=True)  # x + norm2(mlp(x)) in one launch where the Mlp is HBM-bound (stage 0)
+            if x2 is not None:
+                return x2
             m, xr = self.mlp(x, apply_out_drop=False, residual_alias=True)
             return self.norm2(m, residual=xr, row_scale=self._path_scale(x), drop_p=self.mlp.drop.p if train else 0.0)
         if self.use_v2_norm_placement:  # foreign norm layers

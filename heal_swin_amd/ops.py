@@ -1645,13 +1645,15 @@ def fused_mlp_ok(x, hidden):
 
 
 class FusedMlpBlockFn(torch.autograd.Function):
-    """x + fc2(gelu(fc1(LayerNorm(x)))) -- the block's second residual branch (reference swin_hp_transformer.py:337-338 around
-    Mlp.forward :38-44) -- as ONE forward kernel that also writes what the backward reads (LayerNorm(x) with its statistics, h,
-    gelu(h)), and ONE backward kernel for the two input-gradient products around gelu'; the weight / bias gradients come from
-    `hs_linear_wgrad`, the LayerNorm backward (with the residual gradient folded in) from `hs_add_layernorm_bwd`."""
+    """The block's second residual branch as ONE forward kernel that also writes what the backward reads, and ONE backward kernel for
+    the two input-gradient products around gelu' (csrc/mlp_fused.hip):
+        v1 placement (reference swin_hp_transformer.py:337-338):  x + fc2(gelu(fc1(LayerNorm(x))))
+        v2 placement (`post_norm`, :334-335):                     x + LayerNorm(fc2(gelu(fc1(x))))
+    with Mlp.forward :38-44.  Weight / bias gradients come from `hs_linear_wgrad`, the LayerNorm backward from the LayerNorm
+    kernels (v1: with the residual gradient folded in; v2: in front of the Mlp backward, whose epilogue adds the residual path)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, post_norm=False):
         _require_gpu(x, ln_w, ln_b, w1, b1, w2, b2)
         C, hid = x.shape[-1], w1.shape[0]
         x2 = x.reshape(-1, C)
@@ -1663,20 +1665,22 @@ class FusedMlpBlockFn(torch.autograd.Function):
         w1c, w2c = _cast_param(w1, torch.bfloat16).contiguous(), _cast_param(w2, torch.bfloat16).contiguous()
         g, b = _f32(ln_w), _f32(ln_b)
         out = torch.empty_like(x2)
-        n = torch.empty_like(x2) if need else None
+        n = torch.empty_like(x2) if need else None  # v1: LayerNorm(x) (fc1's input); v2: mlp(x) (the LayerNorm's input)
         mean = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         h = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
         act = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
+        flags = _lib.HS_ATTN_RESIDUAL | (_lib.HS_MLP_NORM_AFTER if post_norm else 0)
         # algorithmic traffic: x in, out (+ n, h, gelu(h) kept for the backward); flops: the two products
         with _timed("mlp_fused_fwd", dev, 2 * rows * ((3 if need else 2) * C + (2 * hid if need else 0)), 4 * rows * C * hid):
             check(lib.hs_mlp_fused_fwd(ptr(x2), ptr(g), ptr(b), ptr(w1c), ptr(_f32(b1)), ptr(w2c), ptr(_f32(b2)), ptr(n), ptr(mean), ptr(rstd),
-                                       ptr(h), ptr(act), ptr(out), rows, C, hid, _lib.HS_ATTN_RESIDUAL, _lib.HS_BF16, stream_ptr(dev)),
+                                       ptr(h), ptr(act), ptr(out), rows, C, hid, flags, _lib.HS_BF16, stream_ptr(dev)),
                   "hs_mlp_fused_fwd")
         ctx.save_for_backward(x2, n, mean, rstd, h, act, g, w1, w2)
         ctx.params = (ln_w, ln_b, b1, b2)
         ctx.cast_cache = RT.cast_cache
         ctx.x_shape = x.shape
+        ctx.post_norm = bool(post_norm)
         return out.view(x.shape)
 
     @staticmethod
@@ -1692,29 +1696,43 @@ class FusedMlpBlockFn(torch.autograd.Function):
         w2t = _cast_param_t(w2, torch.bfloat16, ctx.cast_cache)  # [4C, C]
         w1t = _cast_param_t(w1, torch.bfloat16, ctx.cast_cache)  # [C, 4C]
         ctx.cast_cache = None
-        dh = torch.empty_like(h)
-        dn = torch.empty_like(x2)
-        with _timed("mlp_fused_bwd", dev, 2 * rows * (2 * C + 2 * hid), 4 * rows * C * hid):
-            check(lib.hs_mlp_fused_bwd(ptr(dy2), ptr(h), ptr(w2t), ptr(w1t), ptr(dh), ptr(dn), rows, C, hid, _lib.HS_BF16, stream_ptr(dev)),
-                  "hs_mlp_fused_bwd")
-        dw2, db2 = _param_grads(dy2, act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6])
-        dw1, db1 = _param_grads(dh, n, w1, b1, ctx.needs_input_grad[3], b1 is not None and ctx.needs_input_grad[4])
-        # norm2 backward with the residual gradient (dy itself) added inside the kernel
-        dx = torch.empty_like(x2)
         dgamma, dbeta, direct = _norm_param_grads(ln_w, ln_b, C, dev, ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         ws = torch.empty(int(lib.hs_layernorm_bwd_workspace(rows, C)), dtype=torch.float32, device=dev)
         acc = (1 | _defer_flag(dev)) if direct else 0
-        check(lib.hs_add_layernorm_bwd(ptr(dn), ptr(dy2), ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                       acc, rows, C, _lib.HS_BF16, stream_ptr(dev)), "hs_add_layernorm_bwd")
+        dh = torch.empty_like(h)
+        if ctx.post_norm:
+            # out = x + LN(m): LayerNorm backward first (dm from dout and the saved m), then the Mlp backward on dm with the
+            # residual path's gradient (dout itself) added in its epilogue: dx = dout + dh W1
+            dm = torch.empty_like(x2)
+            check(lib.hs_layernorm_bwd(ptr(dy2), ptr(n), ptr(g), ptr(mean), ptr(rstd), ptr(dm), ptr(dgamma), ptr(dbeta), ptr(ws), acc, rows, C,
+                                       _lib.HS_BF16, stream_ptr(dev)), "hs_layernorm_bwd")
+            dx = torch.empty_like(x2)
+            with _timed("mlp_fused_bwd", dev, 2 * rows * (3 * C + 2 * hid), 4 * rows * C * hid):
+                check(lib.hs_mlp_fused_bwd(ptr(dm), ptr(h), ptr(w2t), ptr(w1t), ptr(dy2), ptr(dh), ptr(dx), rows, C, hid, _lib.HS_BF16,
+                                           stream_ptr(dev)), "hs_mlp_fused_bwd")
+            dw2, db2 = _param_grads(dm, act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6])
+            dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[3], b1 is not None and ctx.needs_input_grad[4])
+        else:
+            dn = torch.empty_like(x2)
+            with _timed("mlp_fused_bwd", dev, 2 * rows * (2 * C + 2 * hid), 4 * rows * C * hid):
+                check(lib.hs_mlp_fused_bwd(ptr(dy2), ptr(h), ptr(w2t), ptr(w1t), None, ptr(dh), ptr(dn), rows, C, hid, _lib.HS_BF16,
+                                           stream_ptr(dev)), "hs_mlp_fused_bwd")
+            dw2, db2 = _param_grads(dy2, act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6])
+            dw1, db1 = _param_grads(dh, n, w1, b1, ctx.needs_input_grad[3], b1 is not None and ctx.needs_input_grad[4])
+            # norm2 backward with the residual gradient (dy itself) added inside the kernel
+            dx = torch.empty_like(x2)
+            check(lib.hs_add_layernorm_bwd(ptr(dn), ptr(dy2), ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                           acc, rows, C, _lib.HS_BF16, stream_ptr(dev)), "hs_add_layernorm_bwd")
         if acc & _lib.HS_ACC_DEFER:
             _defer_keep(dev, ws)
         dlw, dlb = _norm_param_result(ln_w, ln_b, dgamma, dbeta, direct)
-        return dx.view(ctx.x_shape), dlw, dlb, dw1, db1, dw2, db2
+        return dx.view(ctx.x_shape), dlw, dlb, dw1, db1, dw2, db2, None
 
 
-def fused_mlp_block(x, ln_w, ln_b, w1, b1, w2, b2):
-    """x + fc2(gelu(fc1(LayerNorm(x)))) in one launch (see FusedMlpBlockFn; use fused_mlp_ok first)."""
-    return FusedMlpBlockFn.apply(x, ln_w, ln_b, w1, b1, w2, b2)
+def fused_mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, post_norm=False):
+    """x + fc2(gelu(fc1(LayerNorm(x)))) -- or, post_norm, x + LayerNorm(fc2(gelu(fc1(x)))) -- in one launch (FusedMlpBlockFn; use
+    fused_mlp_ok first)."""
+    return FusedMlpBlockFn.apply(x, ln_w, ln_b, w1, b1, w2, b2, bool(post_norm))
 
 
 class ConcatLinearFn(torch.autograd.Function):

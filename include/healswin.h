@@ -341,16 +341,20 @@ int hs_reduce_flush(void* stream);
  *   saved for the backward, each may be NULL (not kept): n_out bf16[rows, C] = LayerNorm(x), mean_out / rstd_out f32[rows],
  *   h_out bf16[rows, 4C] = fc1 output, act_out bf16[rows, 4C] = gelu(h);  flags: HS_ATTN_RESIDUAL adds x to the result.
  * hs_mlp_fused_bwd: dy [dev] bf16[rows, C], h [dev] bf16[rows, 4C] (saved), w2_t [dev] bf16[4C, C] and w1_t [dev] bf16[C, 4C] = the
- *   TRANSPOSED weights; writes dh [dev] bf16[rows, 4C] (operand of fc1's weight gradient) and dn [dev] bf16[rows, C] (gradient of
+ *   TRANSPOSED weights; writes dh [dev] bf16[rows, 4C] (operand of fc1's weight gradient) and dn [dev] bf16[rows, C] = dh W1 (+ dres
+ *   [dev] bf16[rows, C] when non-NULL: the residual path's gradient of the v2 placement, added in the epilogue; v1: the gradient of
  *   LayerNorm(x)).  Weight / bias / LayerNorm gradients: hs_linear_wgrad(dy, gelu(h)), hs_linear_wgrad(dh, n), hs_add_layernorm_bwd.
  * rows: a multiple of 32.  HS_ERR_UNSUPPORTED outside hs_mlp_fused_supported (the weights live in registers: C <= 128).
  * ---------------------------------------------------------------------------------------------- */
+#define HS_MLP_NORM_AFTER 16u /* hs_mlp_fused_fwd flags: v2 norm placement (:334-335), out = x + LayerNorm(fc2(gelu(fc1(x)))): ln_gamma / ln_beta
+                                 apply BEHIND the Mlp, n_out receives the un-normalised rows mlp(x) (the LayerNorm backward's input) and
+                                 mean_out / rstd_out their statistics */
 int hs_mlp_fused_supported(int channels, int hidden, int dtype);
 int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1, const void* w2,
                      const float* b2, void* n_out, float* mean_out, float* rstd_out, void* h_out, void* act_out, void* out, int64_t rows,
                      int channels, int hidden, unsigned flags, int dtype, void* stream);
-int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, void* dh, void* dn, int64_t rows, int channels,
-                     int hidden, int dtype, void* stream);
+int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn, int64_t rows,
+                     int channels, int hidden, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step over flat buffers: torch.optim.Adam / AdamW (the reference's training/optimizer.py:57-66; amsgrad = False,

@@ -52,7 +52,7 @@ def _oracle_fwd(t, ln=True, residual=True):
 
 @pytest.mark.parametrize("C", [96, 128])
 @pytest.mark.parametrize("rows", [32, 96, 8192 + 64])
-@pytest.mark.parametrize("ln,residual,keep", [(True, True, True), (True, True, False), (False, False, True)])
+@pytest.mark.parametrize("ln,residual,keep", [(True, True, True), (True, True, False), (False, False, True), (False, True, True)])
 def test_mlp_fused_forward_vs_oracle(C, rows, ln, residual, keep):
     L = _L()
     lib, ptr = L.lib, L.ptr
@@ -85,7 +85,8 @@ def test_mlp_fused_forward_vs_oracle(C, rows, ln, residual, keep):
 
 @pytest.mark.parametrize("C", [96, 128])
 @pytest.mark.parametrize("rows", [32, 4096 + 32])
-def test_mlp_fused_backward_vs_oracle(C, rows):
+@pytest.mark.parametrize("with_res", [False, True])
+def test_mlp_fused_backward_vs_oracle(C, rows, with_res):
     """dh = (dy W2) * gelu'(h), dn = dh W1 against the oracle's autograd through linear / gelu on the same saved h."""
     from oracle import model as OM
     L = _L()
@@ -98,15 +99,71 @@ def test_mlp_fused_backward_vs_oracle(C, rows):
     w2t, w1t = t["w2"].t().contiguous(), t["w1"].t().contiguous()
     dh = torch.full((rows, H), 7.0, device=DEV, dtype=BF)
     dn = torch.full((rows, C), 7.0, device=DEV, dtype=BF)
-    L.check(lib.hs_mlp_fused_bwd(ptr(dy), ptr(h), ptr(w2t), ptr(w1t), ptr(dh), ptr(dn), rows, C, H, L.HS_BF16, _stream()), "hs_mlp_fused_bwd")
+    res = torch.randn((rows, C), generator=g, device=DEV).to(BF) if with_res else None
+    L.check(lib.hs_mlp_fused_bwd(ptr(dy), ptr(h), ptr(w2t), ptr(w1t), ptr(res), ptr(dh), ptr(dn), rows, C, H, L.HS_BF16, _stream()), "hs_mlp_fused_bwd")
     hd = h.double().requires_grad_(True)
     act = OM.gelu(hd)
     (dact,) = [dy.double() @ t["w2"].double()]
     (dh_ref,) = torch.autograd.grad(act, hd, dact)
     dn_ref = dh_ref.to(BF).double() @ t["w1"].double()
+    if with_res:  # v2 placement: the residual path's gradient rides on the epilogue
+        dn_ref = dn_ref + res.double()
     tag = f"mlp_fused bwd C={C} rows={rows}"
     assert_close(dh, dh_ref, TOL[BF], tag + " dh")
     assert_close(dn, dn_ref, TOL[BF], tag + " dn")
+
+
+@pytest.mark.parametrize("C", [96, 128])
+@pytest.mark.parametrize("rows", [64, 8192 + 32])
+def test_mlp_fused_forward_post_norm_vs_oracle(C, rows):
+    """v2 placement through the C ABI: out = x + LayerNorm(fc2(gelu(fc1(x)))), the kept tensor is mlp(x) with ITS statistics."""
+    from oracle import model as OM
+    L = _L()
+    lib, ptr = L.lib, L.ptr
+    t = _case(C, rows, 13 * C + rows)
+    H = 4 * C
+    out = torch.full((rows, C), 7.0, device=DEV, dtype=BF)
+    m = torch.full((rows, C), 7.0, device=DEV, dtype=BF)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    h, act = torch.empty((rows, H), device=DEV, dtype=BF), torch.empty((rows, H), device=DEV, dtype=BF)
+    L.check(lib.hs_mlp_fused_fwd(ptr(t["x"]), ptr(t["ln_w"]), ptr(t["ln_b"]), ptr(t["w1"]), ptr(t["b1"]), ptr(t["w2"]), ptr(t["b2"]), ptr(m),
+                                 ptr(mean), ptr(rstd), ptr(h), ptr(act), ptr(out), rows, C, H, L.HS_ATTN_RESIDUAL | L.HS_MLP_NORM_AFTER,
+                                 L.HS_BF16, _stream()), "hs_mlp_fused_fwd")
+    x = t["x"].double()
+    hr = OM.linear(x, t["w1"].double(), t["b1"].double())
+    mr = OM.linear(OM.gelu(hr).to(BF).double(), t["w2"].double(), t["b2"].double())
+    mb = mr.to(BF).double()  # the LayerNorm reads the rounded rows, as the composed path's kernel does
+    ref = x + OM.layer_norm(mb, t["ln_w"].double(), t["ln_b"].double())
+    tag = f"mlp_fused fwd post-norm C={C} rows={rows}"
+    assert_close(h, hr, TOL[BF], tag + " h")
+    assert_close(m, mr, TOL[BF], tag + " mlp(x)")
+    assert_close(out, ref, TOL[BF], tag + " out")
+    assert_close(mean, m.double().mean(1), 1e-5, tag + " mean")
+    assert_close(rstd, (m.double().var(1, unbiased=False) + 1e-5).rsqrt(), 1e-5, tag + " rstd")
+
+
+@pytest.mark.parametrize("C", [96, 128])
+def test_fused_mlp_block_post_norm_autograd_vs_oracle(C):
+    """ops.fused_mlp_block(post_norm=True): output and every gradient against the oracle's float64 autograd over its own formulas."""
+    from heal_swin_amd import ops
+    from oracle import model as OM
+    rows = 2048
+    t = _case(C, rows, 5 * C)
+    g = torch.Generator(device=DEV).manual_seed(19)
+    dy = torch.randn((rows, C), generator=g, device=DEV).to(BF)
+    names = ("ln_w", "ln_b", "w1", "b1", "w2", "b2")
+    x = t["x"].clone().requires_grad_(True)
+    ps = {k: t[k].float().clone().requires_grad_(True) for k in names}
+    out = ops.fused_mlp_block(x, ps["ln_w"], ps["ln_b"], ps["w1"], ps["b1"], ps["w2"], ps["b2"], post_norm=True)
+    out.backward(dy)
+    xo = t["x"].double().requires_grad_(True)
+    po = {k: t[k].double().requires_grad_(True) for k in names}
+    yo = xo + OM.layer_norm(OM.linear(OM.gelu(OM.linear(xo, po["w1"], po["b1"])), po["w2"], po["b2"]), po["ln_w"], po["ln_b"])
+    yo.backward(dy.double())
+    assert_close(out, yo.detach(), TOL[BF], f"fused_mlp_block post-norm C={C} out")
+    assert_close(x.grad, xo.grad, GRAD_TOL[BF], f"fused_mlp_block post-norm C={C} dx")
+    for k in names:
+        assert_close(ps[k].grad, po[k].grad, GRAD_TOL[BF], f"fused_mlp_block post-norm C={C} d{k}")
 
 
 @pytest.mark.parametrize("C", [96, 128])

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Which Python call sites launch the small torch copy / cast / fill kernels of a training step?  One T@128 step under torch.profiler
+with stacks; aten::copy_ / aten::to / aten::clone / aten::contiguous / aten::fill_ / aten::zero_ events grouped by their innermost
+frames inside this repository.  usage: python tools/trace_copies.py [workload]"""
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from heal_swin_amd.optim import FlatAdam  # noqa: E402
+from heal_swin_amd.parallel import GradBucketAllReduce  # noqa: E402
+
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "T128"]
+dev = torch.device("cuda")
+model, cfg, spec = bench.build_model(wl)
+model = model.to(dev).train()
+model.compute_dtype = torch.bfloat16
+dp = GradBucketAllReduce(model.parameters())
+opt = FlatAdam(model.parameters(), dp, lr=1e-4, model=model)
+g = torch.Generator(device=dev).manual_seed(1)
+imgs = torch.randint(0, 256, (8, 3, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
+labels = torch.randint(0, spec["f_out"], (8, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
+
+
+def step():
+    dp.zero_grad()
+    loss = model.forward_seg_loss(imgs.float(), labels)
+    loss.backward()
+    dp.finish()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], with_stack=True) as prof:
+    step()
+    torch.cuda.synchronize()
+names = ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::mul", "aten::sum", "aten::cat", "aten::index")
+groups = collections.Counter()
+for ev in prof.events():
+    if ev.name in names and ev.device_time_total > 0 or (ev.name in names and any(k.device_time > 0 for k in getattr(ev, "kernels", []))):
+        frames = [f for f in (ev.stack or []) if "heal_swin_amd" in f or "bench.py" in f or "trace_copies" in f]
+        key = (ev.name, " <- ".join(f.split("/")[-1] for f in frames[:3]) or "(no repo frame)", tuple(ev.input_shapes[0]) if ev.input_shapes else ())
+        groups[key[:2]] += 1
+for (name, where), n in groups.most_common(40):
+    print(f"{n:5d}  {name:14s} {where}")
