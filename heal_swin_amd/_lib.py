@@ -62,6 +62,8 @@ _SIGNATURES = {
     "hs_residual_drop": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     "hs_reduce_flush": [c_ptr],
+    "hs_linear_wgrad_gelu": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
+    "hs_linear_wgrad_gelu_supported": [c_i64, c_int, c_int, c_int],
     "hs_mlp_fused_supported": [c_int, c_int, c_int],
     "hs_mlp_fused_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_uint,
                          c_int, c_ptr],

@@ -633,7 +633,7 @@ int launch_tile(GemmParams& p, int epi, int wgs_per_cu, hipStream_t s) {
 }  // namespace hs
 
 namespace {
-int g_tile_variant = getenv("HS_GEMM_TILE") ? atoi(getenv("HS_GEMM_TILE")) : 0;  // A/B runs: 1 = 128x128, 2 = 256x128; 0 = heuristic
+int g_tile_variant = 0;  // hs_gemm_nt_set_tile (measurement hook): 1 = 128x128, 2 = 256x128, 3 = 256x256; 0 = heuristic
 }
 
 #ifdef HS_GEMM_TRACE
@@ -701,9 +701,8 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     // (the 256 x 256 kernels take an epilogue input through the DMA ring, which moves whole 16-byte chunks)
     if (variant == 3 && (epilogue == EPI_DGELU || epilogue == EPI_RESID) && n % 8) variant = 2;
     hipStream_t st = (hipStream_t)stream;
-    // role-separated DMA issue (FAST) wherever there is no K tail; HS_GEMM_FAST=0 keeps the symmetric kernels for A/B runs
-    static const bool fast_on = !(getenv("HS_GEMM_FAST") && atoi(getenv("HS_GEMM_FAST")) == 0);
-    const bool fast = fast_on && k % 64 == 0 && k2 % 64 == 0;
+    // role-separated DMA issue (FAST) wherever there is no K tail (8-16 % on the 256 x 256 tile, profiles/r03_gemm_role_split.txt)
+    const bool fast = k % 64 == 0 && k2 % 64 == 0;
     switch (variant) {
         case 2: return fast ? launch_tile<256, 128, 4, 2, 3, true, true>(p, epilogue, 1, st) : launch_tile<256, 128, 4, 2, 3, true, false>(p, epilogue, 1, st);
         case 3: return fast ? launch_tile<256, 256, 2, 4, 2, true, true>(p, epilogue, 1, st) : launch_tile<256, 256, 2, 4, 2, true, false>(p, epilogue, 1, st);

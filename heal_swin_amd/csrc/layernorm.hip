@@ -54,23 +54,10 @@ struct vec_io<bf16_t, 8> {
         }
     }
 };
-// A/B switch (tools/ln_store_ab.sh): non-temporal stores for the residual-stream sum of the fused add + LayerNorm (it is not
-// read again before the next block's norm, 100+ MB later; its neighbour y is read by the very next GEMM)
-#ifndef HS_LN_NT_SUM
-#define HS_LN_NT_SUM 0
-#endif
+// (non-temporal stores for the residual-stream sum were measured here: +1-3 % on the kernel, nothing on the step --
+// profiles/r03_ln_store_ab.txt; the plain store stays)
 template <typename T, int VEC>
 __device__ __forceinline__ void store_stream(void* p, int64_t i, const float* v) {
-#if HS_LN_NT_SUM
-    if constexpr (std::is_same<T, bf16_t>::value && VEC == 8) {
-        typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
-        u32x4nt w;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-        __builtin_nontemporal_store(w, (u32x4nt*)((uint16_t*)p + i));
-        return;
-    }
-#endif
     vec_io<T, VEC>::store(p, i, v);
 }
 
@@ -727,8 +714,8 @@ __global__ void __launch_bounds__(1024) layernorm_param_reduce_kernel(const floa
 // workgroups of the backward: enough to fill the chip for long inputs, few enough that the partial rows stay cheap
 int bwd_blocks(int64_t rows) {
     // rows per workgroup: 48 (was 128) keeps 8 workgroups per CU busy on the 98 304-row stage as well (89 -> 83.5 us; the
-    // partial rows of the parameter reduce grow with it: 6.7 -> 9.8 us); HS_LN_BWD_ROWS overrides for A/B runs
-    static const int div = getenv("HS_LN_BWD_ROWS") ? atoi(getenv("HS_LN_BWD_ROWS")) : 48;
+    // partial rows of the parameter reduce grow with it: 6.7 -> 9.8 us)
+    constexpr int div = 48;
     int64_t want = rows / div;
     if (want < 64) want = 64;
     if (want > kBwdMaxBlocks) want = kBwdMaxBlocks;
@@ -790,9 +777,8 @@ int run_fwd_fast(const void* x, const void* add_in, const float* g, const float*
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 256, 0) != hipSuccess || n < 1) n = 4;
         resident = n;
     }
-    static const int per_cu_override = getenv("HS_LN_FWD_PER_CU") ? atoi(getenv("HS_LN_FWD_PER_CU")) : 0;  // A/B runs
     constexpr int rows_per_pass = 4 * (64 / LPR);
-    int64_t blocks = (int64_t)usable_cus() * (per_cu_override > 0 ? per_cu_override : resident);
+    int64_t blocks = (int64_t)usable_cus() * resident;
     const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
     if (blocks > by_rows) blocks = by_rows;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, x, add_in, g, b, y, sum_out, mean, rstd, rows, width, residual);
@@ -802,7 +788,7 @@ int run_fwd_fast(const void* x, const void* add_in, const float* g, const float*
 
 // One resident round: as many workgroups as the chip holds at this instantiation's register / LDS footprint (every workgroup
 // then sees the same number of rows and there is no second, partly filled round), at most kBwdMaxBlocks partial rows, at
-// least one row group per wave.  HS_LN_BWD_FAST=0 sends everything through the general kernel (A/B runs).
+// least one row group per wave.
 template <typename T, int LPR, int ITERS>
 int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
                  float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in, int accumulate) {
@@ -817,8 +803,7 @@ int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mea
         resident_width = width;
     }
     constexpr int rows_per_pass = 4 * (64 / LPR);
-    static const int per_cu_override = getenv("HS_LN_BWD_PER_CU") ? atoi(getenv("HS_LN_BWD_PER_CU")) : 0;  // A/B runs
-    int64_t blocks = (int64_t)usable_cus() * (per_cu_override > 0 ? per_cu_override : resident);
+    int64_t blocks = (int64_t)usable_cus() * resident;
     if (blocks > kBwdMaxBlocks) blocks = kBwdMaxBlocks;
     const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
     if (blocks > by_rows) blocks = by_rows;
@@ -874,8 +859,7 @@ int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const f
     if (int st = check_extra(ex, rows)) return st;
     if (rows == 0) return HS_OK;
     hipStream_t s = (hipStream_t)stream;
-    static const bool fast = !(getenv("HS_LN_FWD_FAST") && atoi(getenv("HS_LN_FWD_FAST")) == 0);
-    const bool plain = fast && !(residual && add_in) && !ex.row_scale && ex.drop_p == 0.f && !ex.lo_in && !ex.lo_out;
+    const bool plain = !(residual && add_in) && !ex.row_scale && ex.drop_p == 0.f && !ex.lo_in && !ex.lo_out;
     if (dtype == HS_BF16) {
         if (plain && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32))
             return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s, residual); });
@@ -899,8 +883,7 @@ int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* 
     HS_CHECK_ARG(dtype == HS_F32 || dtype == HS_BF16, "dtype must be HS_F32 or HS_BF16");
     if (int st = check_extra(ex, rows)) return st;
     hipStream_t s = (hipStream_t)stream;
-    static const bool fast = !(getenv("HS_LN_BWD_FAST") && atoi(getenv("HS_LN_BWD_FAST")) == 0);
-    const bool plain = fast && !ex.row_scale && ex.drop_p == 0.f && !dadd_out;
+    const bool plain = !ex.row_scale && ex.drop_p == 0.f && !dadd_out;
     if (dtype == HS_F32 && plain && width % 4 == 0 && width <= 2048 && rows * width * 4 < (1ll << 32))
         return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd_fast<float, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, accumulate); });
     if (dtype == HS_BF16) {

@@ -20,7 +20,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "hs_device.h"
+#include "hs_gelu.h"
 
 namespace hs {
 namespace {
@@ -74,10 +74,10 @@ inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int 
     g.per_xcd = (g.slices * g.tiles + 7) / 8;
     // the LDS-DMA kernels address a slice through 32-bit buffer offsets
     g.dma = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * elt < ((int64_t)1 << 31);
-    static const int reads_first = getenv("HS_WGRAD_READS_FIRST") ? atoi(getenv("HS_WGRAD_READS_FIRST")) : 3;
-    // stage schedule of the LDS-DMA kernels (A/B hook): 0 = next stage's DMA issued before the fragment reads, 1 = behind them,
-    // 2 = behind the first MFMA group, 3 (default) = 1 + the second wave group half a stage out of phase (8-wave tile)
-    g.reads_first = reads_first;
+    // stage schedule of the LDS-DMA kernels: 3 = next stage's DMA issued behind the fragment reads + the second wave group half a
+    // stage out of phase (8-wave tile).  (0 = DMA before the reads, 1 = behind them, 2 = behind the first MFMA group: the schedules
+    // round 2 measured against it, profiles/r02_wgrad_schedule_ab.txt)
+    g.reads_first = 3;
     return g;
 }
 
@@ -266,7 +266,11 @@ __device__ __forceinline__ s16x8 tr_frag_asm(uint32_t a, int ks) {
     return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int NB, int TK>
+// GX: the X operand is gelu(X) -- the weight gradient of the Linear BEHIND a GELU taken from the saved pre-activation (fc2 of the fused
+// Mlp block, csrc/mlp_fused.hip, which then does not write gelu(h) at all).  The activation is applied to the MFMA fragments
+// between their LDS read and the product: 16 packed evaluations per stage and wave, which an HBM-bound launch (C <= 128: the only
+// shapes that use it) has the VALU slots for.
+template <int NB, int TK, bool GX = false>
 __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                            float* __restrict__ part_w, float* __restrict__ part_b,
                                                            int64_t rows, int n_out, int k_in, Geometry g, int ldy, int ldx, int yc0, int xc0) {
@@ -377,6 +381,18 @@ __global__ void __launch_bounds__(TK * 2, 2) wgrad_dma_kernel(const uint16_t* __
         }
     };
     auto mma_half = [&](int ks) {
+        if constexpr (GX) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 w = __builtin_bit_cast(u32x4, bf[ks][j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 v = gelu2(f32x2{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)});
+                    w[e] = pack_bf16x2(v.x, v.y);
+                }
+                bf[ks][j] = __builtin_bit_cast(s16x8, w);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -708,12 +724,23 @@ int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in) {
 
 namespace {
 int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out, int k_in,
-                      int accumulate, int dtype, void* stream, int ldy, int ldx, int yc0, int xc0);
+                      int accumulate, int dtype, void* stream, int ldy, int ldx, int yc0, int xc0, bool gelu_x = false);
 }
 
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out,
                     int k_in, int accumulate, int dtype, void* stream) {
     return linear_wgrad_impl(dy, x, dw, dbias, workspace, rows, n_out, k_in, accumulate, dtype, stream, n_out, k_in, 0, 0);
+}
+
+int hs_linear_wgrad_gelu_supported(int64_t rows, int n_out, int k_in, int dtype) {
+    if (dtype != HS_BF16 || rows <= 0 || n_out <= 0 || k_in <= 0 || n_out % 4 || k_in % 8) return 0;
+    const hs::Geometry g = hs::make_geometry(rows, n_out, k_in);
+    return g.dma && g.tile_k != 256 && g.tile_n != 256;
+}
+
+int hs_linear_wgrad_gelu(const void* dy, const void* h, float* dw, float* dbias, float* workspace, int64_t rows, int n_out, int k_in,
+                         int accumulate, int dtype, void* stream) {
+    return linear_wgrad_impl(dy, h, dw, dbias, workspace, rows, n_out, k_in, accumulate, dtype, stream, n_out, k_in, 0, 0, true);
 }
 
 int hs_linear_wgrad_ld(const void* dy, int64_t ldy, int64_t ycol0, const void* x, int64_t ldx, int64_t xcol0, float* dw, float* dbias,
@@ -727,7 +754,7 @@ int hs_linear_wgrad_ld(const void* dy, int64_t ldy, int64_t ycol0, const void* x
 
 namespace {
 int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, float* workspace, int64_t rows, int n_out, int k_in,
-                      int accumulate, int dtype, void* stream, int ldy, int ldx, int yc0, int xc0) {
+                      int accumulate, int dtype, void* stream, int ldy, int ldx, int yc0, int xc0, bool gelu_x) {
     using namespace hs;
     HS_CHECK_ARG(dy && x && dw && workspace, "null pointer");
     HS_CHECK_ARG(rows > 0 && n_out > 0 && k_in > 0, "bad shape");
@@ -739,6 +766,8 @@ int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, fl
         return fail(HS_ERR_UNSUPPORTED, "bf16: n_out must be a multiple of 4 and k_in a multiple of 8");
     if (dtype == HS_F32 && (n_out % 4 || k_in % 4)) return fail(HS_ERR_UNSUPPORTED, "fp32: n_out and k_in must be multiples of 4");
     Geometry g = dtype == HS_F32 ? make_geometry_f32(rows, n_out, k_in) : make_geometry(rows, n_out, k_in);
+    if (gelu_x && !(dtype == HS_BF16 && g.dma && g.tile_k != 256 && g.tile_n != 256))
+        return fail(HS_ERR_UNSUPPORTED, "hs_linear_wgrad_gelu: bf16 and the 128 x 128 LDS-DMA tile only (n_out <= 128-class shapes)");
     const bool strided = ldy != n_out || ldx != k_in || yc0 || xc0;
     if (strided) {  // column blocks of wider matrices: LDS-DMA kernels only, 32-bit offsets inside a token slice
         if (!g.dma || g.rows_per_slice * (int64_t)(ldy > ldx ? ldy : ldx) * 2 >= ((int64_t)1 << 31))
@@ -760,6 +789,8 @@ int linear_wgrad_impl(const void* dy, const void* x, float* dw, float* dbias, fl
         hipLaunchKernelGGL((wgrad_dma_kernel<4, 256>), grid, dim3(512), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g, ldy, ldx, yc0, xc0);
     else if (g.dma && g.tile_n == 256)
         hipLaunchKernelGGL((wgrad_dma_kernel<4, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g, ldy, ldx, yc0, xc0);
+    else if (g.dma && gelu_x)
+        hipLaunchKernelGGL((wgrad_dma_kernel<2, 128, true>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g, ldy, ldx, yc0, xc0);
     else if (g.dma)
         hipLaunchKernelGGL((wgrad_dma_kernel<2, 128>), grid, dim3(256), 0, s, dyp, xp, part_w, part_b, rows, n_out, k_in, g, ldy, ldx, yc0, xc0);
     else if (g.tile_n == 256)

@@ -1026,11 +1026,9 @@ int fwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / h
 // slower).  Backward (two waves per head): round 2 measured pairs ahead of four heads on the 5-barrier kernel (8-wave barriers);
 // with the 3-barrier kernel of round 4 FOUR heads per workgroup (8 waves, 137 KB of LDS, one workgroup per CU, 256-byte row
 // segments) win at every stage of HEAL-SWIN-B (profiles/r04_attn_bwd_hg4_ab.txt, same box: 570 -> 515, 290 -> 260, 163 -> 150,
-// 96 -> 93 us).  HS_ATTN_BWD_HG / HS_ATTN_FWD_HG force a size for A/B runs.
+// 96 -> 93 us).
 int pick_head_group_bwd(const AttnParams& p) {
-    static const int forced = getenv("HS_ATTN_BWD_HG") ? atoi(getenv("HS_ATTN_BWD_HG")) : 0;  // A/B runs
     const int nH = p.nH;
-    if (forced >= 1 && forced <= 4 && nH % forced == 0) return forced;
     // four heads per workgroup pay on the large launches only (one [B, N, C] tensor >= 64 MB: stages 0-2 of HEAL-SWIN-B at nside
     // 256); on the small ones (HEAL-SWIN-T: stage 2 at nside 256 88 vs 93 us, at nside 128 33 vs 44 us) two workgroups of four
     // waves per CU hide each other's prologue and barriers better
@@ -1068,9 +1066,7 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
 }
 
 int pick_head_group(const AttnParams& p) {
-    static const int forced = getenv("HS_ATTN_FWD_HG") ? atoi(getenv("HS_ATTN_FWD_HG")) : 0;  // A/B runs
     const int nH = p.nH;
-    if (((forced >= 1 && forced <= 4) || forced == 8) && nH % forced == 0) return forced;
     // eight heads per workgroup (512-byte row segments, one workgroup of 8 waves per CU) on the large launches: with the
     // 2-barrier kernel of round 4 stages 1 / 2 of HEAL-SWIN-B run 177 -> 166 / 107 -> 99 us (profiles/r04_attn_fwd_hg8_ab.txt;
     // round 3 had measured the opposite on the 3-barrier kernel); the small stage 3 (50 MB) loses 10 %

@@ -75,7 +75,7 @@ struct ModParams {
     int64_t N;
     int slots;
     unsigned flags;
-    int dma_mode;  // where the next window's x tile is requested (HS_MOD_DMA, A/B): 0 (default) = in front of the LayerNorm, 1 = behind the
+    int dma_mode;  // where the next window's x tile is requested: 0 (shipped) = in front of the LayerNorm, 1 = behind the
                    // second k-step of the qkv product, 2 = one piece behind each of its first k-steps
     // training form (null in the inference form), natural token order
     uint16_t* xn_out;   // [B, N, C]   LayerNorm(x): input of the qkv product (its weight gradient reads it)
@@ -891,8 +891,7 @@ int module_fwd_impl(const char* who, const void* x, void* out, const TrainOut& t
         p.proj_w = (const uint16_t*)proj_w; p.proj_b = proj_b; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.bias = bias;
         p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = std::min(chunk, batch - b0);
         p.N = n_tokens; p.flags = flags;
-        static const int dma_mode = getenv("HS_MOD_DMA") ? atoi(getenv("HS_MOD_DMA")) : 0;
-        p.dma_mode = dma_mode;
+        p.dma_mode = 0;  // (1 / 2: the measured-and-rejected placements under the qkv product, profiles/r04_attn_module_train.txt)
 #ifdef HS_MOD_TRACE
         p.trace = g_mod_trace;
 #endif

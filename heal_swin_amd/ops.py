@@ -278,10 +278,10 @@ def window_attn_core(qkv, bias, head_scale, idx, roll, labels, num_heads, window
 # tail's roundings dominate it, tests/experiments/bf16_error_budget.py) and costs 2.4 % of the step (158.7 -> 162.6 ms).
 COMP_RESIDUAL = os.environ.get("HS_COMP_RESIDUAL", "0") == "1"
 # the same for the LAST decoder stage only (the two blocks in front of the tail; 2 of 46 blocks of HEAL-SWIN-B): experiment switch
-COMP_RESIDUAL_LAST_STAGE = os.environ.get("HS_COMP_RESIDUAL_LAST", "0") == "1"
+COMP_RESIDUAL_LAST_STAGE = False  # (set by tests / experiments; no environment switch)
 
 
-FUSED_ATTN_MODULE = os.environ.get("HS_FUSED_ATTN_MODULE", "1") != "0"  # A/B switch of the no-grad fused module path
+FUSED_ATTN_MODULE = True  # the no-grad fused module path (tests flip the attribute to compare with the composition)
 
 
 def window_attn_module_ok(x, num_heads, window_size):
@@ -317,7 +317,7 @@ def window_attn_module(x, qkv_w, qkv_b, proj_w, proj_b, bias, head_scale, idx, r
 FUSED_ATTN_MODULE_TRAIN = os.environ.get("HS_FUSED_ATTN_TRAIN", "1") != "0"
 # the block's norm2 as that kernel's epilogue: built, parity-tested, time-NEUTRAL on the step (144.3-144.5 ms either way: the standalone
 # LayerNorm streams at 4.7 TB/s, the one-wave-per-SIMD module kernel pays about as much for the extra phase) -- off by default
-FUSED_NORM2 = os.environ.get("HS_FUSED_NORM2", "0") == "1"
+FUSED_NORM2 = False  # superseded: norm2 is now the PROLOGUE of the fused Mlp block (csrc/mlp_fused.hip); kept as a tested kernel option
 
 
 def window_attn_module_train_ok(x, num_heads, window_size):
@@ -860,9 +860,9 @@ OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice bel
 # bf16 Linear product then runs on hs_gemm_nt, whose persistent grids honour hs_set_reserved_cus.  The library GEMMs fill all
 # 256 CUs and cannot be masked: with 8 foreign workgroups resident they lose 64 % (256 -> 420 us, profiles/r03_cu_contention.json).
 # Costs ~3 ms per step on an idle chip (HS_OWN_GEMM=1 measurement of round 3), saves ~27 ms under contention (r04_cu_contention.json).
-OWN_GELU_MAX_K = int(os.environ.get("HS_OWN_GELU_MAX_K", "4096"))
-OWN_DGELU_MAX_K = int(os.environ.get("HS_OWN_DGELU_MAX_K", "1024"))
-OWN_BIAS_MAX_K = int(os.environ.get("HS_OWN_BIAS_MAX_K", "0"))  # A/B: > 0 sends every bias / residual product with k <= this to hs_gemm_nt
+OWN_GELU_MAX_K = 4096
+OWN_DGELU_MAX_K = 1024
+OWN_BIAS_MAX_K = 0  # (> 0 would send every bias / residual product with k <= this to hs_gemm_nt: measured, slower -- profiles/r03_gemm_policy_ab.txt)
 
 
 def own_gemm_ok(epi, n, k, dtype, k2=0):
@@ -873,8 +873,7 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     loads) and loses the long reductions (K >= 1024: 0.96-1.06 vs 1.26 PFLOP/s).  A GELU forward epilogue pays while the
     product is HBM-bound (it has to write h AND gelu(h): at K = 512 the 256x256 tile needs 355-368 us against 197 us tuned
     library GEMM + 141 us standalone GELU pass); the GELU-gradient epilogue (reads h, writes once) wins at every stage
-    (K = 1024: 265 us against 175-188 us library GEMM + 105 us GELU' pass).  HS_OWN_GELU_MAX_K / HS_OWN_DGELU_MAX_K move the
-    two thresholds for A/B runs."""
+    (K = 1024: 265 us against 175-188 us library GEMM + 105 us GELU' pass)."""
     if dtype != torch.bfloat16 or OWN_GEMM == "0" or k % 8 or k2 % 8 or n % 8 or n < 16:
         return False  # (n % 8: whole-row-segment stores; the model pads the 12-class head to 16 rows)
     if OWN_GEMM == "1" or RT.prefer_own_gemm:
@@ -897,7 +896,7 @@ def own_gemm_legal(n, k, dtype):
 # Residual adds in the GEMM epilogue (v1 blocks without stochastic regularisers): x1 = x + proj(o) and x2 = x1 + fc2(act) leave the
 # proj / fc2 product's epilogue (EPI_RESID: acc + bias + residual, ONE rounding), so the LayerNorm that follows is a plain
 # LayerNorm (reads 1, writes 1) instead of the fused add + LayerNorm (reads 2, writes 2): 2 of 8 tensor-units per block.
-RESID_EPILOGUE = os.environ.get("HS_RESID_EPILOGUE", "1") != "0"
+RESID_EPILOGUE = True
 
 
 def gemm_nt(a2d, w, bias=None, epi=0, aux=None, a2=None, w2=None, want_c=True, drop_p=0.0, seed=0):
@@ -929,7 +928,7 @@ def _lib_tag(kind, m, n, k):
 # fp32 product, 3/16 of the fp32-MFMA time); "strict" keeps exact-fp32 GEMMs (library fp32 GEMM, v_mfma_f32_32x32x2_f32 weight
 # gradients) -- the reference form, used by the finite-difference tests.
 FP32_GEMM = os.environ.get("HS_FP32_GEMM", "bf16x3")
-_BF16X3_MIN = int(os.environ.get("HS_BF16X3_MIN", "160"))  # n k / (n + k) from which a product takes the bf16x3 form (A/B hook)
+_BF16X3_MIN = 160  # n k / (n + k) from which a product takes the bf16x3 form (sweep: see _bf16x3_ok)
 _SPLIT_MEMO = []  # the last few splits (key, tensor): dy is split once for the input- and the weight-gradient product
 _MM_OUT_DTYPE = [None]  # whether torch.mm(..., out_dtype=) is available in this build (probed on first use)
 
@@ -1094,9 +1093,10 @@ def _cast_param_t(p, dtype, cache=None):
     return c
 
 
-def _param_grads(dy2, x2, weight, bias, want_w, want_b, x3=None):
+def _param_grads(dy2, x2, weight, bias, want_w, want_b, x3=None, gelu_x=False):
     """Weight / bias gradient of y = x W^T + b from dy2 [rows, n_out], x2 [rows, k_in]: deposited straight into the gradient
-    sink's buffers when one knows the parameters (returns (None, None)), else returned in the parameters' dtype."""
+    sink's buffers when one knows the parameters (returns (None, None)), else returned in the parameters' dtype.
+    gelu_x: the Linear's input was gelu(x2) and only the pre-activation x2 was kept (`hs_linear_wgrad_gelu`)."""
     n_out = weight.shape[0]
     k_in = weight.numel() // n_out
     if not (want_w or want_b):
@@ -1121,19 +1121,20 @@ def _param_grads(dy2, x2, weight, bias, want_w, want_b, x3=None):
             dy2.record_stream(aw.stream)
             (x2 if x2 is not None else x3).record_stream(aw.stream)
             with torch.cuda.stream(aw.stream):
-                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3)
+                LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3, gelu_x)
         else:
-            LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3)
+            LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, wbuf, bbuf, x3, gelu_x)
         RT.grad_sink.deposited(weight)
         if want_b:
             RT.grad_sink.deposited(bias)
         return None, None
     dw = db = None
     if hip_ok:
-        dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, x3=x3)
+        dw32, db32 = LinearFn._wgrad_hip(dy2, x2, n_out, k_in, want_b, x3=x3, gelu_x=gelu_x)
         dw = dw32.to(weight.dtype).view(weight.shape) if want_w else None
         db = db32.to(bias.dtype) if want_b else None
     else:  # odd widths: library GEMM
+        assert not gelu_x
         if want_w:
             dw = (dy2.t() @ x2).to(weight.dtype).view(weight.shape)
         if want_b:
@@ -1187,7 +1188,7 @@ class LinearFn(torch.autograd.Function):
         return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None, x3=None):
+    def _wgrad_hip(dy2, x2, n_out, k_in, want_b, dw_out=None, db_out=None, x3=None, gelu_x=False):
         """dW (and db) of one Linear.  With dw_out/db_out (existing fp32 gradient buffers) the result is ADDED there."""
         rows = dy2.shape[0]
         dev = dy2.device
@@ -1222,8 +1223,12 @@ class LinearFn(torch.autograd.Function):
                         _defer_keep(dev, ws)
             return dw32, db32
         with _timed("linear_wgrad", dev, x2.element_size() * rows * (n_out + k_in), 2 * rows * n_out * k_in):
-            check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate | defer,
-                                      _lib.dtype_code(x2.dtype), stream_ptr(dev)), "hs_linear_wgrad")
+            if gelu_x:  # dW = dY^T gelu(x2): the activation is applied to the operand fragments inside the kernel
+                check(lib.hs_linear_wgrad_gelu(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate | defer,
+                                               _lib.dtype_code(x2.dtype), stream_ptr(dev)), "hs_linear_wgrad_gelu")
+            else:
+                check(lib.hs_linear_wgrad(ptr(dy2), ptr(x2), ptr(dw32), ptr(db32), ptr(ws), rows, n_out, k_in, accumulate | defer,
+                                          _lib.dtype_code(x2.dtype), stream_ptr(dev)), "hs_linear_wgrad")
         if defer:
             _defer_keep(dev, ws)
         return dw32, db32
@@ -1308,7 +1313,7 @@ def pad_slice(x, n):
     return PadSliceFn.apply(x, n)
 
 
-FUSED_LN_HEAD = os.environ.get("HS_FUSED_LN_HEAD", "1") != "0"
+FUSED_LN_HEAD = True  # (tests flip the attribute to compare with the unfused tail)
 
 
 def ln_head_ok(x, width, n_classes):
@@ -1402,7 +1407,7 @@ def _fold_head(gamma, beta, weight, C, device):
     return wfold, bvec
 
 
-FUSED_EXPAND_HEAD = os.environ.get("HS_FUSED_EXPAND_HEAD", "1") != "0"
+FUSED_EXPAND_HEAD = True
 
 
 def expand_ln_head_ok(x, width, children, n_classes):
@@ -1634,6 +1639,7 @@ def mlp(x, w1, b1, w2, b2, drop_p=0.0, seed=None, passthrough=False, residual=No
 
 # ----------------------------------------------------------------------------- fused Mlp block (HBM-bound stages)
 FUSED_MLP = os.environ.get("HS_FUSED_MLP", "1") != "0"  # A/B switch: off = LayerNorm -> hs_gemm_nt(GELU) -> hs_gemm_nt(residual)
+MLP_KEEP_ACT = False  # True: the fused forward also writes gelu(h) for fc2's weight gradient (tests and tools/bench_mlp_fused.py flip it)
 
 
 def fused_mlp_ok(x, hidden):
@@ -1669,10 +1675,12 @@ class FusedMlpBlockFn(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         h = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
-        act = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
+        # gelu(h) is kept only where fc2's weight gradient cannot take it from h (hs_linear_wgrad_gelu): 7 instead of 11 row-units
+        keep_act = need and (MLP_KEEP_ACT or not lib.hs_linear_wgrad_gelu_supported(rows, C, hid, _lib.HS_BF16))
+        act = torch.empty((rows, hid), dtype=x.dtype, device=dev) if keep_act else None
         flags = _lib.HS_ATTN_RESIDUAL | (_lib.HS_MLP_NORM_AFTER if post_norm else 0)
         # algorithmic traffic: x in, out (+ n, h, gelu(h) kept for the backward); flops: the two products
-        with _timed("mlp_fused_fwd", dev, 2 * rows * ((3 if need else 2) * C + (2 * hid if need else 0)), 4 * rows * C * hid):
+        with _timed("mlp_fused_fwd", dev, 2 * rows * ((3 if need else 2) * C + ((2 if keep_act else 1) * hid if need else 0)), 4 * rows * C * hid):
             check(lib.hs_mlp_fused_fwd(ptr(x2), ptr(g), ptr(b), ptr(w1c), ptr(_f32(b1)), ptr(w2c), ptr(_f32(b2)), ptr(n), ptr(mean), ptr(rstd),
                                        ptr(h), ptr(act), ptr(out), rows, C, hid, flags, _lib.HS_BF16, stream_ptr(dev)),
                   "hs_mlp_fused_fwd")
@@ -1710,14 +1718,16 @@ class FusedMlpBlockFn(torch.autograd.Function):
             with _timed("mlp_fused_bwd", dev, 2 * rows * (3 * C + 2 * hid), 4 * rows * C * hid):
                 check(lib.hs_mlp_fused_bwd(ptr(dm), ptr(h), ptr(w2t), ptr(w1t), ptr(dy2), ptr(dh), ptr(dx), rows, C, hid, _lib.HS_BF16,
                                            stream_ptr(dev)), "hs_mlp_fused_bwd")
-            dw2, db2 = _param_grads(dm, act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6])
+            dw2, db2 = _param_grads(dm, h if act is None else act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6],
+                                    gelu_x=act is None)
             dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[3], b1 is not None and ctx.needs_input_grad[4])
         else:
             dn = torch.empty_like(x2)
             with _timed("mlp_fused_bwd", dev, 2 * rows * (2 * C + 2 * hid), 4 * rows * C * hid):
                 check(lib.hs_mlp_fused_bwd(ptr(dy2), ptr(h), ptr(w2t), ptr(w1t), None, ptr(dh), ptr(dn), rows, C, hid, _lib.HS_BF16,
                                            stream_ptr(dev)), "hs_mlp_fused_bwd")
-            dw2, db2 = _param_grads(dy2, act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6])
+            dw2, db2 = _param_grads(dy2, h if act is None else act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6],
+                                    gelu_x=act is None)
             dw1, db1 = _param_grads(dh, n, w1, b1, ctx.needs_input_grad[3], b1 is not None and ctx.needs_input_grad[4])
             # norm2 backward with the residual gradient (dy itself) added inside the kernel
             dx = torch.empty_like(x2)

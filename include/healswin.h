@@ -316,6 +316,13 @@ int hs_seg_ce_bwd(const void* logits, const void* labels, const float* class_wei
 int64_t hs_linear_wgrad_workspace(int64_t rows, int n_out, int k_in);
 int hs_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* workspace,
                     int64_t rows, int n_out, int k_in, int accumulate, int dtype, void* stream);
+/* dw[n, k] = sum_m dy[m, n] * gelu(h[m, k]): the weight gradient of a Linear whose input is gelu(h), taken from the saved
+ * pre-activation h (fc2 of reference Mlp.forward :38-44) -- the fused Mlp block then keeps h only.  Exact-erf GELU as everywhere
+ * (csrc/hs_gelu.h), applied to the MFMA operand fragments; bf16 and the shapes of hs_linear_wgrad_gelu_supported (the 128 x 128
+ * tile: C <= 128-class layers, whose launches are HBM-bound and have the VALU slots). */
+int hs_linear_wgrad_gelu_supported(int64_t rows, int n_out, int k_in, int dtype);
+int hs_linear_wgrad_gelu(const void* dy, const void* h, float* dw, float* dbias, float* workspace, int64_t rows, int n_out, int k_in,
+                         int accumulate, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Deferred parameter-gradient reductions.  hs_linear_wgrad / hs_linear_wgrad_ld and the four LayerNorm backward entry points

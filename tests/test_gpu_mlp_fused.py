@@ -225,3 +225,57 @@ def test_fused_mlp_rejects_unsupported_shapes():
     with pytest.raises(AssertionError):
         L.check(L.lib.hs_mlp_fused_fwd(L.ptr(x), None, None, L.ptr(w), None, L.ptr(w), None, None, None, None, None, None, L.ptr(x), 48, 128, 512,
                                        0, L.HS_BF16, _stream()), "hs_mlp_fused_fwd")
+
+
+@pytest.mark.parametrize("rows,n_out,k_in", [(8192, 128, 512), (4096 + 32, 96, 384), (300, 128, 128)])
+def test_linear_wgrad_gelu_equals_wgrad_of_gelu(rows, n_out, k_in):
+    """hs_linear_wgrad_gelu(dy, h) = dY^T gelu(h): against float64 with the oracle's gelu on the same bf16 h, and against
+    hs_linear_wgrad on a materialised bf16 gelu(h) (the form it replaces; they differ by that tensor's rounding only)."""
+    from oracle import model as OM
+    L = _L()
+    lib, ptr = L.lib, L.ptr
+    assert lib.hs_linear_wgrad_gelu_supported(rows, n_out, k_in, L.HS_BF16)
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    dy = torch.randn((rows, n_out), generator=g, device=DEV).to(BF)
+    h = (torch.randn((rows, k_in), generator=g, device=DEV) * 1.5).to(BF)
+    nws = int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in))
+    dw, db = torch.zeros((n_out, k_in), device=DEV), torch.zeros(n_out, device=DEV)
+    L.check(lib.hs_linear_wgrad_gelu(ptr(dy), ptr(h), ptr(dw), ptr(db), ptr(torch.empty(nws, device=DEV)), rows, n_out, k_in, 0, L.HS_BF16,
+                                     _stream()), "hs_linear_wgrad_gelu")
+    act64 = OM.gelu(h.double())
+    ref = dy.double().t() @ act64.to(BF).double()
+    assert_close(dw, ref, 3e-3, f"wgrad_gelu {rows}x{n_out}x{k_in} dW")
+    assert_close(db, dy.double().sum(0), 1e-3, f"wgrad_gelu {rows}x{n_out}x{k_in} db")
+    dw2 = torch.zeros_like(dw)
+    act = act64.to(BF)
+    L.check(lib.hs_linear_wgrad(ptr(dy), ptr(act), ptr(dw2), None, ptr(torch.empty(nws, device=DEV)), rows, n_out, k_in, 0, L.HS_BF16,
+                                _stream()), "hs_linear_wgrad")
+    assert_close(dw, dw2, 3e-3, f"wgrad_gelu vs wgrad(gelu) {rows}x{n_out}x{k_in}")
+    assert not lib.hs_linear_wgrad_gelu_supported(98304, 2048, 512, L.HS_BF16)  # the 256-wide tiles keep the plain form
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_fused_mlp_block_with_and_without_kept_activation(keep):
+    """The two forms of the fused block's saved state -- h only (fc2's weight gradient re-applies GELU) and h + gelu(h) -- give the
+    same gradients to bf16 rounding."""
+    from heal_swin_amd import ops
+    C, rows = 128, 4096
+    t = _case(C, rows, 77)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    dy = torch.randn((rows, C), generator=g, device=DEV).to(BF)
+    names = ("ln_w", "ln_b", "w1", "b1", "w2", "b2")
+    res = {}
+    prev = ops.MLP_KEEP_ACT
+    try:
+        for mode in (keep, not keep):
+            ops.MLP_KEEP_ACT = mode
+            x = t["x"].clone().requires_grad_(True)
+            ps = {k: t[k].float().clone().requires_grad_(True) for k in names}
+            out = ops.fused_mlp_block(x, ps["ln_w"], ps["ln_b"], ps["w1"], ps["b1"], ps["w2"], ps["b2"])
+            out.backward(dy)
+            res[mode] = dict(out=out.detach(), x=x.grad, **{k: ps[k].grad for k in names})
+    finally:
+        ops.MLP_KEEP_ACT = prev
+    assert torch.equal(res[True]["out"], res[False]["out"])
+    for k in ("x",) + names:
+        assert_close(res[False][k], res[True][k], 3e-3, f"fused mlp keep_act on/off d{k}")
