@@ -1639,7 +1639,12 @@ def mlp(x, w1, b1, w2, b2, drop_p=0.0, seed=None, passthrough=False, residual=No
 
 # ----------------------------------------------------------------------------- fused Mlp block (HBM-bound stages)
 FUSED_MLP = os.environ.get("HS_FUSED_MLP", "1") != "0"  # A/B switch: off = LayerNorm -> hs_gemm_nt(GELU) -> hs_gemm_nt(residual)
-MLP_KEEP_ACT = False  # True: the fused forward also writes gelu(h) for fc2's weight gradient (tests and tools/bench_mlp_fused.py flip it)
+# gelu(h) kept for fc2's weight gradient (True), or re-applied to the saved h inside that weight-gradient kernel (False:
+# hs_linear_wgrad_gelu -- 4 of the forward's 11 row-units and 1.6 GB per stage-0 block of HEAL-SWIN-B less).  Measured on MI355X
+# (profiles/r05_mlp_fused_keep_act_ab.txt): the forward kernel gains 864 -> 775 us (it is then bound by its own issue rate, not by
+# HBM), the weight gradient loses ~300 us (two waves evaluate every fragment's GELU), the step is unchanged (142.3 vs 142.6 ms) at
+# 103.5 instead of 109.9 GB peak: the memory-saving form is an option, the default keeps the activation.
+MLP_KEEP_ACT = True
 
 
 def fused_mlp_ok(x, hidden):
@@ -1675,7 +1680,7 @@ class FusedMlpBlockFn(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         h = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
-        # gelu(h) is kept only where fc2's weight gradient cannot take it from h (hs_linear_wgrad_gelu): 7 instead of 11 row-units
+        # (ops.MLP_KEEP_ACT = False: kept only where fc2's weight gradient cannot take it from h, hs_linear_wgrad_gelu)
         keep_act = need and (MLP_KEEP_ACT or not lib.hs_linear_wgrad_gelu_supported(rows, C, hid, _lib.HS_BF16))
         act = torch.empty((rows, hid), dtype=x.dtype, device=dev) if keep_act else None
         flags = _lib.HS_ATTN_RESIDUAL | (_lib.HS_MLP_NORM_AFTER if post_norm else 0)
