@@ -888,6 +888,9 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
     return kk <= 128 or n <= 128 or (n <= 256 and kk <= 256)
 
 
+RESID_DGRAD_OWN = True  # (T@256 paper config, same box: 46.2 vs 46.9 ms per step)
+
+
 def own_gemm_legal(n, k, dtype):
     """Whether `hs_gemm_nt` CAN run an [*, k] x [n, k]^T product (the policy question is own_gemm_ok)."""
     return dtype == torch.bfloat16 and OWN_GEMM != "0" and k % 8 == 0 and n % 8 == 0 and n >= 16
@@ -1259,7 +1262,10 @@ def _input_grad(dy2, weight, w_cast, dx_res2=None, cache=None):
     n_out = weight.shape[0]
     k_in = weight.numel() // n_out
     epi = _lib.HS_EPI_BIAS if dx_res2 is None else _lib.HS_EPI_RESID
-    if own_gemm_ok(epi, k_in, n_out, dy2.dtype):
+    # with a residual-path gradient to add (v2 placement), the library form is torch.addmm(res, dy, W): a device-to-device copy of
+    # `res` into the result and THEN the product with beta = 1 -- a whole extra pass (36 copies, ~1 ms per HEAL-SWIN-T @ 256 step);
+    # hs_gemm_nt reads the addend in its epilogue instead
+    if own_gemm_ok(epi, k_in, n_out, dy2.dtype) or (dx_res2 is not None and RESID_DGRAD_OWN and own_gemm_legal(k_in, n_out, dy2.dtype)):
         res = None if dx_res2 is None else dx_res2.to(dy2.dtype).contiguous()
         return gemm_nt(dy2, _cast_param_t(weight, dy2.dtype, cache), None, epi, aux=res)[0]
     w = w_cast if (w_cast is not None and w_cast.dtype == dy2.dtype) else (

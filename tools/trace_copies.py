@@ -40,12 +40,20 @@ torch.cuda.synchronize()
 with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
-names = ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::mul", "aten::sum", "aten::cat", "aten::index")
 groups = collections.Counter()
+times = collections.Counter()
 for ev in prof.events():
-    if ev.name in names and ev.device_time_total > 0 or (ev.name in names and any(k.device_time > 0 for k in getattr(ev, "kernels", []))):
-        frames = [f for f in (ev.stack or []) if "heal_swin_amd" in f or "bench.py" in f or "trace_copies" in f]
-        key = (ev.name, " <- ".join(f.split("/")[-1] for f in frames[:3]) or "(no repo frame)", tuple(ev.input_shapes[0]) if ev.input_shapes else ())
-        groups[key[:2]] += 1
-for (name, where), n in groups.most_common(40):
-    print(f"{n:5d}  {name:14s} {where}")
+    if ev.device_type == torch.autograd.DeviceType.CUDA or not ev.kernels:
+        continue
+    kn = [k.name for k in ev.kernels]
+    if not any(("Memcpy" in k or "copyBuffer" in k or "elementwise" in k or "fillBuffer" in k or "Memset" in k) for k in kn):
+        continue
+    chain, cur = [], ev
+    while cur is not None and len(chain) < 8:
+        chain.append(cur.name)
+        cur = cur.cpu_parent
+    key = (kn[0][:40], " <- ".join(chain))
+    groups[key] += 1
+    times[key] += sum(k.duration for k in ev.kernels)
+for key, n in sorted(groups.items(), key=lambda kv: -times[kv[0]])[:45]:
+    print(f"{n:5d} {times[key]:9.1f} us  {key[0]:40s} {key[1][:260]}")
