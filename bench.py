@@ -551,6 +551,20 @@ def main():
                     "achieved_TFLOPs": tf, "frac_of_dense_bf16_peak": tf / MFMA_PEAK_TFLOPS,
                     "attention_roofline": {"bound": "hbm", "achieved": rl["achieved"], "peak": rl["peak"], "unit": "GB/s", "frac": rl["frac"],
                                            "avg_launch_us": rl["avg_launch_us"], "launches": rl["launches"], "measured_in": "the eager run"}}
+            # the paper's ACTUAL training configuration: the same model with drop_rate = attn_drop_rate = drop_path_rate = 0.1
+            # (run_configs/segmentation/swin_hp_woodscape_train_run_config.py:50-51 + the config default :715); eager only -- the
+            # dropout seeds are drawn on the host per call, a graph would freeze them
+            w = WORKLOADS["T256"]
+            wd = dict(w, cfg=dict(w["cfg"], drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1), name=w["name"] + " drop 0.1/0.1/0.1")
+            dctx = types.SimpleNamespace(**{**vars(ctx), "wl": wd, "args": argparse.Namespace(**{**vars(args), "paper_drop_rates": True})})
+            rd_ = run_workload(dctx, "bf16", 8, 2, timing=False)
+            base = out["companions"]["T256"]
+            out["companions"]["T256_paper_drop"] = {
+                "workload": wd["name"], "value": args.batch * 8 / rd_.elapsed, "unit": "images/s", "batch_per_gpu": args.batch, "steps": 8, "warmup": 2,
+                "launch": "eager", "ms_per_step_eager": 1e3 * rd_.elapsed / 8, "final_loss": rd_.loss,
+                "ratio_to_no_drop_eager": base["ms_per_step_eager"] / (1e3 * rd_.elapsed / 8),
+                "note": "in-kernel counter-based dropout / DropPath (attention probabilities, GELU epilogues, LayerNorm kernels); the fused "
+                        "stage-0 module / Mlp kernels and the specialised LayerNorm kernels do not carry the stochastic variants"}
         except Exception as e:  # noqa: BLE001
             out.setdefault('companions', {})
             out['companions'] = {**(out['companions'] if isinstance(out['companions'], dict) else {}), "error": f"{type(e).__name__}: {str(e)[:300]}"}
