@@ -772,6 +772,28 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
     for _ in range(warmup):
         step()
     sync()
+    gemm_policy = None
+    if world > 1 and dtype_name == "bf16" and not args.graph:
+        # With CUs reserved for RCCL the sink routes every bf16 Linear to hs_gemm_nt (whose grids honour the reservation), which costs
+        # ~4 % on an idle chip and saves 16 % if the exchange's kernels do stay resident (profiles/r04_cu_contention.json).  Which of the
+        # two this node's exchange looks like is MEASURED here instead of assumed: three steps under each policy (max over ranks), the
+        # faster one runs the timed region.  Every rank takes the same decision (the times are all-reduced).
+        trial = {}
+        for pref in (True, False):
+            ops.RT.prefer_own_gemm = pref
+            step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            sync()
+            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[pref] = float(t.item()) / 3
+        ops.RT.prefer_own_gemm = trial[True] <= trial[False]
+        gemm_policy = {"all_linear_products_on_hs_gemm_nt": bool(ops.RT.prefer_own_gemm),
+                       "trial_ms_per_step": {"own": round(1e3 * trial[True], 3), "per_shape_with_library": round(1e3 * trial[False], 3)},
+                       "note": "decided at run time from 3 + 3 untimed steps under the live exchange"}
     if args.tune_gemm:
         torch.cuda.tunable.tuning_enable(False)  # every shape was met during the warm-up; PyTorch writes the file at exit
     if args.graph:
@@ -834,6 +856,7 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
                 "allreduce_bytes_per_step": nbytes, "allreduce_ms_per_step_standalone_per_rank": [round(v, 3) for v in ms],
                 "allreduce_bus_GBps": 2 * (world - 1) / world * nbytes / (max(ms) * 1e-3) / 1e9,
                 "reserved_cus": int(__import__("heal_swin_amd")._lib.lib.hs_get_reserved_cus()), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "gemm_policy": gemm_policy,
                 "exchange": f"{args.comm_dtype} wire format of fp32 flat buckets, async all-reduce launched from gradient hooks during backward"}
     res = types.SimpleNamespace(elapsed=elapsed, loss=float(loss.item()), timings=timings if rank == 0 else None, rccl=rccl,
                                 params_m=round(sum(p.numel() for p in model.parameters()) / 1e6, 2),

@@ -41,6 +41,10 @@ constexpr int kTileBytes = kWs * kHd * 2;  // 4096: [64][32] bf16, rows of 64 B 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNormEps = 1e-12f;
+// 1 / max(|x|, eps) from the squared norm: v_rsq_f32 (1 ulp) + a clamp instead of the correctly rounded sqrt and division hipcc
+// expands to ~20 instructions each -- four of them per row block were half of what cosine attention added to the kernels' VALU
+// count (profiles/r05_attn_pmc_T256_vs_D256.txt: 66 vs 37 VALU per MFMA in the forward); results are bf16 rows
+__device__ __forceinline__ float inv_norm(float sumsq) { return fminf(__builtin_amdgcn_rsqf(sumsq), 1.f / kNormEps); }
 constexpr float kMaskLog2 = -100.f * kLog2e;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -350,11 +354,11 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 sq += __shfl_xor(sq, 2, 64);
                 sk += __shfl_xor(sk, 1, 64);
                 sk += __shfl_xor(sk, 2, 64);
-                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
+                const float kinv = inv_norm(sk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vk[i] = pack_bf16(bf_lo(vk[i]) * kinv, bf_hi(vk[i]) * kinv);
                 if (scc == 0) {
-                    qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+                    qinv_s[sg * kWs + row] = inv_norm(sq);
                     kinv_s[sg * kWs + row] = kinv;
                 }
             }
@@ -820,10 +824,10 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
                 sq += __shfl_xor(sq, 2, 64);
                 sk += __shfl_xor(sk, 1, 64);
                 sk += __shfl_xor(sk, 2, 64);
-                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
+                const float kinv = inv_norm(sk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vk[i] = pack_bf16(bf_lo(vk[i]) * kinv, bf_hi(vk[i]) * kinv);
-                if (scc == 0) qinv_s[sg * kWs + row] = 1.f / fmaxf(sqrtf(sq), kNormEps);
+                if (scc == 0) qinv_s[sg * kWs + row] = inv_norm(sq);
             }
             const int off = swz(row, scc);
             *(u32x4*)(st + off) = vq;
@@ -908,7 +912,7 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
                     l += e;
                 }
             l += __shfl_xor(l, 32, 64);
-            const float linv = 1.f / l;
+            const float linv = __builtin_amdgcn_rcpf(l);  // (1 ulp; l in [1, 64])
             if constexpr (DROP) {
                 const DropRng rng(p, ((int64_t)b * nH + h) * N + j0 + qq);
 #pragma unroll

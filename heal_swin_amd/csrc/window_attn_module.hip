@@ -53,6 +53,10 @@ constexpr int kWs = 64;
 constexpr int kRowB = 256;  // bytes per LDS tile row (C <= 128 bf16; rows of C = 96 are padded)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNormEps = 1e-12f;
+// 1 / max(|x|, eps) from the squared norm: v_rsq_f32 (1 ulp) + a clamp instead of the correctly rounded sqrt and division hipcc
+// expands to ~20 instructions each -- four of them per row block were half of what cosine attention added to the kernels' VALU
+// count (profiles/r05_attn_pmc_T256_vs_D256.txt: 66 vs 37 VALU per MFMA in the forward); results are bf16 rows
+__device__ __forceinline__ float inv_norm(float sumsq) { return fminf(__builtin_amdgcn_rsqf(sumsq), 1.f / kNormEps); }
 constexpr float kMaskLog2 = -100.f * kLog2e;
 constexpr float kLnEps = 1e-5f;
 __device__ constexpr uint32_t kOob = 0x7FFFFF00u;
@@ -556,8 +560,8 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                 }
                 sq += __shfl_xor(sq, 32, 64);
                 sk += __shfl_xor(sk, 32, 64);
-                qinv[t] = 1.f / fmaxf(sqrtf(sq), kNormEps);
-                const float kinv = 1.f / fmaxf(sqrtf(sk), kNormEps);
+                qinv[t] = inv_norm(sq);
+                const float kinv = inv_norm(sk);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     kw[t][i] = pack_bf16x2(__uint_as_float(kw[t][i] << 16) * kinv, __uint_as_float(kw[t][i] & 0xffff0000u) * kinv);
@@ -632,7 +636,7 @@ __global__ void __launch_bounds__(NH * 64, 1) attn_module_fwd_kernel(ModParams p
                     l += e;
                 }
             l += __shfl_xor(l, 32, 64);
-            const float linv = 1.f / l;
+            const float linv = __builtin_amdgcn_rcpf(l);  // (1 ulp; l in [1, 64])
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
