@@ -1037,8 +1037,11 @@ int pick_head_group_bwd(const AttnParams& p) {
     // 256); on the small ones (HEAL-SWIN-T: stage 2 at nside 256 88 vs 93 us, at nside 128 33 vs 44 us) two workgroups of four
     // waves per CU hide each other's prologue and barriers better
     if (nH % 4 == 0 && (int64_t)p.B * p.N * p.C * 2 >= (64ll << 20)) return 4;
-    // 33 KB of LDS per head; odd head counts (nH = 3 at stage 0 of the T model) run one head per workgroup and let the
-    // neighbouring workgroup's half of each 128-B line come from L2
+    // 33 KB of LDS per head.  Three heads (stage 0 of the T model: 192-byte rows) go together -- whole rows per workgroup instead of
+    // 64-byte slices whose line neighbours come from L2 (PMC: 1.24 x the algorithmic traffic with one head per workgroup,
+    // profiles/r05_attn_pmc_T256_vs_D256.txt): T @ 128 stage 0 122 -> 92 us, T @ 256 462 -> 450 (profiles/r04_attn_hg_T.txt; six
+    // heads stay in pairs: 214 vs 238 us in threes)
+    if (nH == 3) return 3;
     return nH % 2 == 0 ? 2 : 1;
 }
 
