@@ -265,11 +265,17 @@ __device__ __forceinline__ uint4 chunk_pack<float>(const float* v) {
 // y = [residual +] LN(x) or (sum_out = x + add_in, y = LN(sum_out)); no dropout, DropPath scale or compensated stream.  Next
 // rows' chunks requested packed before the current rows are reduced, 32-bit byte offsets from uniform bases, launch sized to
 // one resident round.
-template <typename T, int LPR, int ITERS>
+// EX (round 5): the train-mode extras of the v2 / plain form -- y = [residual +] rs * LN(drop(x)), the paper's drop rates -- on the
+// same kernel (the general kernel carried them at half the rate: 202 vs ~100 us at T @ 256 stage 0).  Same mask as everywhere
+// (ElemRng keyed by the element index), so the general and the specialised kernels are interchangeable per call.
+template <typename T, int LPR, int ITERS, bool EX = false>
 __global__ void __launch_bounds__(256, (ITERS == 1 ? 6 : ITERS == 2 ? 5 : ITERS == 4 ? 3 : 1)) layernorm_fwd_fast_kernel(
     const void* __restrict__ x, const void* __restrict__ add_in, const float* __restrict__ gamma, const float* __restrict__ beta,
     void* __restrict__ y, void* __restrict__ sum_out, float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
-    int width, const void* __restrict__ residual) {
+    int width, const void* __restrict__ residual, const float* __restrict__ row_scale = nullptr, int64_t rows_per_sample = 1,
+    float drop_p = 0.f, uint64_t seed = 0) {
+    const ElemRng rng(drop_p, seed);
+    const bool dropping = EX && drop_p > 0.f;
     // (add_in and residual are exclusive: the second packed stream `pa` carries whichever is given)
     constexpr int RPW = 64 / LPR, VEC = 16 / (int)sizeof(T), ES = (int)sizeof(T);
     constexpr bool PF = ITERS <= 2;
@@ -315,6 +321,13 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 6 : ITERS == 2 ? 5 : ITERS 
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
                 vec_io<T, VEC>::decode(cx[it], v[it]);
+                if constexpr (EX) {
+                    if (dropping) {
+                        const int64_t e0 = row * width + (int64_t)c * VEC;
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) v[it][k] *= rng.mult(e0 + k);
+                    }
+                }
                 if (adding) {  // the stream as every other consumer sees it: rounded to bf16 exactly as a separate add would store it
                     float a2[VEC];
                     vec_io<T, VEC>::decode(ca[it], a2);
@@ -356,6 +369,11 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 6 : ITERS == 2 ? 5 : ITERS 
                 }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = fmaf((v[it][k] - mean) * rstd, g[k], b[k]);
+                if constexpr (EX) {  // DropPath factor of this row's sample
+                    const float rs = row_scale ? row_scale[row / rows_per_sample] : 1.f;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o[k] *= rs;
+                }
                 if (with_res) {  // v2 placement (ref :334-335): y = residual + LN(x), one rounding
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) o[k] += chunk_elem<T>(ca[it], k);
@@ -525,12 +543,16 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
 // 3.2-3.9 TB/s on the 98 304 x 512 rows of stage 2; 162 registers and 1.6-2.0 TB/s at 1024 columns).  Here the chunks of the
 // wave's NEXT rows are requested -- and held packed, 4 registers per 16 bytes -- before the current rows are reduced, and the
 // launch is sized to ONE resident round of workgroups (run_bwd_fast).
-template <typename T, int LPR, int ITERS>
+// EX: the backward of y = rs * LN(drop(x)) (non-v1 form of the general kernel): dy_eff = rs dy, xhat from mask * x, dx = mask * LN_bwd.
+template <typename T, int LPR, int ITERS, bool EX = false>
 __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) layernorm_bwd_fast_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                                  const float* __restrict__ rstd_in, void* __restrict__ dx,
                                                                  float* __restrict__ partials, int64_t rows, int width,
-                                                                 const void* __restrict__ dres_in) {
+                                                                 const void* __restrict__ dres_in, const float* __restrict__ row_scale = nullptr,
+                                                                 int64_t rows_per_sample = 1, float drop_p = 0.f, uint64_t seed = 0) {
+    const ElemRng rng(drop_p, seed);
+    const bool dropping = EX && drop_p > 0.f;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [3 waves][2][width]
     constexpr int RPW = 64 / LPR, VEC = 16 / (int)sizeof(T), ES = (int)sizeof(T);
     constexpr bool PF = ITERS <= 2;  // (wider rows have >= 4 chunks per lane and tensor in flight already)
@@ -596,13 +618,27 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
         // x and dy stay PACKED across the row reductions and are decoded a second time behind them (xhat and dy * gamma in fp32
         // would be 16 registers per chunk over the two shuffle trees: 114 registers, 4 waves per SIMD; this form needs 80: 6)
         float s1 = 0.f, s2 = 0.f;
+        float rs = 1.f;
+        if constexpr (EX) rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
+        uint32_t keep[ITERS];  // EX: the chunk's keep decisions, one bit per element -- the hash (two integer-multiply rounds per element
+                               // pair: the dominant cost of this variant) is evaluated ONCE and reused by the second decode
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
+            keep[it] = 0u;
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
+                const int64_t e0 = row * width + (int64_t)c * VEC;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const float xv = chunk_elem<T>(cx[it], k), dv = chunk_elem<T>(cdy[it], k);
+                    float xv = chunk_elem<T>(cx[it], k), dv = chunk_elem<T>(cdy[it], k);
+                    if constexpr (EX) {
+                        dv *= rs;
+                        if (dropping) {
+                            const float mk = rng.mult(e0 + k);
+                            keep[it] |= (mk != 0.f ? 1u : 0u) << k;
+                            xv *= mk;
+                        }
+                    }
                     const float xh = (xv - mean) * rstd, g = dv * gm[it][k];
                     s1 += g;
                     s2 = fmaf(g, xh, s2);
@@ -624,10 +660,19 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
                 float o[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const float xv = chunk_elem<T>(cx[it], k), dv = chunk_elem<T>(cdy[it], k);
+                    float xv = chunk_elem<T>(cx[it], k), dv = chunk_elem<T>(cdy[it], k);
+                    float mk = 1.f;
+                    if constexpr (EX) {
+                        dv *= rs;
+                        if (dropping) {
+                            mk = ((keep[it] >> k) & 1u) ? rng.keep_scale : 0.f;
+                            xv *= mk;
+                        }
+                    }
                     const float xh = (xv - mean) * rstd, g = dv * gm[it][k];
                     o[k] = rstd * (g - m1 - xh * m2);
                     if (has_res) o[k] += chunk_elem<T>(cd2[it], k);
+                    if constexpr (EX) o[k] *= mk;
                 }
                 const uint32_t e = ((uint32_t)row * (uint32_t)width + (uint32_t)(c * VEC)) * (uint32_t)ES;
                 *(uint4*)((char*)dx + e) = chunk_pack<T>(o);
@@ -767,10 +812,10 @@ int run_bwd(const void* dy, const void* x, const float* g, const float* mean, co
     return HS_OK;
 }
 
-template <typename T, int LPR, int ITERS>
+template <typename T, int LPR, int ITERS, bool EX = false>
 int run_fwd_fast(const void* x, const void* add_in, const float* g, const float* b, void* y, void* sum_out, float* mean, float* rstd,
-                 int64_t rows, int width, hipStream_t s, const void* residual) {
-    auto kern = layernorm_fwd_fast_kernel<T, LPR, ITERS>;
+                 int64_t rows, int width, hipStream_t s, const void* residual, const LnExtra& ex = LnExtra{}) {
+    auto kern = layernorm_fwd_fast_kernel<T, LPR, ITERS, EX>;
     static int resident = 0;
     if (resident == 0) {
         int n = 0;
@@ -781,7 +826,8 @@ int run_fwd_fast(const void* x, const void* add_in, const float* g, const float*
     int64_t blocks = (int64_t)usable_cus() * resident;
     const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
     if (blocks > by_rows) blocks = by_rows;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, x, add_in, g, b, y, sum_out, mean, rstd, rows, width, residual);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, x, add_in, g, b, y, sum_out, mean, rstd, rows, width, residual,
+                       ex.row_scale, ex.rows_per_sample, ex.drop_p, ex.seed);
     HS_LAUNCH_CHECK("layernorm_fwd_fast");
     return HS_OK;
 }
@@ -789,10 +835,11 @@ int run_fwd_fast(const void* x, const void* add_in, const float* g, const float*
 // One resident round: as many workgroups as the chip holds at this instantiation's register / LDS footprint (every workgroup
 // then sees the same number of rows and there is no second, partly filled round), at most kBwdMaxBlocks partial rows, at
 // least one row group per wave.
-template <typename T, int LPR, int ITERS>
+template <typename T, int LPR, int ITERS, bool EX = false>
 int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx, float* dgamma,
-                 float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in, int accumulate) {
-    auto kern = layernorm_bwd_fast_kernel<T, LPR, ITERS>;
+                 float* dbeta, float* ws, int64_t rows, int width, hipStream_t s, const void* dres_in, int accumulate,
+                 const LnExtra& ex = LnExtra{}) {
+    auto kern = layernorm_bwd_fast_kernel<T, LPR, ITERS, EX>;
     const size_t smem = (size_t)3 * 2 * width * sizeof(float);
     if (smem > 48 * 1024) HS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     static int resident_width = 0, resident = 0;  // per instantiation; the LDS footprint follows the width
@@ -807,7 +854,8 @@ int run_bwd_fast(const void* dy, const void* x, const float* g, const float* mea
     if (blocks > kBwdMaxBlocks) blocks = kBwdMaxBlocks;
     const int64_t by_rows = (rows + rows_per_pass - 1) / rows_per_pass;
     if (blocks > by_rows) blocks = by_rows;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, dy, x, g, mean, rstd, dx, ws, rows, width, dres_in, ex.row_scale,
+                       ex.rows_per_sample, ex.drop_p, ex.seed);
     HS_LAUNCH_CHECK("layernorm_bwd_fast");
     if ((accumulate & HS_ACC_DEFER) && width % 4 == 0)
         return reduce_defer(ws, 2 * width, (int)blocks, width, 2 * width, dgamma, dbeta, accumulate & 1, s);
@@ -860,6 +908,10 @@ int ln_fwd_impl(const void* x, const void* residual, const float* gamma, const f
     if (rows == 0) return HS_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool plain = !(residual && add_in) && !ex.row_scale && ex.drop_p == 0.f && !ex.lo_in && !ex.lo_out;
+    // the v2 / plain form with dropout and / or a DropPath factor (y = [residual +] rs LN(drop(x))): the specialised kernel's EX variant
+    const bool extras = !add_in && (ex.row_scale || ex.drop_p > 0.f) && !ex.lo_in && !ex.lo_out;
+    if (dtype == HS_BF16 && extras && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32))
+        return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value, true>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s, residual, ex); });
     if (dtype == HS_BF16) {
         if (plain && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32))
             return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_fwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value>(x, add_in, gamma, beta, y, sum_out, mean, rstd, rows, width, s, residual); });
@@ -884,6 +936,8 @@ int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* 
     if (int st = check_extra(ex, rows)) return st;
     hipStream_t s = (hipStream_t)stream;
     const bool plain = !ex.row_scale && ex.drop_p == 0.f && !dadd_out;
+    if (dtype == HS_BF16 && !plain && !v1_mode && !dadd_out && !dres_in && width % 8 == 0 && width <= 4096 && rows * width * 2 < (1ll << 32))
+        return with_shape<bf16_t, 8>(width, [&](auto lpr, auto it) { return run_bwd_fast<bf16_t, decltype(lpr)::value, decltype(it)::value, true>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, accumulate, ex); });
     if (dtype == HS_F32 && plain && width % 4 == 0 && width <= 2048 && rows * width * 4 < (1ll << 32))
         return with_shape<float, 4>(width, [&](auto lpr, auto it) { return run_bwd_fast<float, decltype(lpr)::value, decltype(it)::value>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, width, s, dres_in, accumulate); });
     if (dtype == HS_BF16) {
