@@ -138,8 +138,10 @@ __global__ void __launch_bounds__(256) gelu_split3_kernel(const float* __restric
             for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
         }
         if (DROP) {
+            float mk[4];
+            rng.mult4(e, mk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= rng.mult(e + j);
+            for (int j = 0; j < 4; ++j) v[j] *= mk[j];
         }
         const uint32_t h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
         const uint2 hi = make_uint2(h0, h1);

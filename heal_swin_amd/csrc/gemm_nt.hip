@@ -450,13 +450,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                         f32x16& a16 = acc[TJ * jh + j][i];
                         f32x2 v[2] = {f32x2{a16[4 * g], a16[4 * g + 1]} + f32x2{bias4[j][g].x, bias4[j][g].y},
                                       f32x2{a16[4 * g + 2], a16[4 * g + 3]} + f32x2{bias4[j][g].z, bias4[j][g].w}};
-                        const int64_t e0 = (m0 + ml) * p.n + n;  // element index of v[0].x in the [m, n] tensor (dropout counter)
+                        float mk[4];  // dropout multipliers of the lane's four consecutive elements (half a chunk of the generator)
+                        if (DROP) rng.mult4((m0 + ml) * p.n + n, mk);
                         if (EPI == EPI_GELU) {
                             o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
 #pragma unroll
                             for (int t = 0; t < 2; ++t) {
                                 v[t] = gelu2(v[t]);
-                                if (DROP) v[t] *= f32x2{rng.mult(e0 + 2 * t), rng.mult(e0 + 2 * t + 1)};
+                                if (DROP) v[t] *= f32x2{mk[2 * t], mk[2 * t + 1]};
                             }
                             o2[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
                         } else {
@@ -466,7 +467,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                                     const f32x2 x = {__uint_as_float(xin[j][g][t] << 16), __uint_as_float(xin[j][g][t] & 0xffff0000u)};
                                     if (EPI == EPI_DGELU) {
                                         v[t] *= gelu_grad2(x);
-                                        if (DROP) v[t] *= f32x2{rng.mult(e0 + 2 * t), rng.mult(e0 + 2 * t + 1)};
+                                        if (DROP) v[t] *= f32x2{mk[2 * t], mk[2 * t + 1]};
                                     } else {
                                         v[t] += x;
                                     }

@@ -55,16 +55,71 @@ struct ElemRng {
         thresh16 = p >= 1.f ? 65536u : (uint32_t)(p * 65536.f);  // drop probability in steps of 2^-16
         keep_scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
     }
-    // multiplier of element i: 0 (dropped) or 1/(1-p).  One hash serves the element pair (2j, 2j+1), 16 bits each: the kernels
-    // process 4 or 8 consecutive elements per lane, so half of the hashes are shared.
+    // The mask of element i (16 random bits, dropped when they are below thresh16) is defined in two levels, so that the integer
+    // multiplies -- quarter rate on the VALU, and what a stochastic kernel's time goes into -- are shared by 8 elements:
+    //   chunk c = i >> 3 : key ck(c) = two full finaliser rounds over the chunk number, one key word entering BETWEEN them (masks of
+    //                      different seeds are related by a pseudo-random index map, not by an index (XOR-)translation);
+    //   pair p = (i >> 1) & 3 of the chunk: u = ck * M_p (four fixed odd multipliers: (u_p, u_q) is the lattice of an LCG with
+    //                      multiplier M_q / M_p, uniform in both coordinates), element 2j takes lo16(u) ^ hi16(u), 2j + 1 hi16(u).
+    // 1.5 multiplies per element instead of 4.  mult(i) is the definition; mult8 / mult4 are what kernels with aligned element
+    // runs call (same bits).
+    static constexpr uint32_t kM0 = 0x9E3779B1u, kM1 = 0x85EBCA6Bu, kM2 = 0xC2B2AE35u, kM3 = 0x27D4EB2Fu;
+    __device__ __forceinline__ uint32_t chunk_key(uint64_t c) const {
+        return mix32(mix32((uint32_t)c ^ key_hi ^ ((uint32_t)(c >> 32) * 0x9E3779B9u)) ^ key_lo);
+    }
+    static __device__ __forceinline__ uint32_t pair_bits(uint32_t ck, uint32_t m) {
+        const uint32_t u = ck * m;
+        return u ^ (u >> 16);
+    }
+    __device__ __forceinline__ float keep_lo(uint32_t h) const { return (h & 0xffffu) >= thresh16 ? keep_scale : 0.f; }
+    __device__ __forceinline__ float keep_hi(uint32_t h) const { return (h >> 16) >= thresh16 ? keep_scale : 0.f; }
+    // multiplier of element i: 0 (dropped) or 1/(1-p)
     __device__ __forceinline__ float mult(int64_t i) const {
-        const uint64_t j = (uint64_t)i >> 1;
-        // keyed, two full rounds with one key word entering BETWEEN them: masks of different seeds are then related by a
-        // pseudo-random index map, not by an index translation (j + key) or XOR-translation (j ^ key) as with a single
-        // keyed round
-        const uint32_t h = mix32(mix32((uint32_t)j ^ key_hi ^ ((uint32_t)(j >> 32) * 0x9E3779B9u)) ^ key_lo);
-        const uint32_t bits = (i & 1) ? (h >> 16) : (h & 0xffffu);
-        return bits >= thresh16 ? keep_scale : 0.f;
+        const uint32_t ck = chunk_key((uint64_t)i >> 3);
+        const uint32_t pr = ((uint32_t)i >> 1) & 3u;
+        const uint32_t h = pair_bits(ck, pr == 0 ? kM0 : pr == 1 ? kM1 : pr == 2 ? kM2 : kM3);
+        return (i & 1) ? keep_hi(h) : keep_lo(h);
+    }
+    // elements 8 c ... 8 c + 7
+    __device__ __forceinline__ void mult8(uint64_t c, float (&out)[8]) const {
+        const uint32_t ck = chunk_key(c);
+        const uint32_t h0 = pair_bits(ck, kM0), h1 = pair_bits(ck, kM1), h2 = pair_bits(ck, kM2), h3 = pair_bits(ck, kM3);
+        out[0] = keep_lo(h0), out[1] = keep_hi(h0), out[2] = keep_lo(h1), out[3] = keep_hi(h1);
+        out[4] = keep_lo(h2), out[5] = keep_hi(h2), out[6] = keep_lo(h3), out[7] = keep_hi(h3);
+    }
+    // In-order form for an aligned run of V elements starting at e0 (a multiple of V): ck = run_key<V>(e0) once, then
+    // run_mult<V>(e0, k, ck, h) for k = 0 ... V - 1 in order inside the kernel's own unrolled element loop (k folds to a constant; h
+    // carries a pair's bits from its even to its odd element) -- two live registers instead of V multipliers.
+    template <int V>
+    __device__ __forceinline__ uint32_t run_key(int64_t e0) const {
+        return (V == 8 || V == 4) ? chunk_key((uint64_t)e0 >> 3) : 0u;
+    }
+    template <int V>
+    __device__ __forceinline__ float run_mult(int64_t e0, int k, uint32_t ck, uint32_t& h) const {
+        if constexpr (V == 8 || V == 4) {
+            if ((k & 1) == 0) {
+                const int pr = k >> 1;
+                uint32_t m;
+                if constexpr (V == 8) {
+                    m = pr == 0 ? kM0 : pr == 1 ? kM1 : pr == 2 ? kM2 : kM3;
+                } else {
+                    const bool second = ((uint32_t)e0 >> 2) & 1u;
+                    m = pr == 0 ? (second ? kM2 : kM0) : (second ? kM3 : kM1);
+                }
+                h = pair_bits(ck, m);
+                return keep_lo(h);
+            }
+            return keep_hi(h);
+        } else {
+            return mult(e0 + k);
+        }
+    }
+    // elements i0 ... i0 + 3, i0 a multiple of 4 (the first or the second half of a chunk)
+    __device__ __forceinline__ void mult4(int64_t i0, float (&out)[4]) const {
+        const uint32_t ck = chunk_key((uint64_t)i0 >> 3);
+        const bool second = ((uint32_t)i0 >> 2) & 1u;
+        const uint32_t ha = pair_bits(ck, second ? kM2 : kM0), hb = pair_bits(ck, second ? kM3 : kM1);
+        out[0] = keep_lo(ha), out[1] = keep_hi(ha), out[2] = keep_lo(hb), out[3] = keep_hi(hb);
     }
 };
 

@@ -159,10 +159,13 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                     if constexpr (PF) vec_io<T, VEC>::decode(ca[it], a2);
                     else vec_io<T, VEC>::load(add_in, base + (int64_t)c * VEC, a2);
                     if (lo_in) vec_io<T, VEC>::load(lo_in, base + (int64_t)c * VEC, l2);
+                    const int64_t e0 = base + (int64_t)c * VEC;
+                    uint32_t hp = 0;
+                    const uint32_t ck = dropping ? rng.template run_key<VEC>(e0) : 0u;
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         float add = a2[k] * rs;
-                        if (dropping) add *= rng.mult(base + (int64_t)c * VEC + k);
+                        if (dropping) add *= rng.template run_mult<VEC>(e0, k, ck, hp);
                         const float full = v[it][k] + (lo_in ? l2[k] : 0.f) + add;
                         hi[k] = round_to<T>(full);  // the stream as every other consumer sees it
                         l2[k] = full - hi[k];
@@ -173,8 +176,11 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                     store_stream<T, VEC>(sum_out, base + (int64_t)c * VEC, hi);
                     if (lo_out) vec_io<T, VEC>::store(lo_out, base + (int64_t)c * VEC, l2);
                 } else if (dropping) {
+                    const int64_t e0 = base + (int64_t)c * VEC;
+                    uint32_t hp = 0;
+                    const uint32_t ck = rng.template run_key<VEC>(e0);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) v[it][k] *= rng.mult(base + (int64_t)c * VEC + k);
+                    for (int k = 0; k < VEC; ++k) v[it][k] *= rng.template run_mult<VEC>(e0, k, ck, hp);
                 }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) sum += v[it][k];
@@ -324,8 +330,10 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 6 : ITERS == 2 ? 5 : ITERS 
                 if constexpr (EX) {
                     if (dropping) {
                         const int64_t e0 = row * width + (int64_t)c * VEC;
+                        uint32_t hp = 0;
+                        const uint32_t ck = rng.template run_key<VEC>(e0);
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) v[it][k] *= rng.mult(e0 + k);
+                        for (int k = 0; k < VEC; ++k) v[it][k] *= rng.template run_mult<VEC>(e0, k, ck, hp);
                     }
                 }
                 if (adding) {  // the stream as every other consumer sees it: rounded to bf16 exactly as a separate add would store it
@@ -444,11 +452,14 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
                 // two loads per lane are in flight already, 4.7-5.1 TB/s)
                 vec_io<T, VEC>::load(x, base + (int64_t)c * VEC, xh[it]);
                 vec_io<T, VEC>::load(dy, base + (int64_t)c * VEC, dyv);
+                const int64_t e0 = base + (int64_t)c * VEC;
+                uint32_t hp = 0;
+                const uint32_t ck = (!v1_mode && dropping) ? rng.template run_key<VEC>(e0) : 0u;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     if (!v1_mode) {
                         dyv[k] *= rs;
-                        if (dropping) xh[it][k] *= rng.mult(base + (int64_t)c * VEC + k);
+                        if (dropping) xh[it][k] *= rng.template run_mult<VEC>(e0, k, ck, hp);
                     }
                     xh[it][k] = (xh[it][k] - mean) * rstd;
                     g[it][k] = dyv[k] * gm[it][k];
@@ -475,17 +486,23 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
                     vec_io<T, VEC>::store(dx, base + (int64_t)c * VEC, o);
                     if (dadd_out) {  // gradient of the added operand: through DropPath scale and dropout mask
                         float o2[VEC];
+                        const int64_t e0 = base + (int64_t)c * VEC;
+                        uint32_t hp = 0;
+                        const uint32_t ck = dropping ? rng.template run_key<VEC>(e0) : 0u;
 #pragma unroll
                         for (int k = 0; k < VEC; ++k) {
                             o2[k] = o[k] * rs;
-                            if (dropping) o2[k] *= rng.mult(base + (int64_t)c * VEC + k);
+                            if (dropping) o2[k] *= rng.template run_mult<VEC>(e0, k, ck, hp);
                         }
                         vec_io<T, VEC>::store(dadd_out, base + (int64_t)c * VEC, o2);
                     }
                 } else {
                     if (dropping) {
+                        const int64_t e0 = base + (int64_t)c * VEC;
+                        uint32_t hp = 0;
+                        const uint32_t ck = rng.template run_key<VEC>(e0);
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) o[k] *= rng.mult(base + (int64_t)c * VEC + k);
+                        for (int k = 0; k < VEC; ++k) o[k] *= rng.template run_mult<VEC>(e0, k, ck, hp);
                     }
                     vec_io<T, VEC>::store(dx, base + (int64_t)c * VEC, o);
                 }
@@ -545,7 +562,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
 // launch is sized to ONE resident round of workgroups (run_bwd_fast).
 // EX: the backward of y = rs * LN(drop(x)) (non-v1 form of the general kernel): dy_eff = rs dy, xhat from mask * x, dx = mask * LN_bwd.
 template <typename T, int LPR, int ITERS, bool EX = false>
-__global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) layernorm_bwd_fast_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+__global__ void __launch_bounds__(256, (ITERS == 1 ? (EX ? 4 : 5) : ITERS == 2 ? 3 : 1)) layernorm_bwd_fast_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                                  const float* __restrict__ rstd_in, void* __restrict__ dx,
                                                                  float* __restrict__ partials, int64_t rows, int width,
@@ -628,13 +645,17 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 5 : ITERS == 2 ? 3 : 1)) la
             const int c = sub + LPR * it;
             if (live && c < nchunk) {
                 const int64_t e0 = row * width + (int64_t)c * VEC;
+                uint32_t hp = 0, ck = 0;
+                if constexpr (EX) {
+                    if (dropping) ck = rng.template run_key<VEC>(e0);
+                }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float xv = chunk_elem<T>(cx[it], k), dv = chunk_elem<T>(cdy[it], k);
                     if constexpr (EX) {
                         dv *= rs;
                         if (dropping) {
-                            const float mk = rng.mult(e0 + k);
+                            const float mk = rng.template run_mult<VEC>(e0, k, ck, hp);
                             keep[it] |= (mk != 0.f ? 1u : 0u) << k;
                             xv *= mk;
                         }

@@ -365,8 +365,8 @@ class SwinTransformerBlock(nn.Module):
             # HBM-bound shapes of stages 0-1); the norm behind it is then a plain LayerNorm whose second output is an alias of its
             # input (the alias' gradient is added inside the LayerNorm backward kernel).  Elsewhere the add stays in the norm kernel.
             C = self.dim
-            proj_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, C, x.dtype)
-            fc2_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, self.mlp.fc1.weight.shape[0], x.dtype)
+            proj_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, C, x.dtype, m=x.numel() // C)
+            fc2_own = ops.own_gemm_ok(_lib.HS_EPI_BIAS, C, self.mlp.fc1.weight.shape[0], x.dtype, m=x.numel() // C)
             if pending is None and self.attn.trainable_fused(x, self.window_size):
                 # norm1 -> qkv -> attention -> proj -> residual add in ONE launch that also writes what the backward reads
                 idx, roll, labels = self._shift_args(x)

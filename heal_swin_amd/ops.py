@@ -862,10 +862,15 @@ OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice bel
 # Costs ~3 ms per step on an idle chip (HS_OWN_GEMM=1 measurement of round 3), saves ~27 ms under contention (r04_cu_contention.json).
 OWN_GELU_MAX_K = 4096
 OWN_DGELU_MAX_K = 1024
+# (n, k) -> bool: measured exceptions to the class rule of own_gemm_ok for the bias / residual products, in situ against the TunableOp
+# picks (profiles/r05_gemm_shape_table_ab.txt, us per launch lib -> own): T stage-1 qkv 146 -> 122, T stage-2 qkv 103 -> 76, T stage-2
+# proj 39 / 43 -> 33, B stage-1 qkv 259 -> 217.  The long reductions of the same stages stay with the library (T fc2 141 vs 160, 101 vs 113).
+OWN_SHAPE_TABLE = {(576, 192): True, (1152, 384): True, (384, 384): True, (768, 256): True}
+OWN_SHAPE_TABLE_MIN_M = 49152  # measured at m = 65536 ... 393216 rows only
 OWN_BIAS_MAX_K = 0  # (> 0 would send every bias / residual product with k <= this to hs_gemm_nt: measured, slower -- profiles/r03_gemm_policy_ab.txt)
 
 
-def own_gemm_ok(epi, n, k, dtype, k2=0):
+def own_gemm_ok(epi, n, k, dtype, k2=0, m=None):
     """Whether `hs_gemm_nt` should run this product (else the library GEMM + the standalone elementwise kernel).
     Measured on MI355X against hipBLASLt on the B / nside 256 / batch 8 shapes (tools/bench_gemm_nt.py,
     profiles/r02_gemm_nt_vs_library.*): the own kernel wins where the product is HBM-bound (short reductions, narrow outputs:
@@ -885,6 +890,10 @@ def own_gemm_ok(epi, n, k, dtype, k2=0):
         return kk <= OWN_GELU_MAX_K
     if OWN_BIAS_MAX_K > 0:
         return kk <= OWN_BIAS_MAX_K
+    if m is None or m >= OWN_SHAPE_TABLE_MIN_M:
+        pick = OWN_SHAPE_TABLE.get((n, kk))
+        if pick is not None:
+            return pick
     return kk <= 128 or n <= 128 or (n <= 256 and kk <= 256)
 
 
@@ -1177,7 +1186,7 @@ class LinearFn(torch.autograd.Function):
             else:
                 y = _lib_linear(x, w, None if bias is None else _cast_param(bias, x.dtype)) + residual
                 ctx.x3 = _split_of(x.reshape(-1, k_in)) if x.is_contiguous() else None
-        elif own_gemm_ok(_lib.HS_EPI_BIAS, n_out, k_in, x.dtype) and x.is_contiguous():
+        elif own_gemm_ok(_lib.HS_EPI_BIAS, n_out, k_in, x.dtype, m=x.numel() // k_in) and x.is_contiguous():
             y = gemm_nt(x.reshape(-1, k_in), w, bias)[0].view(x.shape[:-1] + (n_out,))  # fp32 master bias added in the epilogue
         else:
             y = _lib_linear(x, w, None if bias is None else _cast_param(bias, x.dtype))
@@ -1265,7 +1274,7 @@ def _input_grad(dy2, weight, w_cast, dx_res2=None, cache=None):
     # with a residual-path gradient to add (v2 placement), the library form is torch.addmm(res, dy, W): a device-to-device copy of
     # `res` into the result and THEN the product with beta = 1 -- a whole extra pass (36 copies, ~1 ms per HEAL-SWIN-T @ 256 step);
     # hs_gemm_nt reads the addend in its epilogue instead
-    if own_gemm_ok(epi, k_in, n_out, dy2.dtype) or (dx_res2 is not None and RESID_DGRAD_OWN and own_gemm_legal(k_in, n_out, dy2.dtype)):
+    if own_gemm_ok(epi, k_in, n_out, dy2.dtype, m=dy2.shape[0]) or (dx_res2 is not None and RESID_DGRAD_OWN and own_gemm_legal(k_in, n_out, dy2.dtype)):
         res = None if dx_res2 is None else dx_res2.to(dy2.dtype).contiguous()
         return gemm_nt(dy2, _cast_param_t(weight, dy2.dtype, cache), None, epi, aux=res)[0]
     w = w_cast if (w_cast is not None and w_cast.dtype == dy2.dtype) else (

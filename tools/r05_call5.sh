@@ -1,18 +1,24 @@
 #!/bin/bash
-set -u
-cd "$GRAFT_REPO_ROOT"
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/r05_c5_tests.log
-Q="--no-cpu-baseline --no-fp32-companion --no-pmc-traffic --no-graph-companion"
-timeout 600 python bench.py --steps 20 --warmup 5 $Q > gpurun_out/r05_c5_bench_fused.json 2> gpurun_out/r05_c5_bench_fused.err
-HS_FUSED_MLP=0 timeout 600 python bench.py --steps 20 --warmup 5 $Q > gpurun_out/r05_c5_bench_nofused.json 2> gpurun_out/r05_c5_bench_nofused.err
-timeout 600 python bench.py --steps 20 --warmup 5 $Q --no-companions > gpurun_out/r05_c5_bench_fused2.json 2> /dev/null
-tail -4 gpurun_out/r05_c5_tests.log
-for f in fused nofused fused2; do python - <<PY
+# per-shape policy A/B for the stage-1 / stage-2 bias products (T256 and B256)
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/r05_call5; mkdir -p $O
+X="--steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --kernel-table"
+B="--workload T256 $X"
+python bench.py $B > $O/t256_base.json 2> $O/t256_base.err
+python tools/policy_ab.py "OWN_SHAPE_TABLE={(192,768):True,(192,576):True,(576,192):True,(768,192):True}" -- $B > $O/t256_s1own.json 2> $O/t256_s1own.err
+python tools/policy_ab.py "OWN_SHAPE_TABLE={(384,1536):True,(384,1152):True,(1152,384):True,(384,384):True}" -- $B > $O/t256_s2own.json 2> $O/t256_s2own.err
+python bench.py $B > $O/t256_base2.json 2> $O/t256_base2.err
+B="--workload B256 $X"
+python bench.py $B > $O/b256_base.json 2> $O/b256_base.err
+python tools/policy_ab.py "OWN_SHAPE_TABLE={(768,256):True,(256,768):True,(256,1024):True}" -- $B > $O/b256_s1own.json 2> $O/b256_s1own.err
+python bench.py $B > $O/b256_base2.json 2> $O/b256_base2.err
+for f in t256_base t256_s1own t256_s2own t256_base2 b256_base b256_s1own b256_base2; do python - <<PY
 import json
 try:
-    d=json.loads(open("gpurun_out/r05_c5_bench_$f.json").read().strip().splitlines()[-1])
-    c=d.get("companions",{})
-    print("$f", round(d["ms_per_step"],2), d["config"].get("peak_device_memory_GB"), {k:(round(v["value"],1), round(v["ms_per_step_eager"],2), round(v["ms_per_step_graph"],2)) for k,v in c.items() if isinstance(v,dict) and "value" in v})
-except Exception as e: print("$f", "ERR", e)
+    d=json.loads(open("$O/$f.json").read().strip().splitlines()[-1])
+    print("$f", d["ms_per_step"], d["value"])
+except Exception as e:
+    print("$f", "failed", e)
 PY
-done
+done > $O/summary.txt
+cat $O/summary.txt

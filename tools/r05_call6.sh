@@ -1,13 +1,19 @@
 #!/bin/bash
-set -u
-cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_mlp_fused.py tests/test_gpu_training.py tests/test_gpu_model.py tests/test_gpu_baseline_configs.py -q 2>&1 | grep -E "^E  .*AssertionError|passed|failed|^FAILED" | cut -c1-220 > gpurun_out/r05_c6_tests.log 2>&1
-cat gpurun_out/r05_c6_tests.log | head -30
-timeout 600 python tools/bench_mlp_fused.py 2>/dev/null | tee gpurun_out/r05_c6_mlp_bench.txt
-Q="--no-cpu-baseline --no-fp32-companion --no-pmc-traffic --no-graph-companion --no-companions"
-for W in T256; do
-for F in 1 0; do
-HS_FUSED_MLP=$F timeout 300 python bench.py --workload $W --steps 20 --warmup 5 $Q --graph 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$W fused=$F graph', round(d['ms_per_step'],2), round(d['value'],1))"
-done; done
+# chunk-keyed dropout generator: tests, then the paper-drop line against the no-drop line
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/r05_call6; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gemm.py tests/test_gpu_hygiene.py -x -q -m gpu > $O/tests.txt 2>&1
+tail -3 $O/tests.txt
+X="--workload T256 --steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --kernel-table"
+python bench.py $X > $O/t256_nodrop.json 2> $O/t256_nodrop.err
+python bench.py $X --paper-drop-rates > $O/t256_drop.json 2> $O/t256_drop.err
+for f in t256_nodrop t256_drop; do python - <<PY
+import json
+try:
+    d=json.loads(open("$O/$f.json").read().strip().splitlines()[-1])
+    print("$f", d["ms_per_step"], d["value"])
+except Exception as e:
+    print("$f", "failed", e)
+PY
+done > $O/summary.txt
+cat $O/summary.txt
