@@ -68,6 +68,9 @@ _SIGNATURES = {
     "hs_mlp_fused_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_uint,
                          c_int, c_ptr],
     "hs_mlp_fused_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
+    "hs_mlp_fused_drop_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_float,
+                              ctypes.c_uint64, ctypes.c_uint64, c_i64, c_int, c_int, c_uint, c_int, c_ptr],
+    "hs_mlp_fused_drop_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_float, ctypes.c_uint64, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_adam_step": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_float, c_ptr, c_float, c_float, c_float, c_float, c_int, c_ptr, c_ptr],
     "hs_adam_advance": [c_ptr, c_ptr],
     "hs_split_bf16x3": [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr],

@@ -450,14 +450,20 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                         f32x16& a16 = acc[TJ * jh + j][i];
                         f32x2 v[2] = {f32x2{a16[4 * g], a16[4 * g + 1]} + f32x2{bias4[j][g].x, bias4[j][g].y},
                                       f32x2{a16[4 * g + 2], a16[4 * g + 3]} + f32x2{bias4[j][g].z, bias4[j][g].w}};
-                        float mk[4];  // dropout multipliers of the lane's four consecutive elements (half a chunk of the generator)
-                        if (DROP) rng.mult4((m0 + ml) * p.n + n, mk);
+                        // dropout: the lane's four consecutive elements are the first (half = 0) or second half of a chunk of the
+                        // generator (hs_device.h): one chunk key, one multiply per element pair, formed where the pair is used
+                        uint32_t ck = 0;
+                        if (DROP) ck = rng.chunk_key((uint64_t)((m0 + ml) * p.n + n) >> 3);
+                        auto drop2 = [&](int t) {
+                            const uint32_t hh = ElemRng::pair_bits(ck, t == 0 ? (half ? ElemRng::kM2 : ElemRng::kM0) : (half ? ElemRng::kM3 : ElemRng::kM1));
+                            return f32x2{rng.keep_lo(hh), rng.keep_hi(hh)};
+                        };
                         if (EPI == EPI_GELU) {
                             o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
 #pragma unroll
                             for (int t = 0; t < 2; ++t) {
                                 v[t] = gelu2(v[t]);
-                                if (DROP) v[t] *= f32x2{mk[2 * t], mk[2 * t + 1]};
+                                if (DROP) v[t] *= drop2(t);
                             }
                             o2[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
                         } else {
@@ -467,7 +473,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                                     const f32x2 x = {__uint_as_float(xin[j][g][t] << 16), __uint_as_float(xin[j][g][t] & 0xffff0000u)};
                                     if (EPI == EPI_DGELU) {
                                         v[t] *= gelu_grad2(x);
-                                        if (DROP) v[t] *= f32x2{mk[2 * t], mk[2 * t + 1]};
+                                        if (DROP) v[t] *= drop2(t);
                                     } else {
                                         v[t] += x;
                                     }

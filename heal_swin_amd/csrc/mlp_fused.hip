@@ -67,6 +67,15 @@ struct MlpParams {
     int ln_after;         // forward: ln_g / ln_b apply to the product-2 rows (no LayerNorm in front)
     uint16_t* m_out;      // forward, ln_after: the un-normalised rows mlp(x) [M, C] (input of the LayerNorm backward; null: not kept)
     const uint16_t* res_in;  // backward: rows [M, C] added to dn (the residual path's gradient), or null
+    // train-mode regularisers of the branch (DROP instantiations; v2 placement only): Mlp.drop after the activation and after fc2
+    // (reference :41, :43; counter-based masks of hs_device.h keyed by the element index in the [M_total, 4C] / [M_total, C] tensor,
+    // i.e. the masks hs_gemm_nt's GELU epilogue and hs_layernorm_drop_* generate for the same seeds) and DropPath (:335) as the
+    // per-sample factor row_scale[row / rows_per_sample]
+    float drop_p;
+    uint64_t seed_h, seed_o;
+    const float* row_scale;    // [M_total / rows_per_sample] or null
+    int tiles_per_sample;      // rows_per_sample / 32
+    int64_t row0;              // first row of this launch in the whole tensor (mask counters, sample index)
 };
 
 __device__ __forceinline__ u32x4 ld128(uint32_t addr) {
@@ -119,7 +128,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int C, bool BWD>
+template <int C, bool BWD, bool DROP>
 __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int H = 4 * C, NW = C / 16, KS1 = C / 16, KS2 = H / 32, NCH = C / 8, HCH = H / 8;
@@ -141,6 +150,8 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
     const bool ln_post = !BWD && p.ln_g != nullptr && p.ln_after;
     const bool keep_raw = !BWD && p.residual;
     const bool add_res = BWD && p.res_in != nullptr;
+    const ElemRng rng_h(DROP ? p.drop_p : 0.f, p.seed_h), rng_o(DROP ? p.drop_p : 0.f, p.seed_o);
+    const bool dropping = DROP && p.drop_p > 0.f;
 
     // tile offsets: [token][16-byte chunk] with the chunk index xor-ed by (row & 15) inside its aligned group of 16
     auto aoff = [](int row, int chunk) { return (uint32_t)(row * APITCH + ((chunk ^ (row & 15)) << 4)); };
@@ -241,8 +252,18 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
                     for (int e = 0; e < 4; ++e) {
                         f[2 * e] = valid ? lo_f(mw[e]) : 0.f;
                         f[2 * e + 1] = valid ? hi_f(mw[e]) : 0.f;
-                        s1 += f[2 * e] + f[2 * e + 1];
                     }
+                    if constexpr (DROP) {  // Mlp.drop behind fc2: y = x + rs * LN(drop(m)), as hs_layernorm_drop_fwd
+                        if (dropping) {
+                            const int64_t e0 = ((p.row0 + grow) * C) + lcc * 8;
+                            uint32_t hp = 0;
+                            const uint32_t ck = rng_o.template run_key<8>(e0);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] *= rng_o.template run_mult<8>(e0, e, ck, hp);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s1 += f[e];
                     const float mean = row16_sum(s1) * (1.f / C);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -258,6 +279,13 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
                     if ((lane_o & 15) == 0 && p.mean_out) {
                         p.mean_out[grow] = mean;
                         p.rstd_out[grow] = rstd;
+                    }
+                    if constexpr (DROP) {
+                        if (p.row_scale) {  // DropPath: one factor per sample; a tile never straddles two samples
+                            const float rs = p.row_scale[(uint32_t)((p.row0 >> 5) + tp) / (uint32_t)p.tiles_per_sample];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] *= rs;
+                        }
                     }
                 }
                 if (keep_raw || add_res) {
@@ -396,6 +424,8 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
         // register group; the tile is free since barrier A -- so only gelu(h) stays in registers (16) across the step.
         u32x2v hw[2][4];  // backward: the saved h of this lane's 32 accumulator positions
         const uint32_t h2base = lds0 + HB_OFF;  // forward: h goes to a tile of its own, gelu(h) to the tile product 2 reads
+        // (DROP) generator chunk (8 elements) of this lane's token in the [M_total, 4C] tensor, at the wave's first hidden unit
+        const uint64_t cbase = DROP ? (uint64_t)(p.row0 + ti * kT + l31) * (uint64_t)(H / 8) + (uint64_t)(8 * wave) : 0ull;
         if constexpr (BWD) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -409,16 +439,35 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
             for (int g = 0; g < 4; ++g) {
                 f32x2 v[2] = {f32x2{acc[i][4 * g], acc[i][4 * g + 1]}, f32x2{acc[i][4 * g + 2], acc[i][4 * g + 3]}};
                 const uint32_t off = aoff(l31, 8 * wave + 4 * i + g) + 8 * half, dst = abase + off;
+                // Mlp.drop behind the activation: the lane's four consecutive hidden units are the first (half = 0) or second half of
+                // a chunk of the generator; one chunk key, one multiply per element pair, formed where the pair is used
+                uint32_t ck = 0;
+                if constexpr (DROP) {
+                    if (dropping) ck = rng_h.chunk_key(cbase + (uint32_t)(4 * i + g));
+                }
+                auto drop2 = [&](int t) {
+                    const uint32_t hh = ElemRng::pair_bits(ck, t == 0 ? (half ? ElemRng::kM2 : ElemRng::kM0) : (half ? ElemRng::kM3 : ElemRng::kM1));
+                    return f32x2{rng_h.keep_lo(hh), rng_h.keep_hi(hh)};
+                };
                 if constexpr (!BWD) {
                     st64(h2base + off, pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y));
                     v[0] = gelu2(v[0]);
                     v[1] = gelu2(v[1]);
+                    if constexpr (DROP) {
+                        if (dropping) {
+                            v[0] *= drop2(0);
+                            v[1] *= drop2(1);
+                        }
+                    }
                     st64(dst, pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y));
                 } else {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const f32x2 hx = {lo_f(hw[i][g][t]), hi_f(hw[i][g][t])};
                         v[t] *= gelu_grad2(hx);
+                        if constexpr (DROP) {
+                            if (dropping) v[t] *= drop2(t);
+                        }
                     }
                     st64(dst, pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y));
                 }
@@ -499,10 +548,12 @@ __global__ void __launch_bounds__(C * 4, 1) mlp_fused_kernel(MlpParams p) {
 }
 
 template <int C>
-int launch_mlp(const MlpParams& p, bool bwd, hipStream_t stream) {
+int launch_mlp(const MlpParams& p, bool bwd, bool drop, hipStream_t stream) {
     const int64_t grid = std::min<int64_t>(p.tiles, usable_cus());  // one persistent workgroup per CU (weights in registers)
-    if (bwd) hipLaunchKernelGGL((mlp_fused_kernel<C, true>), dim3((unsigned)grid), dim3(C * 4), 0, stream, p);
-    else hipLaunchKernelGGL((mlp_fused_kernel<C, false>), dim3((unsigned)grid), dim3(C * 4), 0, stream, p);
+    if (bwd && drop) hipLaunchKernelGGL((mlp_fused_kernel<C, true, true>), dim3((unsigned)grid), dim3(C * 4), 0, stream, p);
+    else if (bwd) hipLaunchKernelGGL((mlp_fused_kernel<C, true, false>), dim3((unsigned)grid), dim3(C * 4), 0, stream, p);
+    else if (drop) hipLaunchKernelGGL((mlp_fused_kernel<C, false, true>), dim3((unsigned)grid), dim3(C * 4), 0, stream, p);
+    else hipLaunchKernelGGL((mlp_fused_kernel<C, false, false>), dim3((unsigned)grid), dim3(C * 4), 0, stream, p);
     HS_LAUNCH_CHECK("mlp_fused");
     return HS_OK;
 }
@@ -519,9 +570,10 @@ int hs_mlp_fused_supported(int channels, int hidden, int dtype) {
     return dtype == HS_BF16 && (channels == 96 || channels == 128) && hidden == 4 * channels;
 }
 
-int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1, const void* w2,
-                     const float* b2, void* n_out, float* mean_out, float* rstd_out, void* h_out, void* act_out, void* out, int64_t rows,
-                     int channels, int hidden, unsigned flags, int dtype, void* stream) {
+static int mlp_fused_fwd_impl(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1, const void* w2,
+                              const float* b2, void* n_out, float* mean_out, float* rstd_out, void* h_out, void* act_out, void* out,
+                              int64_t rows, int channels, int hidden, unsigned flags, int dtype, void* stream, bool drop,
+                              const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed_h, uint64_t seed_o) {
     using namespace hs;
     HS_CHECK_ARG(x && w1 && w2 && out, "hs_mlp_fused_fwd: null pointer");
     HS_CHECK_ARG(!(flags & HS_MLP_NORM_AFTER) || ln_gamma, "hs_mlp_fused_fwd: HS_MLP_NORM_AFTER needs ln_gamma / ln_beta");
@@ -548,14 +600,36 @@ int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta,
         p.out = (uint16_t*)out + r0 * channels;
         p.tiles = n / kT;
         p.residual = (flags & HS_ATTN_RESIDUAL) ? 1 : 0;
-        const int rc = channels == 128 ? launch_mlp<128>(p, false, (hipStream_t)stream) : launch_mlp<96>(p, false, (hipStream_t)stream);
+        p.drop_p = drop_p; p.seed_h = seed_h; p.seed_o = seed_o; p.row_scale = row_scale;
+        p.tiles_per_sample = (int)(rows_per_sample / kT); p.row0 = r0;
+        const int rc = channels == 128 ? launch_mlp<128>(p, false, drop, (hipStream_t)stream) : launch_mlp<96>(p, false, drop, (hipStream_t)stream);
         if (rc != HS_OK) return rc;
     }
     return HS_OK;
 }
 
-int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn, int64_t rows,
-                     int channels, int hidden, int dtype, void* stream) {
+int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1, const void* w2,
+                     const float* b2, void* n_out, float* mean_out, float* rstd_out, void* h_out, void* act_out, void* out, int64_t rows,
+                     int channels, int hidden, unsigned flags, int dtype, void* stream) {
+    return mlp_fused_fwd_impl(x, ln_gamma, ln_beta, w1, b1, w2, b2, n_out, mean_out, rstd_out, h_out, act_out, out, rows, channels, hidden,
+                              flags, dtype, stream, false, nullptr, 32, 0.f, 0, 0);
+}
+
+int hs_mlp_fused_drop_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1, const void* w2,
+                          const float* b2, void* m_out, float* mean_out, float* rstd_out, void* h_out, void* act_out, void* out,
+                          const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed_hidden, uint64_t seed_out,
+                          int64_t rows, int channels, int hidden, unsigned flags, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(flags & HS_MLP_NORM_AFTER, "hs_mlp_fused_drop_fwd: the stochastic form exists for the v2 placement (HS_MLP_NORM_AFTER) only");
+    HS_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "hs_mlp_fused_drop_fwd: drop_p must be in [0, 1)");
+    HS_CHECK_ARG(!row_scale || (rows_per_sample > 0 && rows_per_sample % kT == 0 && rows % rows_per_sample == 0),
+                 "hs_mlp_fused_drop_fwd: rows_per_sample must be a multiple of 32 that divides rows");
+    return mlp_fused_fwd_impl(x, ln_gamma, ln_beta, w1, b1, w2, b2, m_out, mean_out, rstd_out, h_out, act_out, out, rows, channels, hidden,
+                              flags, dtype, stream, true, row_scale, row_scale ? rows_per_sample : 32, drop_p, seed_hidden, seed_out);
+}
+
+static int mlp_fused_bwd_impl(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn,
+                              int64_t rows, int channels, int hidden, int dtype, void* stream, bool drop, float drop_p, uint64_t seed_h) {
     using namespace hs;
     HS_CHECK_ARG(dy && h && w2_t && w1_t && dh && dn, "hs_mlp_fused_bwd: null pointer");
     HS_CHECK_ARG(rows > 0 && rows % kT == 0, "hs_mlp_fused_bwd: rows must be a positive multiple of 32");
@@ -572,10 +646,23 @@ int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void
         p.res_in = dres ? (const uint16_t*)dres + r0 * channels : nullptr;
         p.out = (uint16_t*)dn + r0 * channels;
         p.tiles = n / kT;
-        const int rc = channels == 128 ? launch_mlp<128>(p, true, (hipStream_t)stream) : launch_mlp<96>(p, true, (hipStream_t)stream);
+        p.drop_p = drop_p; p.seed_h = seed_h; p.row0 = r0; p.tiles_per_sample = 1;
+        const int rc = channels == 128 ? launch_mlp<128>(p, true, drop, (hipStream_t)stream) : launch_mlp<96>(p, true, drop, (hipStream_t)stream);
         if (rc != HS_OK) return rc;
     }
     return HS_OK;
+}
+
+int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn, int64_t rows,
+                     int channels, int hidden, int dtype, void* stream) {
+    return mlp_fused_bwd_impl(dy, h, w2_t, w1_t, dres, dh, dn, rows, channels, hidden, dtype, stream, false, 0.f, 0);
+}
+
+int hs_mlp_fused_drop_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn,
+                          float drop_p, uint64_t seed_hidden, int64_t rows, int channels, int hidden, int dtype, void* stream) {
+    using namespace hs;
+    HS_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "hs_mlp_fused_drop_bwd: drop_p must be in [0, 1)");
+    return mlp_fused_bwd_impl(dy, h, w2_t, w1_t, dres, dh, dn, rows, channels, hidden, dtype, stream, true, drop_p, seed_hidden);
 }
 
 }  // extern "C"

@@ -323,11 +323,18 @@ class SwinTransformerBlock(nn.Module):
         (ops.fused_mlp_block) where it applies: HIP norms, exact GELU, hidden = 4 C at C = 96 / 128, nothing stochastic on the
         branch; else None."""
         m = self.mlp
-        if (isinstance(self.norm2, HSLayerNorm) and isinstance(m.fc1, HSLinear) and isinstance(m.fc2, HSLinear) and
-                isinstance(m.act, nn.GELU) and getattr(m.act, "approximate", "none") == "none" and not self._stochastic() and
-                not (self.training and m.drop.p > 0) and ops.fused_mlp_ok(x1, m.fc1.weight.shape[0]) and m.fc2.weight.shape[0] == self.dim):
+        if not (isinstance(self.norm2, HSLayerNorm) and isinstance(m.fc1, HSLinear) and isinstance(m.fc2, HSLinear) and
+                isinstance(m.act, nn.GELU) and getattr(m.act, "approximate", "none") == "none" and
+                ops.fused_mlp_ok(x1, m.fc1.weight.shape[0]) and m.fc2.weight.shape[0] == self.dim):
+            return None
+        rs = self._path_scale(x1) if self.training else None
+        dp = m.drop.p if self.training else 0.0
+        if rs is None and not dp:
             return ops.fused_mlp_block(x1, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
                                        post_norm=post_norm)
+        if ops.fused_mlp_stochastic_ok(x1, post_norm):  # Mlp.drop (both sites) and DropPath inside the launch (v2 placement)
+            return ops.fused_mlp_block(x1, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                       post_norm=True, row_scale=rs, drop_p=dp)
         return None
 
     def can_defer(self):

@@ -1679,8 +1679,11 @@ class FusedMlpBlockFn(torch.autograd.Function):
     kernels (v1: with the residual gradient folded in; v2: in front of the Mlp backward, whose epilogue adds the residual path)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, post_norm=False):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, post_norm=False, stoch=None):
+        """stoch (train mode, post_norm only): (row_scale fp32 [B] or None, rows_per_sample, drop_p, seed_hidden, seed_out) -- Mlp.drop
+        behind the activation and behind fc2, DropPath as a per-sample factor, all inside the launch (hs_mlp_fused_drop_fwd / _bwd)."""
         _require_gpu(x, ln_w, ln_b, w1, b1, w2, b2)
+        assert stoch is None or post_norm
         C, hid = x.shape[-1], w1.shape[0]
         x2 = x.reshape(-1, C)
         if not x2.is_contiguous():
@@ -1696,14 +1699,23 @@ class FusedMlpBlockFn(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         h = torch.empty((rows, hid), dtype=x.dtype, device=dev) if need else None
         # (ops.MLP_KEEP_ACT = False: kept only where fc2's weight gradient cannot take it from h, hs_linear_wgrad_gelu)
-        keep_act = need and (MLP_KEEP_ACT or not lib.hs_linear_wgrad_gelu_supported(rows, C, hid, _lib.HS_BF16))
+        # (with hidden dropout the kept activation is the DROPPED one: fc2's weight gradient cannot take it from h)
+        keep_act = need and (MLP_KEEP_ACT or (stoch is not None and stoch[2] > 0) or
+                             not lib.hs_linear_wgrad_gelu_supported(rows, C, hid, _lib.HS_BF16))
         act = torch.empty((rows, hid), dtype=x.dtype, device=dev) if keep_act else None
         flags = _lib.HS_ATTN_RESIDUAL | (_lib.HS_MLP_NORM_AFTER if post_norm else 0)
         # algorithmic traffic: x in, out (+ n, h, gelu(h) kept for the backward); flops: the two products
         with _timed("mlp_fused_fwd", dev, 2 * rows * ((3 if need else 2) * C + ((2 if keep_act else 1) * hid if need else 0)), 4 * rows * C * hid):
-            check(lib.hs_mlp_fused_fwd(ptr(x2), ptr(g), ptr(b), ptr(w1c), ptr(_f32(b1)), ptr(w2c), ptr(_f32(b2)), ptr(n), ptr(mean), ptr(rstd),
-                                       ptr(h), ptr(act), ptr(out), rows, C, hid, flags, _lib.HS_BF16, stream_ptr(dev)),
-                  "hs_mlp_fused_fwd")
+            if stoch is None:
+                check(lib.hs_mlp_fused_fwd(ptr(x2), ptr(g), ptr(b), ptr(w1c), ptr(_f32(b1)), ptr(w2c), ptr(_f32(b2)), ptr(n), ptr(mean), ptr(rstd),
+                                           ptr(h), ptr(act), ptr(out), rows, C, hid, flags, _lib.HS_BF16, stream_ptr(dev)),
+                      "hs_mlp_fused_fwd")
+            else:
+                rs, rps, dp, seed_h, seed_o = stoch
+                check(lib.hs_mlp_fused_drop_fwd(ptr(x2), ptr(g), ptr(b), ptr(w1c), ptr(_f32(b1)), ptr(w2c), ptr(_f32(b2)), ptr(n), ptr(mean),
+                                                ptr(rstd), ptr(h), ptr(act), ptr(out), ptr(rs), rps, dp, seed_h, seed_o, rows, C, hid, flags,
+                                                _lib.HS_BF16, stream_ptr(dev)), "hs_mlp_fused_drop_fwd")
+        ctx.stoch = stoch
         ctx.save_for_backward(x2, n, mean, rstd, h, act, g, w1, w2)
         ctx.params = (ln_w, ln_b, b1, b2)
         ctx.cast_cache = RT.cast_cache
@@ -1732,12 +1744,22 @@ class FusedMlpBlockFn(torch.autograd.Function):
             # out = x + LN(m): LayerNorm backward first (dm from dout and the saved m), then the Mlp backward on dm with the
             # residual path's gradient (dout itself) added in its epilogue: dx = dout + dh W1
             dm = torch.empty_like(x2)
-            check(lib.hs_layernorm_bwd(ptr(dy2), ptr(n), ptr(g), ptr(mean), ptr(rstd), ptr(dm), ptr(dgamma), ptr(dbeta), ptr(ws), acc, rows, C,
-                                       _lib.HS_BF16, stream_ptr(dev)), "hs_layernorm_bwd")
+            stoch = ctx.stoch
+            if stoch is None:
+                check(lib.hs_layernorm_bwd(ptr(dy2), ptr(n), ptr(g), ptr(mean), ptr(rstd), ptr(dm), ptr(dgamma), ptr(dbeta), ptr(ws), acc, rows, C,
+                                           _lib.HS_BF16, stream_ptr(dev)), "hs_layernorm_bwd")
+            else:  # out = x + rs * LN(drop_o(m)): dm = mask_o * LN_bwd(rs * dout)
+                rs, rps, dp, seed_h, seed_o = stoch
+                check(lib.hs_layernorm_drop_bwd(ptr(dy2), ptr(n), ptr(g), ptr(mean), ptr(rstd), ptr(dm), ptr(dgamma), ptr(dbeta), ptr(ws), acc,
+                                                ptr(rs), rps, dp, seed_o, rows, C, _lib.HS_BF16, stream_ptr(dev)), "hs_layernorm_drop_bwd")
             dx = torch.empty_like(x2)
             with _timed("mlp_fused_bwd", dev, 2 * rows * (3 * C + 2 * hid), 4 * rows * C * hid):
-                check(lib.hs_mlp_fused_bwd(ptr(dm), ptr(h), ptr(w2t), ptr(w1t), ptr(dy2), ptr(dh), ptr(dx), rows, C, hid, _lib.HS_BF16,
-                                           stream_ptr(dev)), "hs_mlp_fused_bwd")
+                if stoch is None:
+                    check(lib.hs_mlp_fused_bwd(ptr(dm), ptr(h), ptr(w2t), ptr(w1t), ptr(dy2), ptr(dh), ptr(dx), rows, C, hid, _lib.HS_BF16,
+                                               stream_ptr(dev)), "hs_mlp_fused_bwd")
+                else:
+                    check(lib.hs_mlp_fused_drop_bwd(ptr(dm), ptr(h), ptr(w2t), ptr(w1t), ptr(dy2), ptr(dh), ptr(dx), dp, seed_h, rows, C, hid,
+                                                    _lib.HS_BF16, stream_ptr(dev)), "hs_mlp_fused_drop_bwd")
             dw2, db2 = _param_grads(dm, h if act is None else act, w2, b2, ctx.needs_input_grad[5], b2 is not None and ctx.needs_input_grad[6],
                                     gelu_x=act is None)
             dw1, db1 = _param_grads(dh, x2, w1, b1, ctx.needs_input_grad[3], b1 is not None and ctx.needs_input_grad[4])
@@ -1756,13 +1778,24 @@ class FusedMlpBlockFn(torch.autograd.Function):
         if acc & _lib.HS_ACC_DEFER:
             _defer_keep(dev, ws)
         dlw, dlb = _norm_param_result(ln_w, ln_b, dgamma, dbeta, direct)
-        return dx.view(ctx.x_shape), dlw, dlb, dw1, db1, dw2, db2, None
+        return dx.view(ctx.x_shape), dlw, dlb, dw1, db1, dw2, db2, None, None
 
 
-def fused_mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, post_norm=False):
+def fused_mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, post_norm=False, row_scale=None, drop_p=0.0, seeds=None):
     """x + fc2(gelu(fc1(LayerNorm(x)))) -- or, post_norm, x + LayerNorm(fc2(gelu(fc1(x)))) -- in one launch (FusedMlpBlockFn; use
-    fused_mlp_ok first)."""
-    return FusedMlpBlockFn.apply(x, ln_w, ln_b, w1, b1, w2, b2, bool(post_norm))
+    fused_mlp_ok first).  Train mode, post_norm only: Mlp.drop (drop_p) behind the activation and behind fc2 and the per-sample DropPath
+    factor `row_scale` ([B] or None) ride in the same launch -- x + rs * LayerNorm(drop(fc2(drop(gelu(fc1(x))))))."""
+    stoch = None
+    if row_scale is not None or drop_p:
+        ex = _extras(x, row_scale, drop_p, None)
+        seed_h, seed_o = seeds if seeds is not None else ((_draw_seed(), _draw_seed()) if drop_p else (0, 0))
+        stoch = (ex[0], ex[1], ex[2], int(seed_h), int(seed_o))
+    return FusedMlpBlockFn.apply(x, ln_w, ln_b, w1, b1, w2, b2, bool(post_norm), stoch)
+
+
+def fused_mlp_stochastic_ok(x, post_norm):
+    """Whether the stochastic form of the fused Mlp block applies: v2 placement, whole 32-row tiles per sample."""
+    return bool(post_norm) and (x.numel() // x.shape[-1] // x.shape[0]) % 32 == 0
 
 
 class ConcatLinearFn(torch.autograd.Function):

@@ -362,6 +362,19 @@ int hs_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta,
                      int channels, int hidden, unsigned flags, int dtype, void* stream);
 int hs_mlp_fused_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn, int64_t rows,
                      int channels, int hidden, int dtype, void* stream);
+/* Train-mode form of the v2 placement with the branch's regularisers inside the launch (flags must carry HS_MLP_NORM_AFTER):
+ *   out = x + rs * LayerNorm(drop_o(fc2(drop_h(gelu(fc1(x))))))       Mlp.drop behind the activation and behind fc2 (:41, :43), DropPath (:335)
+ * drop_h / drop_o are the counter-based masks of hs_gemm_nt's GELU epilogue (seed_hidden, element index in [rows, 4C]) and of
+ * hs_layernorm_drop_fwd (seed_out, [rows, C]); rs = row_scale[row / rows_per_sample] (row_scale [dev] f32 or NULL; rows_per_sample a multiple
+ * of 32).  m_out = fc2's output BEFORE drop_o (hs_layernorm_drop_bwd regenerates the mask), mean_out / rstd_out the statistics of the dropped
+ * rows, act_out = the dropped activation (operand of fc2's weight gradient).  Backward: hs_layernorm_drop_bwd(dout, m_out, ...) -> dm, then
+ * hs_mlp_fused_drop_bwd(dm, h, ..., dres = dout): dh = (dm W2) * mask_h * gelu'(h), dn = dh W1 + dres. */
+int hs_mlp_fused_drop_fwd(const void* x, const float* ln_gamma, const float* ln_beta, const void* w1, const float* b1, const void* w2,
+                          const float* b2, void* m_out, float* mean_out, float* rstd_out, void* h_out, void* act_out, void* out,
+                          const float* row_scale, int64_t rows_per_sample, float drop_p, uint64_t seed_hidden, uint64_t seed_out,
+                          int64_t rows, int channels, int hidden, unsigned flags, int dtype, void* stream);
+int hs_mlp_fused_drop_bwd(const void* dy, const void* h, const void* w2_t, const void* w1_t, const void* dres, void* dh, void* dn,
+                          float drop_p, uint64_t seed_hidden, int64_t rows, int channels, int hidden, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step over flat buffers: torch.optim.Adam / AdamW (the reference's training/optimizer.py:57-66; amsgrad = False,

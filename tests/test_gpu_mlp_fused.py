@@ -279,3 +279,68 @@ def test_fused_mlp_block_with_and_without_kept_activation(keep):
     assert torch.equal(res[True]["out"], res[False]["out"])
     for k in ("x",) + names:
         assert_close(res[False][k], res[True][k], 3e-3, f"fused mlp keep_act on/off d{k}")
+
+
+def _mask_of(seed, p, shape):
+    """The generator's keep mask (x 1 / (1 - p)) for a [rows, width] bf16 tensor, read off the elementwise GELU kernel: gelu(16) = 16."""
+    L = _L()
+    src = torch.full(shape, 16.0, device=DEV, dtype=BF)
+    dst = torch.empty_like(src)
+    L.check(L.lib.hs_gelu_fwd(L.ptr(src), L.ptr(dst), src.numel(), float(p), int(seed), L.HS_BF16, _stream()), "hs_gelu_fwd")
+    return (dst.float() != 0).double() / (1.0 - p)
+
+
+@pytest.mark.parametrize("C", [96, 128])
+@pytest.mark.parametrize("drop_p,with_path", [(0.1, True), (0.25, False), (0.0, True)])
+def test_fused_mlp_block_stochastic_vs_oracle_and_composition(C, drop_p, with_path):
+    """Train-mode v2 block x + rs * LayerNorm(drop(fc2(drop(gelu(fc1(x)))))) in one launch per direction (hs_mlp_fused_drop_fwd / _bwd):
+    against the oracle's float64 autograd with the generator's own masks, and against the composition (ops.mlp with hidden dropout ->
+    hs_layernorm_drop) on the same seeds -- the masks are functions of (seed, element index), so both paths drop the same elements."""
+    from heal_swin_amd import ops
+    from oracle import model as OM
+    B, per = 4, 1024
+    rows = B * per
+    t = _case(C, rows, 7 * C)
+    g = torch.Generator(device=DEV).manual_seed(23)
+    dy = torch.randn((B, per, C), generator=g, device=DEV).to(BF)
+    rs = torch.tensor([0.0, 1.25, 1.25, 1.25], device=DEV) if with_path else None
+    seeds = (0x1234567890ABCDEF, 0x0FEDCBA987654321)
+    names = ("ln_w", "ln_b", "w1", "b1", "w2", "b2")
+
+    def run(fused):
+        x = t["x"].clone().view(B, per, C).requires_grad_(True)
+        ps = {k: t[k].float().clone().requires_grad_(True) for k in names}
+        if fused:
+            out = ops.fused_mlp_block(x, ps["ln_w"], ps["ln_b"], ps["w1"], ps["b1"], ps["w2"], ps["b2"], post_norm=True, row_scale=rs,
+                                      drop_p=drop_p, seeds=seeds)
+        else:
+            m = ops.mlp(x, ps["w1"], ps["b1"], ps["w2"], ps["b2"], drop_p=drop_p, seed=seeds[0])
+            out = ops.layer_norm(m, ps["ln_w"], ps["ln_b"], residual=x, row_scale=rs, drop_p=drop_p, seed=seeds[1])
+        out.backward(dy)
+        return out.detach(), x.grad, {k: ps[k].grad for k in names}
+
+    assert ops.fused_mlp_stochastic_ok(t["x"].view(B, per, C), True)
+    out_f, dx_f, gp_f = run(True)
+    out_c, dx_c, gp_c = run(False)
+    mh = _mask_of(seeds[0], drop_p, (rows, 4 * C)) if drop_p else 1.0
+    mo = _mask_of(seeds[1], drop_p, (rows, C)) if drop_p else 1.0
+    if drop_p:
+        frac = 1.0 - (mh != 0).double().mean().item()
+        assert abs(frac - drop_p) < 0.01, f"hidden drop fraction {frac} vs {drop_p}"
+    rsv = rs.double().repeat_interleave(per).view(rows, 1) if with_path else 1.0
+    xo = t["x"].double().requires_grad_(True)
+    po = {k: t[k].double().requires_grad_(True) for k in names}
+    mlp_o = OM.linear(OM.gelu(OM.linear(xo, po["w1"], po["b1"])) * mh, po["w2"], po["b2"])
+    yo = xo + rsv * OM.layer_norm(mlp_o * mo, po["ln_w"], po["ln_b"])
+    yo.backward(dy.double().view(rows, C))
+    tag = f"stochastic fused_mlp_block C={C} p={drop_p} path={with_path}"
+    assert_close(out_f.view(rows, C), yo.detach(), TOL[BF], tag + " out vs oracle")
+    assert_close(dx_f.view(rows, C), xo.grad, GRAD_TOL[BF], tag + " dx vs oracle")
+    for k in names:
+        assert_close(gp_f[k], po[k].grad, GRAD_TOL[BF], tag + f" d{k} vs oracle")
+    assert_close(out_f, out_c, TOL[BF], tag + " out vs composition")
+    assert_close(dx_f, dx_c, GRAD_TOL[BF], tag + " dx vs composition")
+    for k in names:
+        assert_close(gp_f[k], gp_c[k], GRAD_TOL[BF], tag + f" d{k} vs composition")
+    if with_path:  # a dropped sample passes x through unchanged
+        assert torch.equal(out_f[0], t["x"].view(B, per, C)[0])

@@ -1,11 +1,12 @@
 #!/bin/bash
-set -u
-cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_mlp_fused.py tests/test_gpu_kernels.py tests/test_gpu_ln_head.py tests/test_gpu_attn_module.py -q 2>&1 | grep -E "^E  .*AssertionError|passed|failed|^FAILED|Error" | cut -c1-220 > gpurun_out/r05_c8_tests.log 2>&1
-cat gpurun_out/r05_c8_tests.log | head -30
-timeout 600 python tools/bench_mlp_fused.py 2>/dev/null | tee gpurun_out/r05_c8_mlp_bench.txt
-Q="--no-cpu-baseline --no-fp32-companion --no-pmc-traffic --no-graph-companion"
-timeout 600 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d.get('companions',{})
-print('B', round(d['ms_per_step'],2), d['config']['peak_device_memory_GB'], {k:(round(v['value'],1)) for k,v in c.items() if isinstance(v,dict) and 'value' in v})"
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/r05_call8; mkdir -p $O
+X="--steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic"
+run() { tag=$1; shift; "$@" 2>$O/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d['value'])"; }
+run t256_fused python bench.py --workload T256 $X
+HS_FUSED_ATTN_TRAIN=0 run t256_composed_attn python bench.py --workload T256 $X
+HS_FUSED_MLP=0 run t256_composed_mlp python bench.py --workload T256 $X
+run t128_fused python bench.py --workload T128 $X
+HS_FUSED_ATTN_TRAIN=0 run t128_composed_attn python bench.py --workload T128 $X
+run t256_fused2 python bench.py --workload T256 $X
+run t256_drop python bench.py --workload T256 $X --paper-drop-rates
