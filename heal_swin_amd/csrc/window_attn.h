@@ -40,7 +40,7 @@ __device__ __forceinline__ int64_t shifted_source(const AttnParams& p, int64_t j
     return s >= p.N ? s - p.N : s;
 }
 
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {  // "lowbias32" integer finaliser
+__host__ __device__ constexpr __forceinline__ uint32_t hash32(uint32_t x) {  // "lowbias32" integer finaliser
     x ^= x >> 16;
     x *= 0x7feb352dU;
     x ^= x >> 15;
@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {  // "lowbias32" integer
     return x;
 }
 struct DropRng {
-    uint32_t row_key, thresh16;
+    uint32_t row_key, row_key2, thresh16;
     float keep_scale;
     // row = ((b * nH + h) * N + shifted_row): one per (image, head, query)
     __device__ __forceinline__ DropRng(const AttnParams& p, int64_t row) {
@@ -57,16 +57,30 @@ struct DropRng {
         // keyed with both seed words, one of them entering between the two rounds (once per row): rows of different seeds
         // get unrelated key streams (no row translation between seeds)
         row_key = hash32(hash32((uint32_t)base ^ hash32(p.seed_hi + (uint32_t)(base >> 32) * 0x9E3779B9u)) ^ p.seed_lo);
+        row_key2 = hash32(row_key ^ 0x5BD1E995u);  // second key of the row: the keys whose bit 2 is set
         const float pd = p.drop_p;
         thresh16 = pd >= 1.f ? 65536u : (uint32_t)(pd * 65536.f);  // drop probability in steps of 2^-16
         keep_scale = pd >= 1.f ? 0.f : 1.f / (1.f - pd);
     }
-    // multiplier of probability (row, key): 0 or 1/(1-p).  One 32-bit hash serves the two keys 2m, 2m+1 (16 bits each): the
-    // kernels hold adjacent keys in adjacent registers, so the hash -- most of the dropout's instruction cost -- is shared.
+    // The 16 mask bits of probability (row, key): one multiply per key PAIR.  u = K * M_q with K the row's first or second key
+    // (bit 2 of the key: the MFMA accumulator layouts put keys k and k + 4 in the same register of lanes l and l + 32, so a lane
+    // needs ONE of the two for all of its keys) and M_q an odd constant of the pair index with that bit removed -- a compile-time
+    // constant wherever the key's register is (mult_half: every MFMA kernel), so the mask costs one `v_mul_lo_u32 v, v, literal`
+    // -- quarter rate on the VALU -- per two probabilities.  Key 2q takes lo16(u) ^ hi16(u), key 2q + 1 hi16(u); dropped when
+    // below thresh16.  The row keys are uniform over rows and seeds (finaliser rounds above), so (u_q, u_q') is the lattice of an
+    // LCG with multiplier M_q' / M_q: uniform in both coordinates.
+    static __host__ __device__ constexpr uint32_t pair_mult(uint32_t q) { return hash32(q * 0x9E3779B9u + 0x7F4A7C15u) | 1u; }
+    __device__ __forceinline__ float keep_of(uint32_t k, uint32_t m, int odd) const {
+        const uint32_t u = k * m, h = u ^ (u >> 16);
+        return (odd ? (h >> 16) : (h & 0xffffu)) >= thresh16 ? keep_scale : 0.f;
+    }
+    // multiplier of probability (row, key): 0 or 1/(1-p)
     __device__ __forceinline__ float mult(int key) const {
-        const uint32_t hsh = hash32(row_key + (uint32_t)(key >> 1) * 0x9E3779B9u);
-        const uint32_t bits = (key & 1) ? (hsh >> 16) : (hsh & 0xffffu);
-        return bits >= thresh16 ? keep_scale : 0.f;
+        return keep_of((key & 4) ? row_key2 : row_key, pair_mult(((uint32_t)key >> 1) & ~2u), key & 1);
+    }
+    // the same for key = kc + 4 * half with kc a compile-time constant whose bit 2 is clear
+    __device__ __forceinline__ float mult_half(int kc, int half) const {
+        return keep_of(half ? row_key2 : row_key, pair_mult((uint32_t)kc >> 1), kc & 1);
     }
 };
 

@@ -438,6 +438,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                 }
         }
         float dsum = 0.f, s_pds = 0.f, s_ps = 0.f;
+        uint32_t keepbits = 0u;
         uint32_t pS[2][8], pP[2][8];
         {
         // (Measured, not kept: the same arithmetic on register PAIRS with v_pk_fma / v_pk_mul / v_pk_add -- 17 instead of 23 VALU
@@ -459,7 +460,11 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                         if (lab_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != mylab) tt += kMaskLog2;
                     const float pr = __builtin_amdgcn_exp2f(tt + nlse2);
                     float dpv = accP[kt][r];
-                    if constexpr (DROP) dpv *= rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                    if constexpr (DROP) {  // the keep bit is kept for pass 2 (the mask is evaluated once per probability)
+                        const float mk = rng.mult_half(kt * 32 + (r & 3) + 8 * (r >> 2), half);
+                        keepbits |= (mk != 0.f ? 1u : 0u) << (kt * 16 + r);
+                        dpv *= mk;
+                    }
                     dsum = fmaf(pr, dpv, dsum);
                     if constexpr (COS) {
                         const float ps = pr * sraw;
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
                     const float dsv = pr * (accP[kt][r] - dsum);
                     dbacc[kt][r] += dsv;
                     ds2[e] = dsv * fqn;
-                    pp2[e] = DROP ? pr * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) : pr;
+                    pp2[e] = DROP ? (((keepbits >> (kt * 16 + r)) & 1u) ? pr * rng.keep_scale : 0.f) : pr;
                 }
                 pS[kt][i] = pack_bf16x2(ds2[0], ds2[1]);
                 pP[kt][i] = pack_bf16x2(pp2[0], pp2[1]);
@@ -919,7 +924,7 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        acc[kt][qt][r] *= linv * rng.mult(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                        acc[kt][qt][r] *= linv * rng.mult_half(kt * 32 + (r & 3) + 8 * (r >> 2), half);
             } else {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)

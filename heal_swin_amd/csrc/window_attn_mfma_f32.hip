@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(64, 1) attn_fwd_f32_kernel(AttnParams p) {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv * rng.mult(kt * 32 + kappa(r, half));
+                    for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= linv * rng.mult_half(kt * 32 + kappa(r, 0), half);
             } else {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(64, 1) attn_bwd_f32_kernel(AttnParams p, float
                         const float t = fmaf(sraw, fq2, brow[r]);
                         const float pr = exp2f(t - lse2);
                         float dpv = accP[kt][qt][r];
-                        if constexpr (DROP) dpv *= rng.mult(kt * 32 + kappa(r, half));
+                        if constexpr (DROP) dpv *= rng.mult_half(kt * 32 + kappa(r, 0), half);
                         const float dsv = pr * (dpv - dsum);
                         dbacc[kt][qt][r] += dsv;
                         if constexpr (COS) dscale_acc = fmaf(dsv * qinv, sraw, dscale_acc);

@@ -1,11 +1,10 @@
 #!/bin/bash
-set -u
-cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_mlp_fused.py tests/test_gpu_model.py tests/test_gpu_deferred.py -q 2>&1 | grep -E "^E  .*AssertionError|passed|failed|^FAILED|Error" | cut -c1-220 > gpurun_out/r05_c10_tests.log 2>&1
-cat gpurun_out/r05_c10_tests.log | head -30
-timeout 600 python tools/bench_mlp_fused.py 2>/dev/null | tee gpurun_out/r05_c10_mlp_bench.txt
-Q="--no-cpu-baseline --no-fp32-companion --no-pmc-traffic --no-graph-companion"
-timeout 600 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d.get('companions',{})
-print('B', round(d['ms_per_step'],2), d['config']['peak_device_memory_GB'], {k:(round(v['value'],1)) for k,v in c.items() if isinstance(v,dict) and 'value' in v})"
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/r05_call10; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_hygiene.py tests/test_gpu_attn_module.py -x -q -m gpu > $O/tests.txt 2>&1
+tail -3 $O/tests.txt
+X="--steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --kernel-table"
+run() { tag=$1; shift; "$@" 2>$O/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d['value'])"; }
+run t256_nodrop python bench.py --workload T256 $X
+run t256_drop python bench.py --workload T256 $X --paper-drop-rates
+grep "window_attn" $O/t256_nodrop.err $O/t256_drop.err | cut -c1-150
