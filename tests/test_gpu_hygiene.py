@@ -94,6 +94,60 @@ def test_dropout_masks_of_different_seeds_are_uncorrelated():
         assert (a[idx ^ k] == b).mean() < 0.52
 
 
+def test_dropout_mask_elements_of_a_chunk_are_independent():
+    """The elementwise generator (csrc/hs_device.h: ElemRng) derives the 8 masks of a chunk from ONE 32-bit chunk key by four fixed
+    multipliers: every element is dropped with probability p, every pair of elements of a chunk -- and neighbours across chunks --
+    independently (correlation within 6 sigma of 0), and triples jointly at p^3."""
+    from heal_swin_amd import ops
+    n = 1 << 23
+    x = torch.ones(n, device=DEV) * 3.0
+    for p, seed in ((0.1, 5), (0.5, 0xDEADBEEF_00000007)):
+        keep = (ops.GeluDropoutFn.apply(x, p, seed) > 0).view(-1, 8).double()
+        rows = keep.shape[0]
+        mean = keep.mean(0)
+        assert float((mean - (1 - p)).abs().max()) < 6 * (p * (1 - p) / rows) ** 0.5 + 1e-4, mean
+        z = (keep - mean) / keep.std(0)
+        corr = (z.t() @ z / rows).cpu().numpy()
+        off = corr - np.eye(8)
+        assert np.abs(off).max() < 6 / rows ** 0.5, (p, np.abs(off).max())
+        zc = (z[:-1].t() @ z[1:] / (rows - 1)).cpu().numpy()  # element a of chunk c against element b of chunk c + 1
+        assert np.abs(zc).max() < 6 / rows ** 0.5, (p, np.abs(zc).max())
+        drop = 1 - keep
+        for tri in ((0, 1, 2), (0, 2, 4), (1, 3, 7), (2, 3, 6), (4, 5, 6)):
+            joint = float((drop[:, tri[0]] * drop[:, tri[1]] * drop[:, tri[2]]).mean())
+            sigma = (p ** 3 * (1 - p ** 3) / rows) ** 0.5
+            assert abs(joint - p ** 3) < 6 * sigma + 1e-6, (p, tri, joint, p ** 3)
+
+
+def test_attention_dropout_keys_of_a_row_are_independent():
+    """The attention generator (csrc/window_attn.h: DropRng) derives the 64 key masks of a (head, query) row from two 32-bit row keys
+    by one compile-time multiplier per key pair.  Masks are read off the kernel itself (q = k = 0: uniform probabilities; V = one-hot
+    over 32 of the keys): every key dropped with probability p, all key pairs of a row uncorrelated."""
+    from heal_swin_amd import ops
+    B, nH, Ws, hd = 1, 2, 64, 32
+    N, C = 64 * 1024, 64
+    p = 0.3
+    masks = []
+    for half in (0, 1):
+        qkv = torch.zeros(B, N, 3 * C, device=DEV, dtype=torch.bfloat16)
+        tok = torch.arange(N, device=DEV)
+        key = tok % Ws
+        sel = (key // hd) == half
+        for h in range(nH):
+            qkv[0, tok[sel], 2 * C + h * hd + (key[sel] % hd)] = 1.0
+        o = ops.window_attn_core(qkv, None, torch.ones(nH, device=DEV), None, 0, None, nH, Ws, False, attn_drop=p, seed=0xABCDEF12_3456789)
+        masks.append((o.float().view(N, nH, hd) > 0).permute(1, 0, 2).reshape(nH * N, hd))  # [row, key within the half]
+    keep = torch.cat(masks, 1).double()  # [rows, 64 keys]
+    rows = keep.shape[0]
+    mean = keep.mean(0)
+    assert float((mean - (1 - p)).abs().max()) < 6 * (p * (1 - p) / rows) ** 0.5 + 1e-4, mean
+    z = (keep - mean) / keep.std(0)
+    corr = (z.t() @ z / rows).cpu().numpy() - np.eye(Ws)
+    assert np.abs(corr).max() < 6 / rows ** 0.5, np.abs(corr).max()
+    zr = (z[:-1].t() @ z[1:] / (rows - 1)).cpu().numpy()  # consecutive rows
+    assert np.abs(zr).max() < 6 / rows ** 0.5, np.abs(zr).max()
+
+
 def test_to_device_side_stream_handover():
     from heal_swin_amd import data
     imgs = torch.randint(0, 256, (4, 3, 1 << 20), dtype=torch.uint8).pin_memory()
