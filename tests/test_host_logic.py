@@ -147,6 +147,28 @@ def test_bf16x3_policy_and_legality_helpers():
     assert not ops.own_gemm_legal(128, 512, torch.float32)
 
 
+def test_own_gemm_policy_class_rule_and_measured_exceptions(monkeypatch):
+    """ops.own_gemm_ok: the class rule (HBM-bound shapes, GELU epilogues) plus the table of measured per-shape exceptions, which applies
+    from OWN_SHAPE_TABLE_MIN_M rows up (it was measured on the large workloads only) and never overrides HS_OWN_GEMM = 0 / 1."""
+    import torch
+    from heal_swin_amd import _lib, ops
+    bf = torch.bfloat16
+    monkeypatch.setattr(ops, "OWN_GEMM", "auto")
+    monkeypatch.setattr(ops.RT, "prefer_own_gemm", False)
+    monkeypatch.setattr(ops, "OWN_SHAPE_TABLE", {(1152, 384): True, (128, 128): False})
+    assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 384, 96, bf) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 512, bf)  # class rule: narrow / short
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 512, 2048, bf) and not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1536, 512, bf)
+    assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=65536)  # table entry
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=ops.OWN_SHAPE_TABLE_MIN_M - 32)  # below the measured range: class rule
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1 << 20) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1024)
+    assert ops.own_gemm_ok(_lib.HS_EPI_GELU, 2048, 512, bf) and ops.own_gemm_ok(_lib.HS_EPI_DGELU, 2048, 512, bf)  # epilogue products: own
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, torch.float32) and not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1150, 384, bf)
+    monkeypatch.setattr(ops, "OWN_GEMM", "0")
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf) and not ops.own_gemm_ok(_lib.HS_EPI_GELU, 2048, 512, bf)
+    monkeypatch.setattr(ops, "OWN_GEMM", "1")
+    assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1 << 20) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 512, 2048, bf)
+
+
 def test_weight_split_cache_hits_for_fresh_views_and_follows_the_weight_epoch(monkeypatch):
     """callers pass `w.view(n, k)` / `w.reshape(...)` -- a new tensor object per call -- so an identity check
     never hit.  The entry is now found by the storage it views; it is dropped when the parameter's version OR the weight epoch
