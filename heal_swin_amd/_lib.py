@@ -62,6 +62,7 @@ _SIGNATURES = {
     "hs_residual_drop": [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.c_float, ctypes.c_uint64, c_int, c_ptr],
     "hs_linear_wgrad": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     "hs_reduce_flush": [c_ptr],
+    "hs_set_seed_epoch": [c_ptr],
     "hs_linear_wgrad_gelu": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr],
     "hs_linear_wgrad_gelu_supported": [c_i64, c_int, c_int, c_int],
     "hs_mlp_fused_supported": [c_int, c_int, c_int],
@@ -118,6 +119,7 @@ _OTHER = {
     "hs_status_string": ([c_int], ctypes.c_char_p),
     "hs_device_count": ([], c_int),
     "hs_get_reserved_cus": ([], c_int),
+    "hs_get_seed_epoch": ([], c_ptr),
     "hs_reduce_pending": ([c_ptr], c_int),
     "hs_layernorm_bwd_workspace": ([c_i64, c_int], c_i64),
     "hs_seg_ce_partials": ([c_i64, c_i64], c_i64),

@@ -5,6 +5,7 @@
 #include "hs_gelu.h"
 
 namespace hs {
+HS_DEFINE_SEED_EPOCH_SETTER(set_seed_epoch_gelu)
 namespace {
 
 template <typename T>

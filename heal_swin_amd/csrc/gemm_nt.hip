@@ -33,6 +33,7 @@
 #include "hs_gelu.h"
 
 namespace hs {
+HS_DEFINE_SEED_EPOCH_SETTER(set_seed_epoch_gemm_nt)
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -31,6 +31,15 @@ int reserved_cus();
 inline int usable_cus_per_xcd() { return 32 - reserved_cus() / 8; }
 inline int usable_cus() { return 8 * usable_cus_per_xcd(); }
 
+// per translation unit with stochastic kernels (HS_DEFINE_SEED_EPOCH_SETTER); hs_set_seed_epoch (hs_core.cpp) calls them all
+int set_seed_epoch_gelu(const void* counter);
+int set_seed_epoch_layernorm(const void* counter);
+int set_seed_epoch_gemm_nt(const void* counter);
+int set_seed_epoch_mlp_fused(const void* counter);
+int set_seed_epoch_attn_generic(const void* counter);
+int set_seed_epoch_attn_mfma(const void* counter);
+int set_seed_epoch_attn_mfma_f32(const void* counter);
+
 }  // namespace hs
 
 #define HS_CHECK_ARG(cond, ...)                                        \

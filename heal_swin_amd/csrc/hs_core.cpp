@@ -33,6 +33,8 @@ int fail(int status, const char* fmt, ...) {
 }
 }  // namespace hs
 
+static const void* g_seed_epoch_host = nullptr;
+
 extern "C" {
 const char* hs_version(void) { return "healswin 0.1 (gfx950)"; }
 const char* hs_last_error(void) { return hs::error_buffer(); }
@@ -52,6 +54,19 @@ int hs_set_reserved_cus(int n) {
     return HS_OK;
 }
 int hs_get_reserved_cus(void) { return hs::reserved_cus(); }
+int hs_set_seed_epoch(const void* counter) {
+    // (one static __device__ pointer per translation unit with stochastic kernels: hs_device.h)
+    int (*const setters[])(const void*) = {hs::set_seed_epoch_gelu, hs::set_seed_epoch_layernorm, hs::set_seed_epoch_gemm_nt, hs::set_seed_epoch_mlp_fused,
+                                           hs::set_seed_epoch_attn_generic, hs::set_seed_epoch_attn_mfma, hs::set_seed_epoch_attn_mfma_f32};
+    for (auto set : setters)
+        if (set(counter) != HS_OK) {
+            (void)hipGetLastError();
+            return hs::fail(HS_ERR_HIP, "hs_set_seed_epoch: hipMemcpyToSymbol failed");
+        }
+    g_seed_epoch_host = counter;
+    return HS_OK;
+}
+const void* hs_get_seed_epoch(void) { return g_seed_epoch_host; }
 int hs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

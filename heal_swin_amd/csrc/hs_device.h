@@ -46,10 +46,26 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // "lowbias32" integer 
     x ^= x >> 16;
     return x;
 }
+// Seeds under HIP-graph replay.  Every stochastic kernel takes its seed by value, so a captured launch would repeat its mask on every
+// replay.  hs_set_seed_epoch(ptr) registers a device-resident 64-bit counter: when set, every mask generator adds counter * odd
+// constant to its seed at kernel start (two scalar loads), and the owner of the graph advances the counter once per replayed step
+// (forward and backward of a step see the same value).  The pointer is a static __device__ variable of each translation unit
+// (no relocatable device code in this build), written by the unit's set_seed_epoch_* function.
+static __device__ const unsigned long long* g_seed_epoch = nullptr;
+__device__ __forceinline__ uint64_t epoch_seed(uint64_t seed) {
+    const unsigned long long* e = g_seed_epoch;
+    return e ? seed + (uint64_t)(*e) * 0x9E3779B97F4A7C15ull : seed;
+}
+#define HS_DEFINE_SEED_EPOCH_SETTER(name)                                                                              \
+    int name(const void* counter) {                                                                                    \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_seed_epoch), &counter, sizeof(counter)) == hipSuccess ? 0 : 3; \
+    }
+
 struct ElemRng {
     uint32_t key_lo, key_hi, thresh16;
     float keep_scale;
     __device__ __forceinline__ ElemRng(float p, uint64_t seed) {
+        seed = epoch_seed(seed);
         key_lo = (uint32_t)seed;
         key_hi = mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu);  // pre-mixed once per thread
         thresh16 = p >= 1.f ? 65536u : (uint32_t)(p * 65536.f);  // drop probability in steps of 2^-16

@@ -8,6 +8,7 @@
 #include "hs_device.h"
 
 namespace hs {
+HS_DEFINE_SEED_EPOCH_SETTER(set_seed_epoch_layernorm)
 namespace {
 
 constexpr float kLnEps = 1e-5f;  // torch.nn.LayerNorm default, used by every norm in the reference

@@ -48,6 +48,16 @@ __host__ __device__ constexpr __forceinline__ uint32_t hash32(uint32_t x) {  // 
     x ^= x >> 16;
     return x;
 }
+// Called once at the top of every attention kernel (on its by-value copy of the parameters): the replay counter of hs_device.h enters
+// the seed words here, not in DropRng -- the scalar loads and their wait stay out of the window loop and its counted LDS waits.
+__device__ __forceinline__ void apply_seed_epoch(AttnParams& p) {
+    if (p.drop_p > 0.f) {
+        const uint64_t seed = epoch_seed(((uint64_t)p.seed_hi << 32) | p.seed_lo);
+        p.seed_lo = (uint32_t)seed;
+        p.seed_hi = (uint32_t)(seed >> 32);
+    }
+}
+
 struct DropRng {
     uint32_t row_key, row_key2, thresh16;
     float keep_scale;

@@ -11,6 +11,7 @@
 #include "window_attn.h"
 
 namespace hs {
+HS_DEFINE_SEED_EPOCH_SETTER(set_seed_epoch_attn_generic)
 namespace {
 
 constexpr float kNormEps = 1e-12f;   // F.normalize eps, swin_hp_transformer.py:143
@@ -18,6 +19,7 @@ constexpr float kMaskValue = -100.f; // hp_shifting.py:25
 
 template <typename T, int HD>
 __global__ void __launch_bounds__(256) attn_fwd_generic_kernel(AttnParams p) {
+    apply_seed_epoch(p);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LD = HD + 1;
     const int nthr = blockDim.x, t = threadIdx.x, h = blockIdx.y, Ws = p.Ws, hd = p.hd;
@@ -117,6 +119,7 @@ __global__ void __launch_bounds__(256) attn_fwd_generic_kernel(AttnParams p) {
 // (dk, dv), re-deriving the probabilities from the saved log-sum-exp.
 template <typename T, int HD>
 __global__ void __launch_bounds__(256) attn_bwd_generic_kernel(AttnParams p) {
+    apply_seed_epoch(p);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LD = HD + 1;
     const int nthr = blockDim.x, t = threadIdx.x, h = blockIdx.y, Ws = p.Ws, hd = p.hd;

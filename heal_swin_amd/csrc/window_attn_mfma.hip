@@ -31,6 +31,7 @@
 #include <type_traits>
 
 namespace hs {
+HS_DEFINE_SEED_EPOCH_SETTER(set_seed_epoch_attn_mfma)
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -149,6 +150,7 @@ __device__ __forceinline__ void pack_rows_t(const float (&v)[16], u32x4& p0, u32
 template <int HG, bool DROP, bool COS>
 __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p, float* __restrict__ dbias_part,
                                                                  float* __restrict__ dscale_part, int slots, int groups) {
+    if constexpr (DROP) apply_seed_epoch(p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayoutBwd L(HG);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -652,6 +654,7 @@ struct LdsLayoutFwd {
 
 template <int HG, bool DROP>
 __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p, int slots, int groups) {
+    if constexpr (DROP) apply_seed_epoch(p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayoutFwd L(HG);
     const int tid = threadIdx.x, lane = tid & 63;

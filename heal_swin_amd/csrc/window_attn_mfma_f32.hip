@@ -19,6 +19,7 @@
 #include "window_attn.h"
 
 namespace hs {
+HS_DEFINE_SEED_EPOCH_SETTER(set_seed_epoch_attn_mfma_f32)
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -80,6 +81,7 @@ struct Stage {  // lane -> (row within an 8-row pass, float4 chunk)
 // ================================================================================================ forward
 template <bool DROP>
 __global__ void __launch_bounds__(64, 1) attn_fwd_f32_kernel(AttnParams p) {
+    if constexpr (DROP) apply_seed_epoch(p);
     __shared__ __attribute__((aligned(16))) float smem[3 * kTile + 2 * kWs];
     float* q_t = smem;
     float* k_t = smem + kTile;
@@ -227,6 +229,7 @@ __global__ void __launch_bounds__(64, 1) attn_fwd_f32_kernel(AttnParams p) {
 template <bool DROP, bool COS>
 __global__ void __launch_bounds__(64, 1) attn_bwd_f32_kernel(AttnParams p, float* __restrict__ dbias_part,
                                                              float* __restrict__ dscale_part) {
+    if constexpr (DROP) apply_seed_epoch(p);
     __shared__ __attribute__((aligned(16))) float smem[4 * kTile + 5 * kWs];
     float* q_t = smem;
     float* k_t = smem + kTile;

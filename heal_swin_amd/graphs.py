@@ -11,10 +11,15 @@ what the reference would have needed a tracing compiler for.
     for images, labels in loader:
         loss = step(images, labels)          # copies the batch into the graph's static buffers and replays
 
-Constraints (checked): single process (collectives are not captured -- under DP use the eager step), no dropout / DropPath
-(their seeds are drawn on the host per call and would be frozen into the graph), a `capturable=True` optimizer, fixed shapes.
+Constraints (checked): single process (collectives are not captured -- under DP use the eager step), a `capturable=True` optimizer,
+fixed shapes.  Dropout / DropPath: the kernels' seeds are drawn on the host per call and are frozen into the graph; a model with
+drop rates > 0 is replayed with a device-side step counter registered with the library (`hs_set_seed_epoch`): every mask generator
+adds counter x odd constant to its frozen seed, the captured step ends with counter += 1, so every replay draws fresh masks and the
+forward and backward of a step agree.  DropPath's per-sample factors come from torch's CUDA generator, which is graph-safe by itself.
 """
 import torch
+
+from . import _lib
 
 
 class GraphedTrainStep:
@@ -26,9 +31,8 @@ class GraphedTrainStep:
         grad_sink: optional `parallel.GradBucketAllReduce` of a single-process run (its flat buckets then receive the kernels'
         direct gradient deposits; `zero_grad()` / `finish()` are part of the captured step)."""
         cfg = getattr(model, "config", None)
-        for name in ("drop_rate", "attn_drop_rate", "drop_path_rate"):
-            if cfg is not None and getattr(cfg, name, 0.0) and model.training:
-                raise ValueError(f"GraphedTrainStep: {name} > 0 draws a host-side seed per call, which a graph would freeze")
+        stochastic = model.training and cfg is not None and any(getattr(cfg, n, 0.0) for n in ("drop_rate", "attn_drop_rate", "drop_path_rate"))
+        self._epoch = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise ValueError("GraphedTrainStep: gradient all-reduce is not captured; use the eager step under data parallelism")
         for group in optimizer.param_groups:
@@ -40,6 +44,11 @@ class GraphedTrainStep:
         self.pre_forward, self.grad_sink = pre_forward, grad_sink
         self.inputs = example_inputs.detach().clone()
         self.targets = example_targets.detach().clone()
+        if stochastic:  # replay counter of the mask generators (process-wide in the library: one stochastic graphed step at a time)
+            if _lib.lib.hs_get_seed_epoch():
+                raise ValueError("GraphedTrainStep: another graphed step with dropout is alive in this process (one seed counter per process)")
+            self._epoch = torch.zeros(1, dtype=torch.int64, device=self.inputs.device)
+            _lib.check(_lib.lib.hs_set_seed_epoch(_lib.ptr(self._epoch)), "hs_set_seed_epoch")
 
         # warm-up on a side stream (PyTorch's capture protocol): lazy initialisations -- kernel attributes, the bf16 weight
         # shadows, optimizer state, the allocator's blocks -- happen here, not inside the capture
@@ -68,7 +77,22 @@ class GraphedTrainStep:
         if self.grad_sink is not None:
             self.grad_sink.finish()
         self.optimizer.step()
+        if self._epoch is not None:
+            self._epoch.add_(1)  # the next step (replay) draws new masks
         return loss.detach()
+
+    def close(self):
+        """Unregister the replay counter (stochastic models); the graph must not be replayed afterwards."""
+        if self._epoch is not None:
+            torch.cuda.synchronize(self._epoch.device)
+            _lib.lib.hs_set_seed_epoch(None)
+            self._epoch = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __call__(self, inputs, targets):
         """One training step on (inputs, targets); returns the loss (a static device tensor, overwritten by the next call)."""

@@ -63,6 +63,13 @@ int hs_transpose_many_16(const void* jobs, int count, int blocks_per_job, void* 
  * Affects hs_linear_wgrad (+ _workspace), hs_gemm_nt, hs_window_attn_* (+ _workspace), hs_window_attn_module_fwd(_train). */
 int hs_set_reserved_cus(int n);
 int hs_get_reserved_cus(void);
+/* HIP-graph replay with dropout (graphs.GraphedTrainStep; replaces nothing in the reference -- its trainer draws torch's Philox
+ * stream per call, `nn.Dropout` at models_torch/swin_hp_transformer.py:36, :122, :126).  Every stochastic entry point takes its seed by
+ * value, so a captured launch would repeat its mask on every replay.  hs_set_seed_epoch(counter) registers a [dev] uint64 counter for
+ * this process (NULL: off, the default): every mask generator then adds counter * odd constant to its seed at kernel start, and the owner
+ * of the graph advances the counter once per replayed step (forward and backward of a step read the same value). */
+int hs_set_seed_epoch(const void* counter);
+const void* hs_get_seed_epoch(void);
 /* Diagnostic: `n_workgroups` workgroups of `threads` threads and `lds_bytes` of LDS each that stay resident for `microseconds`
  * on `stream` -- a stand-in for a communication library's long-lived ring kernels (tools/cu_contention.py). */
 int hs_debug_occupy_cus(int n_workgroups, int threads, int lds_bytes, double microseconds, void* stream);

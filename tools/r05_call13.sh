@@ -1,5 +1,11 @@
 #!/bin/bash
-set -u
-cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_attn_module.py tests/test_gpu_baseline_configs.py -q 2>&1 | grep -E "^E  .*AssertionError|passed|failed|^FAILED|Error" | cut -c1-220 | head -20
-TAG=r05b bash tools/collect_attn_pmc_T256.sh 2>&1 | head -12
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/r05_call13; mkdir -p $O
+X="--steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --no-kernel-timing"
+run() { tag=$1; shift; "$@" 2>$O/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d['value'], d['config'].get('final_loss'))"; }
+run t256_drop_eager python bench.py --workload T256 $X --paper-drop-rates
+run t256_drop_graph python bench.py --workload T256 $X --paper-drop-rates --graph
+run t128_drop_eager python bench.py --workload T128 $X --paper-drop-rates
+run t128_drop_graph python bench.py --workload T128 $X --paper-drop-rates --graph
+run t128_nodrop_graph python bench.py --workload T128 $X --graph
+tail -3 $O/t256_drop_graph.err
