@@ -9,6 +9,18 @@
 
 namespace hs {
 HS_DEFINE_SEED_EPOCH_SETTER(set_seed_epoch_layernorm)
+
+// Sample (image) of a row for the per-sample DropPath factor: row / rows_per_sample without the 64-bit division (~150 instructions
+// per row and lane -- more than the rest of a stochastic LayerNorm row costs).  Exact: below 2^24 rows the float quotient is off by
+// at most one, which the two comparisons repair; larger tensors keep the division.
+__device__ __forceinline__ int64_t sample_of(int64_t row, int64_t rows_per_sample) {
+    if (row >= (1 << 24)) return row / rows_per_sample;
+    const uint32_t r = (uint32_t)row, d = (uint32_t)rows_per_sample;
+    uint32_t q = (uint32_t)((float)r * __builtin_amdgcn_rcpf((float)d));
+    if (q * d > r) --q;
+    if ((q + 1) * d <= r) ++q;
+    return (int64_t)q;
+}
 namespace {
 
 constexpr float kLnEps = 1e-5f;  // torch.nn.LayerNorm default, used by every norm in the reference
@@ -97,7 +109,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
                                                             void* __restrict__ lo_out) {
     // Stochastic extras (train mode).  With add_in (v1):  s = x + rs * drop(add_in),  y = LN(s).
     // Without (v2 / plain):                               y = [residual +] rs * LN(drop(x)).
-    // rs = row_scale[row / rows_per_sample] is the per-sample DropPath factor, drop() the counter-based dropout mask.
+    // rs = row_scale[sample_of(row, rows_per_sample)] is the per-sample DropPath factor, drop() the counter-based dropout mask.
     // Compensated residual stream (lo_in / lo_out, optional, activation dtype): the residual stream of a stage is the sum of
     // up to 36 branch outputs; stored in bf16 every add rounds it (2^-9 relative), which is a third of the bf16 logit error of
     // HEAL-SWIN-B (tests/experiments/bf16_error_budget.py).  With lo_out the stream operand is hi + lo: the new sum is
@@ -137,7 +149,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const void* __restri
         const int64_t row = row0 + rsub;
         const bool live = row < rows;
         const int64_t base = row * width;
-        const float rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
+        const float rs = (row_scale && live) ? row_scale[sample_of(row, rows_per_sample)] : 1.f;
         float v[ITERS][VEC];
         uint4 cx[ITERS], ca[ITERS];
         if constexpr (PF) {
@@ -379,7 +391,7 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? 6 : ITERS == 2 ? 5 : ITERS 
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = fmaf((v[it][k] - mean) * rstd, g[k], b[k]);
                 if constexpr (EX) {  // DropPath factor of this row's sample
-                    const float rs = row_scale ? row_scale[row / rows_per_sample] : 1.f;
+                    const float rs = row_scale ? row_scale[sample_of(row, rows_per_sample)] : 1.f;
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) o[k] *= rs;
                 }
@@ -438,7 +450,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const void* __restri
         const bool live = row < rows;
         const int64_t base = row * width;
         const float mean = live ? mean_in[row] : 0.f, rstd = live ? rstd_in[row] : 0.f;
-        const float rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
+        const float rs = (row_scale && live) ? row_scale[sample_of(row, rows_per_sample)] : 1.f;
         float xh[ITERS][VEC], g[ITERS][VEC];
         float d2[ITERS][VEC];  // gradient arriving through the residual path of the fused add: requested WITH x and dy (it
                                // depends on nothing; loaded behind the row reductions it was a second serial round trip per row)
@@ -637,7 +649,7 @@ __global__ void __launch_bounds__(256, (ITERS == 1 ? (EX ? 4 : 5) : ITERS == 2 ?
         // would be 16 registers per chunk over the two shuffle trees: 114 registers, 4 waves per SIMD; this form needs 80: 6)
         float s1 = 0.f, s2 = 0.f;
         float rs = 1.f;
-        if constexpr (EX) rs = (row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
+        if constexpr (EX) rs = (row_scale && live) ? row_scale[sample_of(row, rows_per_sample)] : 1.f;
         uint32_t keep[ITERS];  // EX: the chunk's keep decisions, one bit per element -- the hash (two integer-multiply rounds per element
                                // pair: the dominant cost of this variant) is evaluated ONCE and reused by the second decode
 #pragma unroll
