@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run bench.py with module attributes of heal_swin_amd.ops overridden (policy thresholds, feature flags) -- for same-box A/B runs
 of settings that have no environment switch.
-usage: python tools/policy_ab.py OWN_BIAS_MAX_K=768 MLP_KEEP_ACT=False -- --workload T256 --steps 8 --no-companions ..."""
+usage: python tools/policy_ab.py OWN_BIAS_MAX_K=768 MLP_KEEP_ACT=False [@hs_gemm_nt_set_tile=2] -- --workload T256 --steps 8 --no-companions ..."""
 import ast
 import os
 import sys
@@ -23,6 +23,11 @@ def build_model(*a, **kw):  # (the overrides are applied where bench.py itself f
 
     for s in sets:
         name, val = s.split("=", 1)
+        if name.startswith("@"):  # @hs_function=int: call a C entry point of the library with one integer argument
+            from heal_swin_amd import _lib
+            rc = getattr(_lib.lib, name[1:])(int(val))
+            print(f"[policy_ab] {name[1:]}({val}) -> {rc}", file=sys.stderr)
+            continue
         if not hasattr(ops, name):
             raise SystemExit(f"heal_swin_amd.ops has no attribute {name}")
         try:
