@@ -368,6 +368,58 @@ def test_paper_config_full_size_logits_vs_oracle(dtype):
         assert abs(loss - ref_loss) <= (1e-4 if dtype == torch.float32 else 2e-3) * max(1.0, abs(ref_loss))
 
 
+def test_paper_config_full_size_gradients_vs_oracle():
+    """The paper's model at its full size (HEAL-SWIN-T, nside 256, ring_shift 4, cosine attention, v2 norm placement), the BACKWARD
+    against the oracle's autograd: every parameter gradient of one image's CE loss, fp32 and bf16 kernels, each tensor on its own
+    scale.  (d logit_scale is a cancelling sum over all scores of a head: bounded separately, as in tests/test_gpu_model.py.)"""
+    import psutil
+    from heal_swin_amd.losses import seg_loss
+    from oracle import model as OM
+    if psutil.virtual_memory().available < 64 * 2 ** 30:
+        pytest.skip("the oracle's full-size autograd graph of the paper config needs ~40 GB of host memory")
+    CASES["_paper_full"] = (T_CFG, 256, 8, 1, dict(shift_strategy="ring_shift", shift_size=4, use_cos_attn=True, use_v2_norm_placement=True))
+    try:
+        model, cfg, spec, x, y = _setup_seeded("_paper_full", 21)
+    finally:
+        del CASES["_paper_full"]
+    names = [n for n, _ in model.named_parameters()]
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.endswith("attn_mask")}
+    for n in names:
+        sd[n].requires_grad_(True)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    OM.seg_loss(OM.forward(sd, types.SimpleNamespace(**cfg), types.SimpleNamespace(**spec), x), y).backward()
+    ref = {n: sd[n].grad for n in names}
+    model = model.to(DEV).train()
+    xg, yg = x.to(DEV), y.to(DEV)
+    report = []
+    # three families: the two that are cancelling sums over every score of a head (d logit_scale; the relative-position table, whose
+    # entries at the deep stages sum a few dozen windows of bf16-derived dS) are bounded on their own, as in tests/test_gpu_model.py
+    for dtype, tol, tol_table, tol_scale_param in ((torch.float32, 3e-4, 5e-4, 5e-4), (torch.bfloat16, 8e-2, 0.2, 0.2)):  # observed 4.1e-5 / 1.4e-4 / 8.3e-5 and 5.2e-2 / 1.1e-1 / 7.0e-2
+        model.compute_dtype = dtype
+        model.zero_grad(set_to_none=True)
+        seg_loss(model(xg), yg).backward()
+        worst, worst_tb, worst_ls, rms_all = ("", 0.0), ("", 0.0), ("", 0.0), []
+        for n, p_ in model.named_parameters():
+            assert p_.grad is not None, n
+            e = errors(p_.grad.float().cpu(), ref[n])
+            rms_all.append(e["rms_err"])
+            if n.endswith("logit_scale"):
+                if e["scale_err"] > worst_ls[1]:
+                    worst_ls = (n, e["scale_err"])
+            elif n.endswith("relative_position_bias_table"):
+                if e["scale_err"] > worst_tb[1]:
+                    worst_tb = (n, e["scale_err"])
+            elif e["scale_err"] > worst[1]:
+                worst = (n, e["scale_err"])
+        tag = "fp32" if dtype == torch.float32 else "bf16"
+        report.append(f"{tag}: worst max|a-b|/max|b| {worst[1]:.2e} ({worst[0]}), rel-pos tables {worst_tb[1]:.2e} ({worst_tb[0]}), "
+                      f"d logit_scale {worst_ls[1]:.2e} ({worst_ls[0]}), median rms {sorted(rms_all)[len(rms_all) // 2]:.2e}")
+        assert worst[1] <= tol, (tag, worst)
+        assert worst_tb[1] <= tol_table, (tag, worst_tb)
+        assert worst_ls[1] <= tol_scale_param, (tag, worst_ls)
+    conftest.NOTES.append(f"paper_T_ring_cos_v2_nside256_bp8_FULL parameter gradients vs the ORACLE's autograd ({len(names)} tensors): " + "; ".join(report))
+
+
 # ----------------------------------------------------------------------------- configs[2] at its FULL size: the BACKWARD
 def _param_groups(model):
     """Parameter names grouped the way the network is staged: one finite-difference direction per group, so that an error in a
