@@ -1787,7 +1787,7 @@ def fused_mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, post_norm=False, row_scale=No
     factor `row_scale` ([B] or None) ride in the same launch -- x + rs * LayerNorm(drop(fc2(drop(gelu(fc1(x))))))."""
     stoch = None
     if row_scale is not None or drop_p:
-        ex = _extras(x, row_scale, drop_p, None)
+        ex = _extras(x, row_scale, drop_p, 0)  # (0: no seed drawn here -- the two below are this block's whole share of the host seed stream)
         seed_h, seed_o = seeds if seeds is not None else ((_draw_seed(), _draw_seed()) if drop_p else (0, 0))
         stoch = (ex[0], ex[1], ex[2], int(seed_h), int(seed_o))
     return FusedMlpBlockFn.apply(x, ln_w, ln_b, w1, b1, w2, b2, bool(post_norm), stoch)

@@ -344,3 +344,55 @@ def test_fused_mlp_block_stochastic_vs_oracle_and_composition(C, drop_p, with_pa
         assert_close(gp_f[k], gp_c[k], GRAD_TOL[BF], tag + f" d{k} vs composition")
     if with_path:  # a dropped sample passes x through unchanged
         assert torch.equal(out_f[0], t["x"].view(B, per, C)[0])
+
+
+def test_model_with_paper_drop_rates_fused_and_composed_mlp_agree():
+    """The train-mode fused Mlp block inside the model (v2 placement, drop_rate = attn_drop_rate = drop_path_rate = 0.1, the paper's
+    rates): with the host seed stream and torch's CUDA generator reset, the run that takes `hs_mlp_fused_drop_*` at stage 0 and the run
+    on the composition (`ops.FUSED_MLP = False`) draw the same seeds in the same order and the same DropPath factors -- logits and every
+    parameter gradient agree to bf16 rounding; and the fused path was actually taken."""
+    from heal_swin_amd import ops
+    from heal_swin_amd.data_spec import DataSpec
+    from heal_swin_amd.models_torch.swin_hp_transformer import SwinHPTransformerConfig, SwinHPTransformerSys
+    cfg = dict(patch_size=4, window_size=64, shift_size=4, shift_strategy="ring_shift", rel_pos_bias="flat", embed_dim=96,
+               depths=[2, 2], num_heads=[3, 6], mlp_ratio=4.0, qkv_bias=True, qk_scale=None, use_cos_attn=True, drop_rate=0.1,
+               attn_drop_rate=0.1, drop_path_rate=0.1, use_v2_norm_placement=True, ape=False)
+    spec = dict(dim_in=8 * 16 * 16, f_in=3, f_out=12, base_pix=8, class_names=[])
+    torch.manual_seed(0)
+    model = SwinHPTransformerSys(SwinHPTransformerConfig(**cfg), DataSpec(**spec)).to(DEV).train()
+    model.compute_dtype = BF
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randint(0, 256, (4, 3, spec["dim_in"]), generator=g, device=DEV).float()
+    dy = torch.randn(4, 12, spec["dim_in"], generator=g, device=DEV)
+    calls = []
+    orig = ops.lib.hs_mlp_fused_drop_fwd
+
+    def run(fused):
+        prev = ops.FUSED_MLP
+        ops.FUSED_MLP = fused
+        try:
+            torch.manual_seed(1234)  # the CPU stream of ops._draw_seed and the CUDA generator of DropPath.sample_scale
+            model.zero_grad(set_to_none=True)
+            y = model(x)
+            y.backward(dy)
+            return y.detach().float(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+        finally:
+            ops.FUSED_MLP = prev
+
+    class Spy:  # counts the launches of the stochastic fused kernel without changing them
+        def __call__(self, *a):
+            calls.append(1)
+            return orig(*a)
+    ops.lib.hs_mlp_fused_drop_fwd = Spy()
+    try:
+        y_f, g_f = run(True)
+    finally:
+        ops.lib.hs_mlp_fused_drop_fwd = orig
+    assert len(calls) == 4, f"stage 0 (2 encoder + 2 decoder blocks) should take the fused train-mode Mlp block, took it {len(calls)} times"
+    y_c, g_c = run(False)
+    y_f2, _ = run(True)
+    assert torch.equal(y_f, y_f2)  # same seeds, same masks: the stochastic step is reproducible
+    assert_close(y_f, y_c, TOL[BF], "paper drop rates: logits, fused vs composed Mlp")
+    for n in g_f:
+        tol = 8e-2 if n.endswith(("logit_scale", "relative_position_bias_table")) else 4e-2
+        assert_close(g_f[n], g_c[n], tol, f"paper drop rates: d{n}, fused vs composed Mlp")
