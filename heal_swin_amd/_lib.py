@@ -39,6 +39,9 @@ _SIGNATURES = {
     "hs_rel_bias_scatter_grad_sorted_add": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_cos_head_scale_fwd": [c_ptr, c_ptr, c_int, c_ptr],
     "hs_cos_head_scale_bwd": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr],
+    "hs_rel_bias_gather_many": [c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr],
+    "hs_rel_bias_scatter_grad_sorted_many": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr],
+    "hs_cos_head_scale_many": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr],
     "hs_rel_bias_scatter_grad": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_rel_bias_scatter_grad_sorted": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "hs_window_attn_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,

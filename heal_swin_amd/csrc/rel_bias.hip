@@ -65,9 +65,130 @@ __global__ void __launch_bounds__(64) cos_scale_kernel(const float* __restrict__
     }
 }
 
+// ---- all attention blocks of a model in one launch (T @ nside 128 is bound by its ~600 launches per step: 2 x 22 of them were these)
+constexpr int kManyMax = 48;
+struct GatherJobs {
+    const float* table[kManyMax];
+    int heads[kManyMax], first_head[kManyMax];  // bias of job j = base + first_head[j] * ws2
+};
+__global__ void rel_bias_gather_many_kernel(GatherJobs jobs, const int32_t* __restrict__ rel_idx, float* __restrict__ base, int ws2) {
+    const int j = blockIdx.y, nH = jobs.heads[j];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nH * ws2) return;
+    const int h = e / ws2, ij = e - h * ws2;
+    base[(int64_t)jobs.first_head[j] * ws2 + e] = jobs.table[j][(int64_t)rel_idx[ij] * nH + h];
+}
+struct ScatterJobs {
+    const float* dbias[kManyMax];
+    float* dtable[kManyMax];
+    int heads[kManyMax], accumulate[kManyMax];
+};
+__global__ void __launch_bounds__(256) rel_bias_scatter_many_kernel(ScatterJobs jobs, const int32_t* __restrict__ order,
+                                                                    const int32_t* __restrict__ offsets, int rows, int ws2) {
+    const int j = blockIdx.y, nH = jobs.heads[j];
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (((blockIdx.x * blockDim.x) >> 4) >= rows * nH) return;  // (whole workgroup beyond this job's table)
+    const bool live = g < rows * nH;
+    const int t = live ? g / nH : 0, h = live ? g - t * nH : 0;
+    const int k0 = offsets[t], k1 = live ? offsets[t + 1] : k0;
+    const float* dbias = jobs.dbias[j];
+    float acc = 0.f;
+#pragma unroll 4
+    for (int k = k0 + sub; k < k1; k += 16) acc += dbias[(int64_t)h * ws2 + order[k]];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    float* dtable = jobs.dtable[j];
+    if (live && sub == 0) dtable[g] = jobs.accumulate[j] ? dtable[g] + acc : acc;
+}
+struct ScaleJobs {
+    const float* ls[kManyMax];
+    const float* dscale[kManyMax];
+    float* out[kManyMax];
+    int heads[kManyMax], accumulate[kManyMax];
+};
+__global__ void __launch_bounds__(64) cos_scale_many_kernel(ScaleJobs jobs) {
+    const int j = blockIdx.x, i = threadIdx.x;
+    if (i >= jobs.heads[j]) return;
+    const float l = jobs.ls[j][i], s = __expf(fminf(l, kLogitMax));
+    float* out = jobs.out[j];
+    if (!jobs.dscale[j]) out[i] = s;
+    else {
+        const float d = l <= kLogitMax ? jobs.dscale[j][i] * s : 0.f;
+        out[i] = jobs.accumulate[j] ? out[i] + d : d;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hs_rel_bias_gather_many(const void* const* tables, const int* heads, int count, const int32_t* rel_idx, float* bias_base,
+                            int table_rows, int window_size, void* stream) {
+    HS_CHECK_ARG(tables && heads && rel_idx && bias_base && count > 0 && table_rows > 0 && window_size > 0, "hs_rel_bias_gather_many: bad arguments");
+    const int ws2 = window_size * window_size;
+    int first = 0;
+    for (int j0 = 0; j0 < count; j0 += kManyMax) {
+        GatherJobs jobs{};
+        const int n = count - j0 < kManyMax ? count - j0 : kManyMax;
+        int max_heads = 0;
+        for (int j = 0; j < n; ++j) {
+            HS_CHECK_ARG(tables[j0 + j] && heads[j0 + j] > 0, "hs_rel_bias_gather_many: null table or no heads (job %d)", j0 + j);
+            jobs.table[j] = (const float*)tables[j0 + j];
+            jobs.heads[j] = heads[j0 + j];
+            jobs.first_head[j] = first;
+            first += heads[j0 + j];
+            max_heads = heads[j0 + j] > max_heads ? heads[j0 + j] : max_heads;
+        }
+        hipLaunchKernelGGL(rel_bias_gather_many_kernel, dim3((max_heads * ws2 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, jobs, rel_idx,
+                           bias_base, ws2);
+        HS_LAUNCH_CHECK("rel_bias_gather_many");
+    }
+    return HS_OK;
+}
+
+int hs_rel_bias_scatter_grad_sorted_many(const void* const* dbias, void* const* dtables, const int* heads, const int* accumulate, int count,
+                                         const int32_t* order, const int32_t* offsets, int table_rows, int window_size, void* stream) {
+    HS_CHECK_ARG(dbias && dtables && heads && accumulate && order && offsets && count > 0 && table_rows > 0 && window_size > 0,
+                 "hs_rel_bias_scatter_grad_sorted_many: bad arguments");
+    for (int j0 = 0; j0 < count; j0 += kManyMax) {
+        ScatterJobs jobs{};
+        const int n = count - j0 < kManyMax ? count - j0 : kManyMax;
+        int max_heads = 0;
+        for (int j = 0; j < n; ++j) {
+            HS_CHECK_ARG(dbias[j0 + j] && dtables[j0 + j] && heads[j0 + j] > 0, "hs_rel_bias_scatter_grad_sorted_many: null pointer or no heads (job %d)", j0 + j);
+            jobs.dbias[j] = (const float*)dbias[j0 + j];
+            jobs.dtable[j] = (float*)dtables[j0 + j];
+            jobs.heads[j] = heads[j0 + j];
+            jobs.accumulate[j] = accumulate[j0 + j];
+            max_heads = heads[j0 + j] > max_heads ? heads[j0 + j] : max_heads;
+        }
+        hipLaunchKernelGGL(rel_bias_scatter_many_kernel, dim3((table_rows * max_heads * 16 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, jobs,
+                           order, offsets, table_rows, window_size * window_size);
+        HS_LAUNCH_CHECK("rel_bias_scatter_grad_sorted_many");
+    }
+    return HS_OK;
+}
+
+int hs_cos_head_scale_many(const void* const* logit_scale, const void* const* dscale, void* const* out, const int* heads, const int* accumulate,
+                           int count, void* stream) {
+    HS_CHECK_ARG(logit_scale && out && heads && count > 0, "hs_cos_head_scale_many: bad arguments");
+    for (int j0 = 0; j0 < count; j0 += kManyMax) {
+        ScaleJobs jobs{};
+        const int n = count - j0 < kManyMax ? count - j0 : kManyMax;
+        for (int j = 0; j < n; ++j) {
+            HS_CHECK_ARG(logit_scale[j0 + j] && out[j0 + j] && heads[j0 + j] > 0 && heads[j0 + j] <= 64,
+                         "hs_cos_head_scale_many: null pointer or head count outside [1, 64] (job %d)", j0 + j);
+            jobs.ls[j] = (const float*)logit_scale[j0 + j];
+            jobs.dscale[j] = dscale ? (const float*)dscale[j0 + j] : nullptr;
+            jobs.out[j] = (float*)out[j0 + j];
+            jobs.heads[j] = heads[j0 + j];
+            jobs.accumulate[j] = accumulate ? accumulate[j0 + j] : 0;
+        }
+        hipLaunchKernelGGL(cos_scale_many_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, jobs);
+        HS_LAUNCH_CHECK("cos_head_scale_many");
+    }
+    return HS_OK;
+}
 
 int hs_rel_bias_gather(const float* table, const int32_t* rel_idx, float* bias, int table_rows, int num_heads,
                        int window_size, void* stream) {

@@ -160,6 +160,9 @@ class WindowAttention(nn.Module):
     def head_scale(self):
         """Per-head multiplier of the raw scores: exp(min(logit_scale, ln 100)) (ref :144-147) or the qk scale."""
         if self.use_cos_attn:
+            now = self.__dict__.get("_scale_now")  # made for all blocks at once by the model's forward (SwinHPTransformerSys._prefetch_attn_params)
+            if now is not None:
+                return now
             if self.logit_scale.is_cuda and self.logit_scale.dtype == torch.float32:
                 return ops.cos_head_scale(self.logit_scale)  # one launch forward, one backward
             return torch.exp(torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01))).reshape(-1)
@@ -171,6 +174,9 @@ class WindowAttention(nn.Module):
     def bias(self):
         if self.rel_pos_bias is None:
             return None
+        now = self.__dict__.get("_bias_now")  # made for all blocks at once by the model's forward
+        if now is not None:
+            return now
         return ops.RelPosBiasFn.apply(self.relative_position_bias_table, self._rel_idx32, self.window_size)
 
     def attend(self, x, window_size, idx, roll, labels, apply_proj_drop=True, residual_alias=False, residual=None):
@@ -817,6 +823,37 @@ class SwinHPTransformerSys(nn.Module):
             return torch.get_autocast_gpu_dtype()
         return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
+    def _prefetch_attn_params(self):
+        """The relative-position bias tiles and the cosine score scales of ALL blocks in one launch each (per window size), handed to
+        the blocks for this forward; the backward scatters / differentiates them in one launch each as well."""
+        sink = ops.RT.grad_sink
+        if not ops.BATCH_ATTN_PARAMS or self.config.use_checkpoint or (sink is not None and getattr(sink, "world", 1) > 1):
+            # (a checkpointed block recomputes its forward later, outside this call: it must see the same per-block tensors both times;
+            # under data parallelism the batched backward would report every block's table gradient at the END of the pass, and no
+            # gradient bucket could start its exchange before that: the per-block nodes keep the exchange overlapped with the backward)
+            return
+        mods = self.__dict__.get("_attn_mods")
+        if mods is None:
+            mods = self.__dict__["_attn_mods"] = [m for m in self.modules() if isinstance(m, WindowAttention)]
+        by_ws = {}
+        for m in mods:
+            t = getattr(m, "relative_position_bias_table", None)
+            if m.rel_pos_bias == "flat" and t is not None and t.is_cuda and t.dtype == torch.float32:
+                by_ws.setdefault((m.window_size, t.shape[0]), []).append(m)
+        for (ws, _), group in by_ws.items():
+            if len(group) > 1:
+                for m, b in zip(group, ops.rel_pos_bias_many(group[0]._rel_idx32, ws, [m.relative_position_bias_table for m in group])):
+                    m.__dict__["_bias_now"] = b
+        cos = [m for m in mods if m.use_cos_attn and m.logit_scale.is_cuda and m.logit_scale.dtype == torch.float32 and m.num_heads <= 64]
+        if len(cos) > 1:
+            for m, sc in zip(cos, ops.cos_head_scale_many([m.logit_scale for m in cos])):
+                m.__dict__["_scale_now"] = sc
+
+    def _clear_attn_params(self):
+        for m in self.__dict__.get("_attn_mods") or ():
+            m.__dict__.pop("_bias_now", None)
+            m.__dict__.pop("_scale_now", None)
+
     def forward_features(self, x):
         x = self.patch_embed(x)
         if self.config.ape:
@@ -838,9 +875,11 @@ class SwinHPTransformerSys(nn.Module):
         ops.RT.last_cast_cache = ops.RT.cast_cache
         try:
             with torch.autocast(device_type="cuda", enabled=False):
+                self._prefetch_attn_params()
                 x, x_downsample = self.forward_features(x.to(dt))
                 return self.decoder(x, x_downsample)
         finally:
+            self._clear_attn_params()
             ops.RT.cast_cache = prev
 
     def forward_seg_loss(self, x, labels, class_weights=None):
@@ -861,9 +900,11 @@ class SwinHPTransformerSys(nn.Module):
         ops.RT.last_cast_cache = ops.RT.cast_cache
         try:
             with torch.autocast(device_type="cuda", enabled=False):
+                self._prefetch_attn_params()
                 x, x_downsample = self.forward_features(x.to(dt))
                 return self.decoder(x, x_downsample, ce=(labels, w))
         finally:
+            self._clear_attn_params()
             ops.RT.cast_cache = prev
 
     def _param_casts(self, dt):

@@ -174,6 +174,113 @@ def cos_head_scale(logit_scale):
     return CosHeadScaleFn.apply(logit_scale)
 
 
+# ---- every attention block of a model in one launch each (the model calls these once per forward and hands the results to its blocks:
+# HEAL-SWIN-T at nside 128 is bound by its ~600 launches per step, 2 x 22 (+ 2 x 22 with cosine attention) of which were these)
+BATCH_ATTN_PARAMS = True  # (A/B: tools/policy_ab.py BATCH_ATTN_PARAMS=False)
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+class RelPosBiasManyFn(torch.autograd.Function):
+    """RelPosBiasFn for a list of tables that share one index (one window size): biases as views of ONE buffer, one gather launch;
+    the backward scatters every block's d bias in one launch, straight into the gradient sink where one is installed."""
+
+    @staticmethod
+    def forward(ctx, rel_idx, window_size, *tables):
+        _require_gpu(rel_idx, *tables)
+        assert rel_idx.dtype == torch.int32 and rel_idx.is_contiguous()
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == tables[0].shape[0] for t in tables)
+        rows, heads = tables[0].shape[0], [t.shape[1] for t in tables]
+        flat = torch.empty((sum(heads), window_size, window_size), dtype=torch.float32, device=rel_idx.device)
+        check(lib.hs_rel_bias_gather_many(_ptr_array([t.detach() for t in tables]), _int_array(heads), len(tables), ptr(rel_idx), ptr(flat), rows,
+                                          window_size, stream_ptr(rel_idx.device)), "hs_rel_bias_gather_many")
+        ctx.save_for_backward(rel_idx)
+        ctx.tables, ctx.meta = tables, (rows, heads, window_size)
+        ctx.set_materialize_grads(False)  # a block whose bias takes no gradient costs no job (and gets no zero gradient)
+        return tuple(flat.split(heads, 0))
+
+    @staticmethod
+    def backward(ctx, *dbiases):
+        (rel_idx,) = ctx.saved_tensors
+        rows, heads, ws = ctx.meta
+        order, offsets = _rel_idx_groups(rel_idx, rows)
+        grads = [None] * len(heads)
+        src, dst, nh, acc, sunk = [], [], [], [], []
+        for j, db in enumerate(dbiases):
+            if db is None:
+                continue
+            db = db.to(torch.float32).contiguous()
+            buf = _sink_buffer(ctx.tables[j])
+            if buf is not None:
+                sunk.append(ctx.tables[j])
+                out, a = buf, 1
+            else:
+                out, a = torch.empty((rows, heads[j]), dtype=torch.float32, device=db.device), 0
+                grads[j] = out
+            src.append(db), dst.append(out), nh.append(heads[j]), acc.append(a)
+        if src:
+            check(lib.hs_rel_bias_scatter_grad_sorted_many(_ptr_array(src), _ptr_array(dst), _int_array(nh), _int_array(acc), len(src), ptr(order),
+                                                           ptr(offsets), rows, ws, stream_ptr(src[0].device)), "hs_rel_bias_scatter_grad_sorted_many")
+        for t in sunk:  # (after the launch: a bucket's exchange may start the moment its last gradient is reported)
+            RT.grad_sink.deposited(t)
+        return (None, None, *grads)
+
+
+def rel_pos_bias_many(rel_idx, window_size, tables):
+    """[bias_j] with bias_j[h, i, j] = tables[j][rel_idx[i, j], h] -- all blocks in one launch (fp32 tables on the GPU)."""
+    return RelPosBiasManyFn.apply(rel_idx, int(window_size), *tables)
+
+
+class CosHeadScaleManyFn(torch.autograd.Function):
+    """CosHeadScaleFn for every cosine-attention block of a model: one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, *logit_scales):
+        _require_gpu(*logit_scales)
+        ls = [p.detach().reshape(-1) for p in logit_scales]
+        heads = [t.numel() for t in ls]
+        flat = torch.empty(sum(heads), dtype=torch.float32, device=ls[0].device)
+        outs = list(flat.split(heads))
+        check(lib.hs_cos_head_scale_many(_ptr_array(ls), None, _ptr_array(outs), _int_array(heads), None, len(ls), stream_ptr(flat.device)),
+              "hs_cos_head_scale_many")
+        ctx.params, ctx.heads = logit_scales, heads
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dscales):
+        grads = [None] * len(ctx.heads)
+        ls, ds, dst, nh, acc, sunk = [], [], [], [], [], []
+        for j, d in enumerate(dscales):
+            if d is None:
+                continue
+            p = ctx.params[j]
+            buf = _sink_buffer(p)
+            if buf is not None:
+                sunk.append(p)
+                out, a = buf.view(-1), 1
+            else:
+                out, a = torch.empty(ctx.heads[j], dtype=torch.float32, device=d.device), 0
+                grads[j] = out.view(p.shape)
+            ls.append(p.detach().reshape(-1)), ds.append(d.to(torch.float32).contiguous()), dst.append(out), nh.append(ctx.heads[j]), acc.append(a)
+        if ls:
+            check(lib.hs_cos_head_scale_many(_ptr_array(ls), _ptr_array(ds), _ptr_array(dst), _int_array(nh), _int_array(acc), len(ls),
+                                             stream_ptr(ls[0].device)), "hs_cos_head_scale_many (backward)")
+        for p in sunk:
+            RT.grad_sink.deposited(p)
+        return tuple(grads)
+
+
+def cos_head_scale_many(logit_scales):
+    return CosHeadScaleManyFn.apply(*logit_scales)
+
+
 _REL_IDX_GROUPS = {}
 
 

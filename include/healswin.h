@@ -139,6 +139,18 @@ int hs_rel_bias_scatter_grad_sorted_add(const float* dbias, const int32_t* order
  * (overwritten, or added to when accumulate != 0).  All [dev] f32[num_heads]. */
 int hs_cos_head_scale_fwd(const float* logit_scale, float* scale, int num_heads, void* stream);
 int hs_cos_head_scale_bwd(const float* logit_scale, const float* dscale, float* dlogit_scale, int num_heads, int accumulate, void* stream);
+/* The same three operations for ALL attention blocks of a model in one launch each (`count` jobs; host arrays of device pointers and
+ * per-job head counts; every job shares rel_idx / order / offsets, i.e. the window size):
+ *   hs_rel_bias_gather_many: bias of job j = bias_base + (heads[0] + ... + heads[j-1]) * Ws*Ws, f32[heads[j], Ws, Ws];
+ *   hs_rel_bias_scatter_grad_sorted_many: dtables[j] f32[T, heads[j]] overwritten, or added to where accumulate[j] != 0;
+ *   hs_cos_head_scale_many: dscale == NULL: out[j][h] = exp(min(logit_scale[j][h], ln 100)); else out[j][h] (+)= the gradient above
+ *   (heads[j] <= 64). */
+int hs_rel_bias_gather_many(const void* const* tables, const int* heads, int count, const int32_t* rel_idx, float* bias_base,
+                            int table_rows, int window_size, void* stream);
+int hs_rel_bias_scatter_grad_sorted_many(const void* const* dbias, void* const* dtables, const int* heads, const int* accumulate, int count,
+                                         const int32_t* order, const int32_t* offsets, int table_rows, int window_size, void* stream);
+int hs_cos_head_scale_many(const void* const* logit_scale, const void* const* dscale, void* const* out, const int* heads, const int* accumulate,
+                           int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused  shift -> window_partition -> attention core -> window_reverse -> shift_back.

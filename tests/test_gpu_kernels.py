@@ -871,3 +871,42 @@ def test_rel_bias_scatter_grad_sorted_add_accumulates():
     acc = torch.full((rows, nh), 2.0, device=DEV)
     check(lib.hs_rel_bias_scatter_grad_sorted_add(ptr(dbias), ptr(order), ptr(offsets), ptr(acc), rows, nh, ws, None), "scatter add")
     assert torch.equal(acc, ref + 2.0)
+
+
+def test_batched_bias_gather_and_head_scale_equal_the_per_block_ops():
+    """hs_rel_bias_gather_many / hs_rel_bias_scatter_grad_sorted_many / hs_cos_head_scale_many (all attention blocks of a model in one
+    launch each, `SwinHPTransformerSys._prefetch_attn_params`) against the per-block entry points: identical values, identical gradients
+    -- also when some blocks' outputs are unused -- with different head counts per block (the stages of a model)."""
+    ops, _, _ = _mods()
+    from oracle import tables as OT
+    ws = 64
+    rel = torch.from_numpy(OT.rel_pos_index(ws).astype(np.int32).reshape(-1)).to(DEV)
+    rows = int(rel.max()) + 1
+    g = torch.Generator(device=DEV).manual_seed(2)
+    heads = [3, 3, 6, 12, 24, 4]
+    tabs = [torch.randn(rows, h, generator=g, device=DEV).requires_grad_(True) for h in heads]
+    tabs2 = [t.detach().clone().requires_grad_(True) for t in tabs]
+    many = ops.rel_pos_bias_many(rel, ws, tabs)
+    single = [ops.RelPosBiasFn.apply(t, rel, ws) for t in tabs2]
+    dys = [torch.randn(h, ws, ws, generator=g, device=DEV) for h in heads]
+    for a, b in zip(many, single):
+        assert torch.equal(a, b)
+    used = [0, 2, 3, 5]  # (blocks 1 and 4 take no gradient)
+    torch.autograd.backward([many[j] for j in used], [dys[j] for j in used])
+    torch.autograd.backward([single[j] for j in used], [dys[j] for j in used])
+    for j, (a, b) in enumerate(zip(tabs, tabs2)):
+        if j in used:
+            assert torch.equal(a.grad, b.grad), j
+        else:
+            assert a.grad is None and b.grad is None
+    ls = [torch.randn(h, 1, 1, generator=g, device=DEV).mul(2).add(3).requires_grad_(True) for h in heads]  # some beyond ln 100
+    ls2 = [t.detach().clone().requires_grad_(True) for t in ls]
+    sm = ops.cos_head_scale_many(ls)
+    ss = [ops.cos_head_scale(t) for t in ls2]
+    ds = [torch.randn(h, generator=g, device=DEV) for h in heads]
+    for a, b in zip(sm, ss):
+        assert torch.equal(a, b)
+    torch.autograd.backward(list(sm), ds)
+    torch.autograd.backward(ss, ds)
+    for a, b in zip(ls, ls2):
+        assert torch.equal(a.grad, b.grad)

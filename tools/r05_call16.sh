@@ -1,14 +1,17 @@
 #!/bin/bash
-set -u
-cd "$GRAFT_REPO_ROOT"
-Q="--workload T256 --no-cpu-baseline --no-fp32-companion --no-pmc-traffic --no-graph-companion --no-companions"
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_pd && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pd -o t -- python $GRAFT_REPO_ROOT/bench.py $Q --steps 10 --warmup 3 --paper-drop-rates > /dev/null 2>&1
-cp $(find /tmp/prof_pd -name '*kernel_stats.csv' | head -1) $GRAFT_REPO_ROOT/gpurun_out/r05_d_T256_paperdrop_kernel_stats.csv
-python $GRAFT_REPO_ROOT/tools/prof_summary.py $GRAFT_REPO_ROOT/gpurun_out/r05_d_T256_paperdrop_kernel_stats.csv 13 | head -8
-python - <<PY
-import csv
-rows=sorted(csv.DictReader(open("$GRAFT_REPO_ROOT/gpurun_out/r05_d_T256_paperdrop_kernel_stats.csv")), key=lambda r:-int(r["TotalDurationNs"]))
-for r in rows[:40]:
-    if "layernorm" in r["Name"] or "gemm_nt" in r["Name"]:
-        print(f"{int(r['TotalDurationNs'])/13e6:8.3f} {int(r['Calls'])/13:7.1f} {int(r['TotalDurationNs'])/int(r['Calls'])/1e3:9.1f}  {r['Name'][:110]}")
-PY
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/r05_call16; mkdir -p $O
+timeout 2000 python -m pytest tests/test_gpu_model.py tests/test_gpu_graphs.py tests/test_gpu_parallel.py tests/test_gpu_training.py tests/test_gpu_optim.py tests/test_gpu_deferred.py tests/test_gpu_attn_module.py -x -q -m gpu > $O/tests.txt 2>&1
+tail -3 $O/tests.txt
+X="--steps 20 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --no-kernel-timing"
+run() { tag=$1; shift; "$@" 2>$O/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d['value'])"; }
+for rep in 1 2; do
+run t128_graph_batched python bench.py --workload T128 $X --graph
+run t128_graph_perblock python tools/policy_ab.py BATCH_ATTN_PARAMS=False -- --workload T128 $X --graph
+done
+run t128_eager_batched python bench.py --workload T128 $X
+run t128_eager_perblock python tools/policy_ab.py BATCH_ATTN_PARAMS=False -- --workload T128 $X
+run t256_batched python bench.py --workload T256 $X
+run t256_perblock python tools/policy_ab.py BATCH_ATTN_PARAMS=False -- --workload T256 $X
+run b256_batched python bench.py --workload B256 $X
+run b256_perblock python tools/policy_ab.py BATCH_ATTN_PARAMS=False -- --workload B256 $X
