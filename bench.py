@@ -875,7 +875,16 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
             rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:  # noqa: BLE001
             rccl_version = None
+        # one more (untimed) step with the sink's timeline on: when, in milliseconds after the step began, did each gradient bucket
+        # start its exchange (from a hook during the backward, or only in finish()), and when had all of them been waited for
+        dp.record_timeline(True)
+        t_begin = torch.cuda.Event(enable_timing=True)
+        t_begin.record()
+        step()
+        timeline = dp.timeline_ms(t_begin)
+        dp.record_timeline(False)
         rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl_version,
+                "bucket_timeline_rank0": timeline,
                 "step_ms_per_rank": step_ms_per_rank, "buckets": len(dp.buckets),
                 "allreduce_bytes_per_step": nbytes, "allreduce_ms_per_step_standalone_per_rank": [round(v, 3) for v in ms],
                 "allreduce_bus_GBps": 2 * (world - 1) / world * nbytes / (max(ms) * 1e-3) / 1e9,

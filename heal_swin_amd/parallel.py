@@ -59,6 +59,7 @@ class GradBucketAllReduce:
         self._sync = True       # False inside no_sync()
         self._reduced = False   # a bucket has been exchanged since the gradients were last zeroed
         self._stepped = False   # an attached optimizer has stepped since the last exchange
+        self.timeline, self._in_finish = None, False  # record_timeline(): (bucket, event, "hook" | "finish") per exchange of a pass
         self._reset_pass()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._direct = False
@@ -278,6 +279,10 @@ class GradBucketAllReduce:
         elif not self._avg_in_collective:
             flat.mul_(1.0 / self.world)  # average, as DDP does (gloo has no AVG op)
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM  # RCCL averages inside the all-reduce
+        if self.timeline is not None and flat.is_cuda:  # (diagnostic: when did this bucket become ready, from a hook or only in finish()?)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timeline.append((b, ev, "finish" if self._in_finish else "hook"))
         self._works.append((b, dist.all_reduce(buf, op=op, group=self.group, async_op=True)))
         self._launched[b] = True
         self._reduced = True
@@ -290,18 +295,36 @@ class GradBucketAllReduce:
         if self._direct:
             self._flush_reductions()
         if self._exchange and self._sync:
-            for b, left in enumerate(self._pending):
-                if self._launched[b]:
-                    continue
-                if 0 < left < self._counts[b] and self._pass_open:
-                    raise RuntimeError("a gradient bucket was only partially produced; unused parameters are not supported")
-                # untouched in this pass (parameters without gradient, or gradients accumulated under no_sync() earlier)
-                self._launch(b)
+            self._in_finish = True
+            try:
+                for b, left in enumerate(self._pending):
+                    if self._launched[b]:
+                        continue
+                    if 0 < left < self._counts[b] and self._pass_open:
+                        raise RuntimeError("a gradient bucket was only partially produced; unused parameters are not supported")
+                    # untouched in this pass (parameters without gradient, or gradients accumulated under no_sync() earlier)
+                    self._launch(b)
+            finally:
+                self._in_finish = False
         for b, w in self._works:
             w.wait()
             if self._comm is not None:
                 self.buckets[b].copy_(self._comm[b])
+        if self.timeline is not None and self.buckets and self.buckets[0].is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()  # (the current stream has waited for every exchange: the optimizer may start here)
+            self.timeline.append((-1, ev, "exchanged"))
         self._reset_pass()
+
+    def record_timeline(self, on=True):
+        """Diagnostic for multi-GPU runs: with `on`, every bucket exchange of the following passes records an event on the compute
+        stream at the moment it is launched (from a gradient hook during the backward, or only in finish()), and finish() one when
+        every exchange has been waited for; `timeline_ms(start_event)` turns them into milliseconds since a caller's event."""
+        self.timeline = [] if on else None
+
+    def timeline_ms(self, start):
+        torch.cuda.synchronize()
+        return [dict(bucket=b, ms=round(start.elapsed_time(ev), 3), launched_from=where) for b, ev, where in (self.timeline or [])]
 
     def remove(self):
         for h in self._hooks:
