@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/r05_call16; mkdir -p $O
+O=gpurun_out/ab_batched_attn_params; mkdir -p $O
 timeout 2000 python -m pytest tests/test_gpu_model.py tests/test_gpu_graphs.py tests/test_gpu_parallel.py tests/test_gpu_training.py tests/test_gpu_optim.py tests/test_gpu_deferred.py tests/test_gpu_attn_module.py -x -q -m gpu > $O/tests.txt 2>&1
 tail -3 $O/tests.txt
 X="--steps 20 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --no-kernel-timing"

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/r05_call8; mkdir -p $O
+O=gpurun_out/ab_fused_stage0_T; mkdir -p $O
 X="--steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic"
 run() { tag=$1; shift; "$@" 2>$O/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d['value'])"; }
 run t256_fused python bench.py --workload T256 $X

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-shape policy A/B for the stage-1 / stage-2 bias products (T256 and B256)
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/r05_call5; mkdir -p $O
+O=gpurun_out/ab_gemm_shape_table; mkdir -p $O
 X="--steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --kernel-table"
 B="--workload T256 $X"
 python bench.py $B > $O/t256_base.json 2> $O/t256_base.err

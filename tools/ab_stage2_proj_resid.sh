@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/r05_call11; mkdir -p $O
+O=gpurun_out/ab_stage2_proj_resid; mkdir -p $O
 X="--workload B256 --steps 10 --warmup 3 --no-companions --no-cpu-baseline --no-fp32-companion --no-graph-companion --no-pmc-traffic --kernel-table"
 run() { tag=$1; shift; "$@" 2>$O/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['ms_per_step'], d['value'])"; }
 run b256_base python bench.py $X

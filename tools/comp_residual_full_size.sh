@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/r05_call12; mkdir -p $O
+O=gpurun_out/comp_residual_full_size; mkdir -p $O
 HS_COMP_RESIDUAL=1 timeout 1500 python -m pytest tests/test_gpu_baseline_configs.py -q -m gpu -k "headline_config_full_size_logits or paper_config_full_size_logits" > $O/comp_fullsize.txt 2>&1
 grep "FULL\[" $O/comp_fullsize.txt | grep "bf16\]" | cut -c1-420
 tail -2 $O/comp_fullsize.txt
