@@ -726,6 +726,15 @@ def fold_gemm_tags(agg):
 def run_workload(ctx, dtype_name, steps, warmup, timing):
     """Build the model / optimizer / gradient exchange for `dtype_name`, run `warmup` untimed and `steps` timed steps
     (barrier + synchronize on both sides, MAX over ranks) and release everything again."""
+    undo = []  # process-wide registrations of this run (the library's replay counter): withdrawn on EVERY way out, a failed
+    try:       # capture included -- the companions swallow exceptions and carry on in this process
+        return _run_workload(ctx, dtype_name, steps, warmup, timing, undo)
+    finally:
+        for fn in reversed(undo):
+            fn()
+
+
+def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
     import gc
 
     import torch.distributed as dist
@@ -817,6 +826,11 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
             # every mask generator adds counter x odd constant to its seed, the captured step ends with counter += 1)
             from heal_swin_amd import _lib as _L
             epoch = torch.zeros(1, dtype=torch.int64, device=dev)
+
+            def _unregister(keep=epoch):  # (holds the tensor: the library's pointer is cleared before the memory can go)
+                torch.cuda.synchronize(dev)
+                _L.lib.hs_set_seed_epoch(None)
+            undo.append(_unregister)
             _L.check(_L.lib.hs_set_seed_epoch(_L.ptr(epoch)), "hs_set_seed_epoch")
             plain_step = step
 
@@ -898,11 +912,7 @@ def run_workload(ctx, dtype_name, steps, warmup, timing):
     del model, dp, opt, imgs, labels, loss, step
     if args.graph:
         del graph, static_loss, eager_step
-    if epoch is not None:
-        from heal_swin_amd import _lib as _L
-        sync()
-        _L.lib.hs_set_seed_epoch(None)
-        del epoch
+    del epoch  # (its registration with the library is withdrawn by run_workload's `undo`, which still holds the tensor)
     gc.collect()
     torch.cuda.empty_cache()
     return res

@@ -92,6 +92,22 @@ __global__ void __launch_bounds__(256) reduce_many_kernel(const ReduceTable t) {
 // partial rows of a LayerNorm backward: 64 workgroups x 32 rows per thread, as the dedicated kernel this replaced)
 int reduce_phases(int slices) { return slices <= 8 ? 1 : (slices <= 64 ? 4 : (slices <= 256 ? 16 : 64)); }
 
+// Does [dw, dw + n_w) or [db, db + count - n_w) overlap a destination of a pending job?
+bool overlaps_pending(const ReduceTable& t, const float* dw, int64_t n_w, const float* db, int64_t count) {
+    const float* dw_end = dw + n_w;
+    const float* db_end = db ? db + (count - n_w) : nullptr;
+    auto hit = [](const float* a0, const float* a1, const float* b0, const float* b1) { return a0 && b0 && a0 < b1 && b0 < a1; };
+    for (int i = 0; i < t.n; ++i) {
+        const ReduceJob& p = t.job[i];
+        const float* pw_end = p.dw + p.n_w;
+        const float* pb_end = p.db ? p.db + (p.count - p.n_w) : nullptr;
+        if (hit(dw, dw_end, p.dw, pw_end) || hit(dw, dw_end, p.db, pb_end) || hit(db, db_end, p.dw, pw_end) ||
+            hit(db, db_end, p.db, pb_end))
+            return true;
+    }
+    return false;
+}
+
 }  // namespace
 
 static int flush_locked(hipStream_t s) {
@@ -116,12 +132,17 @@ int reduce_pending(hipStream_t s) {
     return it == g_queues.end() ? 0 : it->second.n;
 }
 
-// Queue (or, when the queue is full, flush first and then queue) one reduction; `s` is the stream of the producing launch.
+// Queue (or, when the queue is full or holds a job with an overlapping destination, flush first and then queue) one reduction; `s` is the stream of the producing launch.
 int reduce_defer(const float* part, int64_t in_stride, int slices, int64_t n_w, int64_t count, float* dw, float* db, int accumulate,
                  hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_mutex);
     ReduceTable& t = g_queues[s];
-    if (t.n == kMaxJobs) {
+    // The jobs of one flush run side by side in ONE launch and read-modify-write their destinations without atomics: two pending
+    // jobs must never share a destination element (the three bf16x3 products of an fp32 weight gradient, a parameter used twice
+    // in one backward, micro-batches accumulated without a flush in between).  A job that overlaps a pending one therefore
+    // flushes the queue first -- the earlier sum is then stream-ordered before it, as with immediate reductions.
+    const bool clash = t.n == kMaxJobs || overlaps_pending(t, dw, n_w, db, count);
+    if (clash) {
         if (int st = flush_locked(s)) return st;
     }
     ReduceJob& q = t.job[t.n];
@@ -145,6 +166,13 @@ int reduce_defer(const float* part, int64_t in_stride, int slices, int64_t n_w, 
 // order, so a gradient does not depend on whether its sum was queued.
 int reduce_now(const float* part, int64_t in_stride, int slices, int64_t n_w, int64_t count, float* dw, float* db, int accumulate,
                hipStream_t s) {
+    {  // a queued sum into the same destination must land first (stream order = issue order, as without deferral)
+        std::lock_guard<std::mutex> lock(g_mutex);
+        auto it = g_queues.find(s);
+        if (it != g_queues.end() && it->second.n && overlaps_pending(it->second, dw, n_w, db, count)) {
+            if (int st = flush_locked(s)) return st;
+        }
+    }
     ReduceTable t{};
     ReduceJob& q = t.job[0];
     q.part = part;

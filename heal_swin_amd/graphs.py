@@ -50,6 +50,13 @@ class GraphedTrainStep:
             self._epoch = torch.zeros(1, dtype=torch.int64, device=self.inputs.device)
             _lib.check(_lib.lib.hs_set_seed_epoch(_lib.ptr(self._epoch)), "hs_set_seed_epoch")
 
+        try:
+            self._warm_up_and_capture(warmup)
+        except BaseException:
+            self.close()  # a failed warm-up / capture must not leave the library pointing at this object's counter
+            raise
+
+    def _warm_up_and_capture(self, warmup):
         # warm-up on a side stream (PyTorch's capture protocol): lazy initialisations -- kernel attributes, the bf16 weight
         # shadows, optimizer state, the allocator's blocks -- happen here, not inside the capture
         side = torch.cuda.Stream(device=self.inputs.device)

@@ -1334,12 +1334,14 @@ class LinearFn(torch.autograd.Function):
                 x3.record_stream(aw.stream)
             with _timed("linear_wgrad bf16x3", dev, 3 * 2 * rows * (n_out + k_in), 6 * rows * n_out * k_in):
                 for i, (yo, xo, dbp) in enumerate(((0, 0, db32), (0, 2 * k_in, None), (2 * n_out, 0, db32))):
-                    if defer and i:  # (a queued sum reads its partial records at the flush: one workspace per product)
-                        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+                    # the three sums share dw32 (two of them db32): jobs of one hs_reduce_flush launch run side by side and would
+                    # race on it, so only the LAST product's sum is queued -- the first two land at once, in stream order, and
+                    # the workspace is free again when the next product writes it
+                    d = defer if i == 2 else 0
                     check(lib.hs_linear_wgrad_ld(ptr(dy3), 3 * n_out, yo, ptr(x3), 3 * k_in, xo, ptr(dw32), ptr(dbp), ptr(ws), rows,
-                                                 n_out, k_in, (1 if (accumulate or i) else 0) | defer, stream_ptr(dev)), "hs_linear_wgrad_ld")
-                    if defer:
-                        _defer_keep(dev, ws)
+                                                 n_out, k_in, (1 if (accumulate or i) else 0) | d, stream_ptr(dev)), "hs_linear_wgrad_ld")
+                if defer:
+                    _defer_keep(dev, ws)
             return dw32, db32
         with _timed("linear_wgrad", dev, x2.element_size() * rows * (n_out + k_in), 2 * rows * n_out * k_in):
             if gelu_x:  # dW = dY^T gelu(x2): the activation is applied to the operand fragments inside the kernel

@@ -18,7 +18,7 @@ graph replay pass `lr` as a 0-dim CUDA tensor and update it in place), `state_di
 """
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check, lib, ptr, stream_ptr
 
 
@@ -46,7 +46,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._lowp_view = {}
         with torch.no_grad():
             for b, g in enumerate(grad_sink.buckets):
-                P = torch.empty_like(g)
+                P = torch.zeros_like(g)  # (alignment gaps between parameters stay finite under the Adam arithmetic)
                 M, V = torch.zeros_like(g), torch.zeros_like(g)
                 S = torch.empty_like(g, dtype=self.lowp_dtype) if self.lowp_dtype is not None else None
                 for p in grad_sink.params:
@@ -98,6 +98,9 @@ class FlatAdam(torch.optim.Optimizer):
                                    float(b1), float(b2), float(grp["eps"]), float(grp["weight_decay"]),
                                    int(grp["decoupled_weight_decay"]), ptr(self._step), s), "hs_adam_step")
         check(lib.hs_adam_advance(ptr(self._step), s), "hs_adam_advance")
+        # the update went through raw pointers (no parameter `_version` moved): caches keyed by weight contents -- the bf16x3
+        # splits of fp32 weights, ops._weight_split -- are told here, also for layers used outside a model's forward
+        ops.RT.weight_epoch += 1
         cache = None if self._model is None else self._model.__dict__.get("_cast_cache")
         if cache is not None:
             cache.mark_refreshed_externally()
@@ -113,11 +116,14 @@ class FlatAdam(torch.optim.Optimizer):
             for p in self.param_groups[0]["params"]:
                 new, old = self.state.get(p, {}), keep[id(p)]
                 for k in ("exp_avg", "exp_avg_sq"):
-                    if k in new and new[k] is not old[k]:
+                    if k not in new:
+                        old[k].zero_()  # an optimizer that never stepped: torch would start from zero moments
+                    elif new[k] is not old[k]:
                         old[k].copy_(new[k])
                 if "step" in new and new["step"] is not old["step"]:
                     step = new["step"]
                 self.state[p] = own[id(p)]
                 self.state[p].update(old)
-            if step is not None:
-                self._step.fill_(int(float(step)))
+            # no step count in the loaded state = a state that never stepped: moments (zeroed above) and bias correction agree
+            self._step.fill_(int(float(step)) if step is not None else 0)
+        ops.RT.weight_epoch += 1

@@ -330,6 +330,9 @@ class GradBucketAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        # queued parameter-gradient sums hold raw pointers into the buckets: land them before anything here can be freed
+        from . import ops as _ops_flush
+        _ops_flush.flush_reductions()
         if self._reserved_prev is not None:
             from . import _lib
             _lib.lib.hs_set_reserved_cus(self._reserved_prev)

@@ -349,7 +349,11 @@ int hs_linear_wgrad_gelu(const void* dy, const void* h, float* dw, float* dbias,
  * per-workgroup partial records into dw / dbias (dgamma / dbeta)" launch.  With HS_ACC_DEFER or-ed into `accumulate` that sum is
  * QUEUED on the call's stream instead of launched; hs_reduce_flush(stream) folds every queued sum of that stream in ONE launch
  * (deterministic order; the queue also flushes itself when it is full).  Contract of a deferring caller: the call's `workspace`
- * stays allocated and untouched until the flush, and nobody reads the gradient buffers before it.  The reference has no
+ * stays allocated and untouched until the flush, and nobody reads the gradient buffers before it.  The sums of one flush run
+ * side by side without atomics, so two PENDING sums never share a destination element: a call whose dw / dbias range overlaps
+ * a pending one (a parameter used twice in a backward, the bf16x3 products of an fp32 weight gradient, micro-batches without a
+ * flush in between) flushes the queue first, and so does an immediate (non-deferred) sum into such a range -- issue order is
+ * stream order either way.  Destination buffers must outlive the flush: flush before freeing gradient buckets.  The reference has no
  * counterpart (autograd of nn.Linear / nn.LayerNorm, models_torch/swin_hp_transformer.py:33-35, :116-118, :256-262): this is
  * how 340 launches per HEAL-SWIN-B training step become about 10.
  * ---------------------------------------------------------------------------------------------- */

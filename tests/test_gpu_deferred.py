@@ -160,3 +160,77 @@ def test_training_step_with_deferred_sums_equals_the_immediate_step():
         b = grads[True][1][k]
         scale = float(a.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 1e-5 * scale, (k, float((a - b).abs().max()), scale)
+
+
+def test_pending_sums_into_one_destination_do_not_race():
+    """Several queued (and immediate) sums into the SAME dw / db -- a parameter used twice in one backward, micro-batches without a
+    flush in between, the three bf16x3 products of an fp32 weight gradient: jobs of one flush launch run side by side without
+    atomics, so the queue flushes itself when a destination repeats; every contribution must arrive (include/healswin.h)."""
+    L = _lib()
+    lib, ptr = L.lib, L.ptr
+    g = torch.Generator(device=DEV).manual_seed(17)
+    rows, n_out, k_in = 16384, 256, 256
+    nws = int(lib.hs_linear_wgrad_workspace(rows, n_out, k_in))
+    dw, db = torch.zeros((n_out, k_in), device=DEV), torch.zeros(n_out, device=DEV)
+    other = torch.zeros((n_out, k_in), device=DEV)
+    ref_w, ref_b, keep = torch.zeros_like(dw), torch.zeros_like(db), []
+    for i, flag in enumerate((1 | L.HS_ACC_DEFER, 1 | L.HS_ACC_DEFER, 1, 1 | L.HS_ACC_DEFER, 1 | L.HS_ACC_DEFER)):
+        dy = torch.randn((rows, n_out), generator=g, device=DEV).to(torch.bfloat16)
+        x = torch.randn((rows, k_in), generator=g, device=DEV).to(torch.bfloat16)
+        ws = torch.empty(nws, dtype=torch.float32, device=DEV)
+        keep.append(ws)
+        L.check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), rows, n_out, k_in, flag, L.HS_BF16, _stream()),
+                "hs_linear_wgrad")
+        assert int(lib.hs_reduce_pending(_stream())) <= 1, "two sums into one destination were left pending together"
+        ref_w += dy.float().t() @ x.float()
+        ref_b += dy.float().sum(0)
+        if i == 0:  # an unrelated destination may share the flush
+            ws2 = torch.empty(nws, dtype=torch.float32, device=DEV)
+            keep.append(ws2)
+            L.check(lib.hs_linear_wgrad(ptr(dy), ptr(x), ptr(other), None, ptr(ws2), rows, n_out, k_in, 1 | L.HS_ACC_DEFER, L.HS_BF16,
+                                        _stream()), "hs_linear_wgrad")
+            assert int(lib.hs_reduce_pending(_stream())) == 2
+    L.check(lib.hs_reduce_flush(_stream()), "hs_reduce_flush")
+    assert float((dw - ref_w).abs().max()) <= 2e-3 * float(ref_w.abs().max())
+    assert float((db - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max())
+
+
+def test_fp32_training_step_with_deferred_sums_equals_autograd():
+    """fp32 activations = three bf16 products per weight gradient, all into one buffer (ops.LinearFn._wgrad_hip): under the gradient
+    sink with deferral ON (the bench's fp32 / depth_fp32 companions) the gradients must equal the ones plain autograd collects
+    without a sink -- a race between the three queued sums loses whole products (round-5 review)."""
+    from heal_swin_amd import ops
+    from heal_swin_amd.data_spec import DataSpec
+    from heal_swin_amd.models_torch.swin_hp_transformer import SwinHPTransformerConfig, SwinHPTransformerSys
+    from heal_swin_amd.parallel import GradBucketAllReduce
+    L = _lib()
+    spec = DataSpec(dim_in=12 * 32 * 32, f_in=3, f_out=12, base_pix=12, class_names=[])
+    cfg = SwinHPTransformerConfig(patch_size=4, window_size=64, shift_size=32, rel_pos_bias="flat", embed_dim=64, depths=[2, 2],
+                                  num_heads=[2, 4], drop_path_rate=0.0)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randint(0, 256, (2, 3, spec.dim_in), generator=g, device=DEV).float()
+    y = torch.randint(0, 12, (2, spec.dim_in), generator=g, device=DEV, dtype=torch.uint8)
+    assert ops.DEFER_REDUCTIONS, "the default is what the bench runs"
+    grads = {}
+    for sink in (False, True):
+        torch.manual_seed(0)
+        model = SwinHPTransformerSys(cfg, spec).to(DEV).train()
+        model.compute_dtype = torch.float32
+        dp = GradBucketAllReduce(model.parameters()) if sink else None
+        try:
+            if dp is not None:
+                dp.zero_grad()
+            loss = model.forward_seg_loss(x, y)
+            loss.backward()
+            if dp is not None:
+                dp.finish()
+                assert int(L.lib.hs_reduce_pending(_stream())) == 0
+            grads[sink] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters()})
+        finally:
+            if dp is not None:
+                dp.remove()
+    assert abs(grads[False][0] - grads[True][0]) <= 1e-6 * abs(grads[False][0])
+    for k, a in grads[False][1].items():
+        b = grads[True][1][k]
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()), scale)
