@@ -56,6 +56,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef HS_GEMM_EXP
 #define HS_GEMM_EXP 0
 #endif
+#ifndef HS_GEMM_STAGGER_CYCLES
+#define HS_GEMM_STAGGER_CYCLES 40000  // one 256 x 256 x 512 tile with a GELU epilogue (tools/gemm_trace.py)
+#endif
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RESID = 3 };
 __device__ constexpr uint32_t kOob = 0x7FFFFF00u;  // a byte offset outside every descriptor below
 constexpr int64_t kMaxRecords = 0x7FFFFE00;  // descriptors are clamped to this many bytes (tiles address < 2 GiB from their origin)
@@ -116,11 +119,20 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     constexpr bool HAS_IN = EPI == EPI_DGELU || EPI == EPI_RESID;
     constexpr bool RING = HS_GEMM_EPI_RING && HAS_IN && ALIAS && TM == 4 && TN == 2 && STAGE >= NW * 8192;
 #ifdef HS_GEMM_TRACE
-    constexpr int TRACE_LDS = NW * kTraceCap * 8;
+    // (the three-stage 256 x 128 tile has no room for the event buffers beside the bias slots: not traced)
+    constexpr int TRACE_LDS = NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096) + 2048 + NW * kTraceCap * 8 <= 163840 ? NW * kTraceCap * 8 : 0;
 #else
     constexpr int TRACE_LDS = 0;
 #endif
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096) + TRACE_LDS];  // stages (+ epilogue patches)
+    // LBIAS: the tile's BN bias values travel global -> LDS by one DMA piece of wave 0 when the ISSUE cursor enters the tile (two 1-KB
+    // slots by tile parity behind the stages) and the epilogue reads them with ds_read_b128.  A global load at the top of the
+    // epilogue is the youngest entry of the wave's in-order vmcnt queue: on the DMA-issuing waves it waited for the whole first
+    // k-step of the NEXT tile (64 KB from L2 / HBM) before row block 0 could start -- 3700 cycles per tile on the waves every
+    // barrier then waits for (profiles/r03_gemm_pass_overlap.txt: row block 0 8582 cycles on wave 0, 4878 on wave 7).
+    // (Not on the 128 x 128 tile: its two workgroups per CU use all 160 KB already.)
+    constexpr bool LBIAS = ALIAS && EPI != EPI_DGELU;
+    constexpr int BIAS_OFF = NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096), BIAS_LDS = LBIAS ? 2048 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BIAS_OFF + BIAS_LDS + TRACE_LDS];  // stages (+ epilogue patches) (+ bias slots)
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +144,15 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     const int id0 = xcd * p.per_xcd + lb;
     if (id0 >= id_end) return;
     const int nk1 = (p.k + 63) >> 6, nk2 = (p.k2 + 63) >> 6, nk = nk1 + nk2;
+#if HS_GEMM_EXP & 24
+    {  // measurement build: start phases of the workgroups of an XCD spread over one tile period (bit 3: two phases, bit 4: four),
+       // so that the epilogues (store bursts) of neighbouring CUs do not coincide
+        const int phases = (HS_GEMM_EXP & 16) ? 4 : 2;
+        const long long wait = (long long)(lb % phases) * (HS_GEMM_STAGGER_CYCLES / phases);
+        const long long t0 = clock64();
+        while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
 
     // ---- DMA lane mapping: LDS position q (16-B units inside a tile) = (super-row R = q / 16, physical chunk q % 16);
     // logical chunk = physical ^ (R & 15); tile row = 2 R + (logical >> 3), 16-byte column chunk = logical & 7
@@ -160,10 +181,21 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     int a_off[AJ], b_off[BJ];  // byte offset of this lane's (row, chunk) inside the tile, k-step 0
     int kseg = 0;              // bytes of a row of the current segment
     int a_ld32 = 0, b_ld32 = 0;  // (FAST) bytes of 32 operand rows
-    auto retarget = [&](int id, bool s2) {
+    int par_i = 0;               // (LBIAS) slot the next tile's bias goes to
+    __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.n * 4 : 0, 0x00020000);
+    auto retarget = [&](int id, bool s2, bool enter) {
         const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
         const int64_t m0 = (int64_t)tm * BM;
         const int n0 = tn * BN;
+        if constexpr (LBIAS) {
+            if (enter) {
+                // lanes beyond the tile's BN floats (and columns beyond n) read outside the descriptor: zeros
+                if (wave == 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (lds_void*)(smem + BIAS_OFF + par_i * 1024), 16,
+                                                             lane * 4 < BN ? (uint32_t)(lane * 16) : kOob, n0 * 4, 0, 0);
+                par_i ^= 1;
+            }
+        }
         const uint16_t* ap = s2 ? p.a2 : p.a;
         const uint16_t* bp = s2 ? p.b2 : p.b;
         const int64_t lda = s2 ? p.lda2 : p.lda, ldb = s2 ? p.ldb2 : p.ldb;
@@ -216,9 +248,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     // byte = R * 256 + ((((r & 1) * 8 + 2 ksub + h) ^ (R & 15)) << 4) = frag_base ^ (ksub << 5)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 #ifdef HS_GEMM_TRACE
-    const bool tr_on = p.trace && (blockIdx.x == 0 || blockIdx.x == 9);
+    const bool tr_on = TRACE_LDS > 0 && p.trace && (blockIdx.x == 0 || blockIdx.x == 9);
     int tr_n = 0;
-    const uint32_t tr_base = lds0 + NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096) + wave * kTraceCap * 8;
+    const uint32_t tr_base = lds0 + BIAS_OFF + BIAS_LDS + wave * kTraceCap * 8;
     auto TR = [&](int code) {
         if (tr_on && tr_n < kTraceCap) {
             const uint64_t t = (clock64() << 8) | (uint64_t)code;
@@ -340,8 +372,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     // compiler-visible LDS access beside the DMA queue would be preceded by s_waitcnt vmcnt(0) and stall the epilogue
     // behind the next tile's first loads.  Needs n % 8 == 0; otherwise (the 12-class head) the direct 8-byte form is used.
     const uint32_t own_rel = wave * 4096 + l31 * 128 + 8 * half;     // + ((chunk ^ (l31 & 7)) << 4), chunk = 4 j + g
+    // OUTPUT blocks are written with the two 8-byte halves of every 16-byte chunk exchanged in rows 8-15 and 24-31: rows r and r + 8
+    // of a 16-lane ds_write_b64 group share chunk slot and half otherwise (2-way conflict on every patch write: 1540 instead of
+    // 770 LDS cycles per row block and CU); the row view undoes it for free -- its row is lane / 8 + 8 t, so bit 3 is t & 1 and the
+    // odd t swap register halves
+    const uint32_t own_out_rel = wave * 4096 + l31 * 128 + 8 * (half ^ ((l31 >> 3) & 1));
     const uint32_t row_rel = wave * 4096 + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + t * 1024: row lane/8 + 8 t
-    auto epilogue = [&](int id, int buf_done) {
+    auto epilogue = [&](int id, int buf_done, int par_c) {
         const uint32_t patch_off = ALIAS ? buf_done * STAGE : NSTAGE * STAGE;  // byte offset of the patch area inside smem
         TR(10);
         if (ALIAS) __builtin_amdgcn_s_barrier();  // every wave is done reading the stage buffer the patches live in
@@ -362,6 +399,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         for (int jh = 0; jh < JH; ++jh) {
         const int ncol0 = n0 + wn * (BN / WN) + jh * 64;  // first of the 64 columns of this pass
         float4 bias4[TJ][4];
+        // (LBIAS: a column block's four float4 are read from the LDS slot where they are used -- 4 broadcast reads per block instead of
+        // 32 registers held across the pass, which the RESID epilogue of the 128 x 64 wave tile does not have)
+        const uint32_t baddr = lds0 + BIAS_OFF + par_c * 1024 + (wn * (BN / WN) + jh * 64 + 4 * half) * 4;
+        auto lds_bias = [&](int j, float4 (&b)[4]) {
+            u32x4 bq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(bq[g]) : "v"(baddr + (j * 32 + 8 * g) * 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b[g] = __builtin_bit_cast(float4, bq[g]);
+        };
+        if constexpr (LBIAS) {
+        } else {
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
@@ -369,6 +419,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                 const int n = ncol0 + j * 32 + 4 * half + 8 * g;
                 bias4[j][g] = (EPI != EPI_DGELU && p.bias && n < p.n) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
         // row-lane view of a block: lane -> (row lane/8 + 8 t, 16-byte chunk lane % 8).  The per-lane part of the byte offset is ONE
         // register; the row block / row group part is wave-uniform and rides in the instruction's scalar offset (it takes part
         // in the descriptor's range check like the vector part).  Per-(i, t) vector offsets were hoisted out of the tile loop
@@ -399,6 +450,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
             // ---- input block (h or the residual) in the own-lane view
             const uint32_t pbase = lds0 + patch_off + (RING ? (i & 1) * (NW * 4096) : 0);
             const uint32_t own_addr = pbase + own_rel, row_addr = pbase + row_rel;
+            const uint32_t own_out = lds0 + patch_off + (RING ? (i & 1) * (NW * 4096) : 0) + own_out_rel;
             u32x2 xin[TJ][4];
             if (HAS_IN) {
                 if (wide) {
@@ -444,7 +496,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
             u32x2 o1[TJ][4], o2[TJ][4];  // o1 -> c ; o2 -> aux (EPI_GELU only)
             {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
+                for (int j = 0; j < TJ; ++j) {
+                    if constexpr (LBIAS) lds_bias(j, bias4[j]);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int n = ncol0 + j * 32 + 4 * half + 8 * g;
@@ -460,13 +513,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                             return f32x2{rng.keep_lo(hh), rng.keep_hi(hh)};
                         };
                         if (EPI == EPI_GELU) {
+                            // h is packed here and kept (fp32) in the accumulator registers; the activation is computed from them
+                            // by make_o2 below, at the place in the block's sequence that the wave's role asks for
                             o1[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) {
-                                v[t] = gelu2(v[t]);
-                                if (DROP) v[t] *= drop2(t);
-                            }
-                            o2[j][g] = u32x2{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y)};
+                            a16[4 * g] = v[0].x; a16[4 * g + 1] = v[0].y; a16[4 * g + 2] = v[1].x; a16[4 * g + 3] = v[1].y;
+                            continue;
                         } else {
                             if (EPI == EPI_DGELU || EPI == EPI_RESID) {
 #pragma unroll
@@ -485,7 +536,41 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) a16[4 * g + r] = 0.f;
                     }
+                }
             }
+            auto make_o2 = [&]() {  // (EPI_GELU) aux = dropout(gelu(h)); clears the accumulators.  Four element pairs in lock step.
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int g0 = 0; g0 < 4; g0 += 2) {
+                        f32x16& a16 = acc[TJ * jh + j][i];
+                        f32x2 v[4] = {f32x2{a16[4 * g0], a16[4 * g0 + 1]}, f32x2{a16[4 * g0 + 2], a16[4 * g0 + 3]},
+                                      f32x2{a16[4 * g0 + 4], a16[4 * g0 + 5]}, f32x2{a16[4 * g0 + 6], a16[4 * g0 + 7]}};
+#if !(HS_GEMM_EXP & 4)  // (measurement build: bit 2 = no activation arithmetic, aux = h -- the floor of a two-output epilogue)
+                        // (four pairs in lock step, gelu2_n<4>, measured: no faster -- the block is bound by its patch round trips
+                        // and store issue, not by the chains' latency; profiles/r06_gemm_epilogue_experiments.txt)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = gelu2(v[t]);
+#endif
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg) {
+                            const int g = g0 + gg;
+                            if (DROP) {
+                                const int n = ncol0 + j * 32 + 4 * half + 8 * g;
+                                const uint32_t ck = rng.chunk_key((uint64_t)((m0 + ml) * p.n + n) >> 3);
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const uint32_t hh = ElemRng::pair_bits(ck, t == 0 ? (half ? ElemRng::kM2 : ElemRng::kM0) : (half ? ElemRng::kM3 : ElemRng::kM1));
+                                    v[2 * gg + t] *= f32x2{rng.keep_lo(hh), rng.keep_hi(hh)};
+                                }
+                            }
+                            o2[j][g] = u32x2{pack_bf16x2(v[2 * gg].x, v[2 * gg].y), pack_bf16x2(v[2 * gg + 1].x, v[2 * gg + 1].y)};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a16[4 * g + r] = 0.f;
+                        }
+                    }
+            };
+            TR(20);  // arithmetic of the block done
             // ---- outputs
             auto emit = [&](const __amdgpu_buffer_rsrc_t& rs, const u32x2 (&o)[TJ][4]) {
                 if (wide) {
@@ -493,16 +578,24 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                     for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            asm volatile("ds_write_b64 %0, %1" ::"v"(own_addr + (((4 * j + g) ^ (l31 & 7)) << 4)), "v"(o[j][g]) : "memory");
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(own_out + (((4 * j + g) ^ (l31 & 7)) << 4)), "v"(o[j][g]) : "memory");
                     u32x4 rws[4];
+                    // (rows 8-15 / 24-31 of the block = odd t: the chunk halves lie exchanged, own_out_rel -- ds_read2_b64 with the
+                    // two 8-byte offsets in reverse order returns them in place.  NOT a register swap after the read: hipcc put the
+                    // four v_mov straight behind the buffer_store_dwordx4 of the previous row group, over its data registers, and
+                    // lanes 12-15 of every 16 stored the NEW first dword (no hazard is listed for a store with an SGPR offset,
+                    // none is inserted; seen on gfx950 / ROCm 7.2, tests/test_gpu_gemm.py caught it))
                     asm volatile("ds_read_b128 %0, %1" : "=v"(rws[0]) : "v"(row_addr));
-                    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(rws[1]) : "v"(row_addr));
+                    asm volatile("ds_read2_b64 %0, %1 offset0:129 offset1:128" : "=v"(rws[1]) : "v"(row_addr));
                     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(rws[2]) : "v"(row_addr));
-                    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(rws[3]) : "v"(row_addr));
+                    asm volatile("ds_read2_b64 %0, %1 offset0:129 offset1:128" : "=v"(rws[3]) : "v"(row_addr + 2048));
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rws[0]), "+v"(rws[1]), "+v"(rws[2]), "+v"(rws[3]));
+                    TR(22);  // patch round trip done
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rws[t]), rs, rl_voff, row_soff(i, t), 0);
+                    // the data registers stay live across one wait state behind the last store (see above)
+                    asm volatile("s_nop 0" ::"v"(rws[0]), "v"(rws[1]), "v"(rws[2]), "v"(rws[3]));
                 } else {
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
@@ -514,8 +607,23 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                 }
             };
             if (EPI == EPI_GELU) {
-                if (p.c) emit(rc, o1);
-                emit(rx, o2);
+                // The two waves of a SIMD (w and w + NW / 2) take the outputs in OPPOSITE order: the GELU arithmetic is bound by the
+                // SIMD's VALU rate (~770 cycles per block and wave alone, twice that when both partners are in it), the h output is
+                // LDS patch + store issue (~1100) -- out of phase each hides under the other (tools/gemm_trace.py,
+                // profiles/r06_gemm_trace_epilogue_phases.txt)
+                if (NW == 8 && wave >= NW / 2) {
+                    make_o2();
+                    emit(rx, o2);
+                    TR(21);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p.c) emit(rc, o1);
+                } else {
+                    if (p.c) emit(rc, o1);
+                    TR(21);  // first output's stores issued
+                    __builtin_amdgcn_sched_barrier(0);
+                    make_o2();
+                    emit(rx, o2);
+                }
             } else {
                 emit(rc, o1);
             }
@@ -531,18 +639,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     const int stride = p.blocks_per_xcd;
     int id_i = id0, ks_i = 0;  // next step to issue
     int id_c = id0, ks_c = 0;  // step being computed
+    int par_c = 0;             // (LBIAS) slot that holds the bias of the tile being computed
     auto advance_issue = [&]() {
         ++ks_i;
         if (ks_i == nk) {
             ks_i = 0;
             id_i += stride;
-            if (id_i < id_end) retarget(id_i, nk1 == 0);
+            if (id_i < id_end) retarget(id_i, nk1 == 0, true);
         } else if (ks_i == nk1) {
-            retarget(id_i, true);
+            retarget(id_i, true, false);
         }
     };
     auto kb_of = [&](int ks) { return (ks >= nk1 ? ks - nk1 : ks) * 128; };
-    retarget(id_i, false);
+    retarget(id_i, false, true);
     constexpr int AHEAD = NSTAGE - 1, PIECES_ALL = AI + BI;
     int issued = 0;  // steps issued and not yet computed
 #pragma unroll
@@ -582,7 +691,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
         buf_free = buf_free + 1 == NSTAGE ? 0 : buf_free + 1;
         if (last) {
-            epilogue(id_c, buf_done);
+            epilogue(id_c, buf_done, par_c);
+            par_c ^= 1;
             drained = true;
             ks_c = 0;
             id_c += stride;

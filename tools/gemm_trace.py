@@ -73,6 +73,11 @@ def main():
                      (2, 10): "last k-step compute", (10, 11): "epilogue: alias barrier", (11, 12): "epilogue row block 0",
                      (12, 13): "epilogue row block 1", (13, 14): "epilogue row block 2", (14, 15): "epilogue row block 3",
                      (15, 3): "epilogue end -> next step", (13, 3): "epilogue end -> next step", (0, 3): "start"}
+            names.update({(11, 20): "row block 0: input wait + arithmetic", (12, 20): "row block 1: input wait + arithmetic",
+                          (13, 20): "row block 2: input wait + arithmetic", (14, 20): "row block 3: input wait + arithmetic",
+                          (20, 22): "arithmetic done -> patch round trip of the first output done", (22, 21): "4 row-segment stores issued (first output)",
+                          (21, 22): "patch round trip of the second output", (22, 12): "stores issued -> end of block 0",
+                          (22, 13): "stores issued -> end of block 1", (22, 14): "stores issued -> end of block 2", (22, 15): "stores issued -> end of block 3"})
             for key in sorted(seg):
                 v = seg[key]
                 print(f"   {key[0]:2d}->{key[1]:2d} {names.get(key, ''):48s} n={len(v):3d} median {statistics.median(v):8.0f} mean {statistics.mean(v):8.0f} max {max(v):7d} cycles")
