@@ -335,6 +335,13 @@ def main():
     ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
     ap.add_argument("--torch-adam", action="store_true",
                     help="step torch.optim.Adam(fused=True) instead of heal_swin_amd.optim.FlatAdam (same arithmetic; A/B runs)")
+    ap.add_argument("--strong-scaling", action="store_true",
+                    help="--batch is the GLOBAL batch, split over the ranks (BASELINE's 'batch=8 at 1/2/4/8' read as a fixed total; SURVEY 8d "
+                         "asks for both readings).  Default: --batch per GPU (weak scaling, the reference's per-process batch, train.py:34-41)")
+    ap.add_argument("--drop-in", action="store_true",
+                    help="INTEGRATION.md level 1 exactly: only the module is swapped -- autograd's own .grad accumulation (no gradient "
+                         "sink, torch's DistributedDataParallel when N > 1), nn.CrossEntropyLoss on the materialised logits, "
+                         "torch.optim.Adam as training/optimizer.py:57-66 builds it, eager")
     ap.add_argument("--reserved-cus", default="auto",
                     help="compute units the chip-filling launches leave free for RCCL (multiple of 8; auto: 16 when N > 1, else 0)")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient buckets")
@@ -347,6 +354,10 @@ def main():
         self_launch(args.gpus)  # does not return
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.strong_scaling:
+        if args.batch % world:
+            raise SystemExit(f"--strong-scaling: the global batch {args.batch} does not split over {world} ranks")
+        args.batch //= world  # from here on: images per GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     # test hook (tests/test_gpu_parallel.py): several ranks on ONE GPU over gloo exercise this script's multi-rank path on a
@@ -445,12 +456,15 @@ def main():
         out = {
             "metric": "images/sec fwd+bwd, HEAL-SWIN nside=256 seg, batch=8 at 1/2/4/8 MI355X",
             "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if args.strong_scaling else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}",
-                       "step": "fwd + CE loss + bwd + grad all-reduce + Adam" + ("" if args.unfused_loss else " (loss fused into the decoder tail: model.forward_seg_loss)"),
-                       "optimizer": "torch.optim.Adam(fused=True)" if args.torch_adam else "heal_swin_amd.optim.FlatAdam (torch.optim.Adam arithmetic on flat buffers)",
+                       "step": ("drop-in (INTEGRATION.md level 1): module swapped only -- fwd, nn.CrossEntropyLoss on the logits, bwd with autograd's "
+                                "own .grad accumulation" + (" inside torch DistributedDataParallel" if world > 1 else "") + ", torch.optim.Adam") if args.drop_in else
+                               "fwd + CE loss + bwd + grad all-reduce + Adam" + ("" if args.unfused_loss else " (loss fused into the decoder tail: model.forward_seg_loss)"),
+                       "optimizer": "torch.optim.Adam (training/optimizer.py:57-66)" if args.drop_in else
+                                    "torch.optim.Adam(fused=True)" if args.torch_adam else "heal_swin_amd.optim.FlatAdam (torch.optim.Adam arithmetic on flat buffers)",
                        "launch": "hip graph replay" if args.graph else "eager",
                        "params_M": res.params_m, "final_loss": res.loss, "peak_device_memory_GB": res.peak_gb,
                        "library_gemm_selection": gemm_selection},
@@ -512,6 +526,26 @@ def main():
         except Exception as e:  # noqa: BLE001
             out.setdefault('depth_fp32', {})
             out['depth_fp32'] = {**(out['depth_fp32'] if isinstance(out['depth_fp32'], dict) else {}), "error": f"{type(e).__name__}: {str(e)[:300]}"}
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+    # what INTEGRATION.md level 1 delivers when NOTHING but the import line of the reference changes: no gradient sink (autograd
+    # accumulates .grad, AccumulateGrad launches included), nn.CrossEntropyLoss on the materialised fp32 logits, torch.optim.Adam as
+    # the reference builds it, eager -- in the reference's precision (fp32) and with `model.compute_dtype = torch.bfloat16`
+    if world == 1 and args.dtype == "bf16" and not args.drop_in and not args.no_companions and not args.graph and not args.tune_gemm:
+        try:  # (a companion line must never cost the headline line: its failure is recorded under its key)
+            dctx = types.SimpleNamespace(**{**vars(ctx), "args": argparse.Namespace(**{**vars(args), "drop_in": True})})
+            out["drop_in"] = {"workload": wl["name"], "batch_per_gpu": args.batch, "unit": "images/s",
+                              "what": "only `from heal_swin_amd.models_torch.swin_hp_transformer import ...` differs from the reference's trainer: "
+                                      "plain .grad accumulation, nn.CrossEntropyLoss(logits, masks.long()), torch.optim.Adam, eager"}
+            for tag, dt, k in (("bf16", "bf16", 6), ("fp32", "fp32", 3)):
+                rdi = run_workload(dctx, dt, k, 2, timing=False)
+                out["drop_in"][tag] = {"value": args.batch * k / rdi.elapsed, "ms_per_step": 1e3 * rdi.elapsed / k, "steps": k, "warmup": 2,
+                                       "final_loss": rdi.loss, "peak_device_memory_GB": rdi.peak_gb}
+            out["drop_in"]["bf16"]["of_the_headline_step"] = (elapsed / args.steps) / (out["drop_in"]["bf16"]["ms_per_step"] * 1e-3)
+        except Exception as e:  # noqa: BLE001
+            out.setdefault('drop_in', {})
+            out['drop_in'] = {**(out['drop_in'] if isinstance(out['drop_in'], dict) else {}), "error": f"{type(e).__name__}: {str(e)[:300]}"}
             import gc
             gc.collect()
             torch.cuda.empty_cache()
@@ -723,6 +757,21 @@ def fold_gemm_tags(agg):
     return out
 
 
+class _NoSink:
+    """--drop-in: stands where the gradient sink stands in the step, and does what a plain trainer does there."""
+    buckets = ()
+    opt = None
+
+    def zero_grad(self):
+        self.opt.zero_grad()  # set_to_none=True, the PyTorch / Lightning default
+
+    def finish(self):
+        pass
+
+    def remove(self):
+        pass
+
+
 def run_workload(ctx, dtype_name, steps, warmup, timing):
     """Build the model / optimizer / gradient exchange for `dtype_name`, run `warmup` untimed and `steps` timed steps
     (barrier + synchronize on both sides, MAX over ranks) and release everything again."""
@@ -748,10 +797,24 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
     model, cfg, spec = build_model(wl)
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-    dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad,
-                             reserved_cus=args.reserved_cus if args.reserved_cus == "auto" else int(args.reserved_cus),
-                             comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else None)
-    if args.torch_adam:
+    drop_in = bool(getattr(args, "drop_in", False))
+    ddp = None
+    if drop_in:
+        # what the reference's trainer does around the module and nothing of this package besides it
+        if args.graph:
+            raise SystemExit("--drop-in is the eager trainer path; it is not captured")
+        dp = _NoSink()
+        if world > 1:
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=False)  # train.py:187
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)  # training/optimizer.py:57-66
+        dp.opt = opt
+    else:
+        dp = GradBucketAllReduce(model.parameters(), async_wgrad=args.async_wgrad,
+                                 reserved_cus=args.reserved_cus if args.reserved_cus == "auto" else int(args.reserved_cus),
+                                 comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else None)
+    if drop_in:
+        pass
+    elif args.torch_adam:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=args.graph)  # ref: training/optimizer.py:57-66
     else:
         # the same Adam on flat parameter / moment buffers laid out like the gradient buckets: one launch per bucket, which also
@@ -770,11 +833,17 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
         labels = torch.randint(0, spec["f_out"], (batch, spec["dim_in"]), generator=g, device=dev, dtype=torch.uint8)
         loss_fn = seg_loss
 
-    fused_loss = wl.get("task") != "depth" and not args.unfused_loss
+    fused_loss = wl.get("task") != "depth" and not args.unfused_loss and not drop_in
+    if drop_in and wl.get("task") != "depth":
+        ce = torch.nn.CrossEntropyLoss()  # model_lightning_swin_hp.py:39-45
+        loss_fn = lambda logits, y: ce(logits, y.long())  # noqa: E731  (`masks.long()`, :104-111)
+    net = ddp if ddp is not None else model
 
     def step():
         dp.zero_grad()
-        if fused_loss:  # model + the caller's CrossEntropyLoss in one call: the loss rides on the decoder tail's kernels
+        if drop_in:
+            loss = loss_fn(net(imgs.float()), labels)
+        elif fused_loss:  # model + the caller's CrossEntropyLoss in one call: the loss rides on the decoder tail's kernels
             loss = model.forward_seg_loss(imgs.float(), labels)
         else:
             logits = model(imgs.float())  # the caller's `.float()` (model_lightning_swin_hp.py:61)
@@ -793,7 +862,7 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
         step()
     sync()
     gemm_policy = None
-    if world > 1 and dtype_name == "bf16" and not args.graph:
+    if world > 1 and dtype_name == "bf16" and not args.graph and not drop_in:
         # With CUs reserved for RCCL the sink routes every bf16 Linear to hs_gemm_nt (whose grids honour the reservation), which costs
         # ~4 % on an idle chip and saves 16 % if the exchange's kernels do stay resident (profiles/r04_cu_contention.json).  Which of the
         # two this node's exchange looks like is MEASURED here instead of assumed: three steps under each policy (max over ranks), the
@@ -870,6 +939,8 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
         elapsed = float(t.item())
         # the exchange on its own: every gradient bucket all-reduced back to back, timed per rank with events
         reps = 5
+        if drop_in:  # (torch DDP owns its buckets: time an all-reduce of the same volume)
+            dp.buckets = [torch.zeros(sum(p.numel() for p in model.parameters()), device=dev)]
         for flat in dp.buckets:
             dist.all_reduce(flat)
         sync()
@@ -891,12 +962,14 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
             rccl_version = None
         # one more (untimed) step with the sink's timeline on: when, in milliseconds after the step began, did each gradient bucket
         # start its exchange (from a hook during the backward, or only in finish()), and when had all of them been waited for
-        dp.record_timeline(True)
-        t_begin = torch.cuda.Event(enable_timing=True)
-        t_begin.record()
-        step()
-        timeline = dp.timeline_ms(t_begin)
-        dp.record_timeline(False)
+        timeline = None
+        if not drop_in:
+            dp.record_timeline(True)
+            t_begin = torch.cuda.Event(enable_timing=True)
+            t_begin.record()
+            step()
+            timeline = dp.timeline_ms(t_begin)
+            dp.record_timeline(False)
         rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl_version,
                 "bucket_timeline_rank0": timeline,
                 "step_ms_per_rank": step_ms_per_rank, "buckets": len(dp.buckets),
@@ -904,12 +977,13 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
                 "allreduce_bus_GBps": 2 * (world - 1) / world * nbytes / (max(ms) * 1e-3) / 1e9,
                 "reserved_cus": int(__import__("heal_swin_amd")._lib.lib.hs_get_reserved_cus()), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
                 "gemm_policy": gemm_policy,
-                "exchange": f"{args.comm_dtype} wire format of fp32 flat buckets, async all-reduce launched from gradient hooks during backward"}
+                "exchange": ("torch.nn.parallel.DistributedDataParallel (its own buckets and hooks)" if drop_in else
+                             f"{args.comm_dtype} wire format of fp32 flat buckets, async all-reduce launched from gradient hooks during backward")}
     res = types.SimpleNamespace(elapsed=elapsed, loss=float(loss.item()), timings=timings if rank == 0 else None, rccl=rccl,
                                 params_m=round(sum(p.numel() for p in model.parameters()) / 1e6, 2),
                                 peak_gb=round(torch.cuda.max_memory_allocated(dev) / 1e9, 1))
     dp.remove()
-    del model, dp, opt, imgs, labels, loss, step
+    del model, dp, opt, imgs, labels, loss, step, net, ddp
     if args.graph:
         del graph, static_loss, eager_step
     del epoch  # (its registration with the library is withdrawn by run_workload's `undo`, which still holds the tensor)

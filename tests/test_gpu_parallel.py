@@ -163,3 +163,106 @@ def test_bench_script_multi_rank_path_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
     assert out["scaling"] == "weak" and out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
     assert out["config"]["parallelism"] == "dp2" and "cpu_baseline" not in out and "roofline" in out
+
+
+def _ddp_worker(rank, world, port, dtype_name, q):
+    """The reference's own trainer wiring (train.py:182-189: Lightning `ddp` = one process per GPU, the module wrapped in
+    torch.nn.parallel.DistributedDataParallel with find_unused_parameters=False; training/optimizer.py:57-66: torch.optim.Adam)
+    around the drop-in module -- no GradBucketAllReduce, no FlatAdam, no fused loss."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from torch.nn.parallel import DistributedDataParallel
+    model = _build()
+    model.compute_dtype = getattr(torch, dtype_name)
+    ddp = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=False)
+    x, y = _data()
+    out = _train_torch(ddp, model, x.chunk(world)[rank], y.chunk(world)[rank])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _train_torch(callable_model, model, xs, ys, steps=3):
+    loss_fn = torch.nn.CrossEntropyLoss()  # model_lightning_swin_hp.py:39-45
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()  # (set_to_none=True: the PyTorch / Lightning default)
+        loss = loss_fn(callable_model(xs), ys.long())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    return losses, [p.detach().float().cpu().numpy().copy() for p in model.parameters()]
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+def test_torch_ddp_wrapper_with_torch_adam_equals_single_process(dtype_name):
+    """INTEGRATION.md level 1 as the reference's trainer would run it: SwinHPTransformerSys inside torch's DistributedDataParallel
+    (two ranks on this box's one GPU, gloo), nn.CrossEntropyLoss, torch.optim.Adam, three steps.  The replicas must stay identical
+    and equal single-process training on the whole batch (to the reduction-order noise of the half batches)."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, dtype_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model = _build()
+    model.compute_dtype = getattr(torch, dtype_name)
+    x, y = _data()
+    ref_losses, ref = _train_torch(model, model, x, y)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)  # replicas identical after three steps
+    # the mean of the two half-batch losses is the full-batch loss (equal halves)
+    tol_l = 2e-5 if dtype_name == "float32" else 5e-3
+    for s, (l0, l1, lr) in enumerate(zip(res[0][0], res[1][0], ref_losses)):
+        assert abs(0.5 * (l0 + l1) - lr) <= tol_l * abs(lr), (s, l0, l1, lr)
+    # Adam normalises every update to ~lr whatever the gradient's size, so a gradient element inside the rounding noise moves by a
+    # different amount in the two runs: the comparison is on the MOVEMENT of three steps as a whole (cosine), and in fp32 -- where
+    # the noise is the reduction order of fp32 sums -- also on its worst element
+    init = [p.detach().float().cpu().numpy().copy() for p in _build().parameters()]
+    d_ddp = np.concatenate([(a - i).ravel() for a, i in zip(res[0][1], init)]).astype(np.float64)
+    d_ref = np.concatenate([(b - i).ravel() for b, i in zip(ref, init)]).astype(np.float64)
+    cos = float(d_ddp @ d_ref / (np.linalg.norm(d_ddp) * np.linalg.norm(d_ref)))
+    assert np.linalg.norm(d_ref) > 0
+    assert cos >= (0.999 if dtype_name == "float32" else 0.97), cos
+    if dtype_name == "float32":
+        worst = float(np.abs(d_ddp - d_ref).max() / np.abs(d_ref).max())
+        assert worst <= 0.1, worst
+
+
+def test_bench_script_eight_ranks_on_one_gpu():
+    """The first real 8-GPU run must not be the first time eight ranks meet: bench.py --gpus 8 as the driver launches it, the eight
+    ranks sharing this box's GPU over gloo at the tiny size, bf16 wire format.  Checks what a mis-wired exchange would break:
+    every rank arrives (max-over-ranks timing of 8 entries), the bucket order / hooks do not deadlock, the GEMM policy is agreed by
+    all ranks (a MAX all-reduce: one dissenting rank would hang the next collective), the timeline diagnostic is there, and the
+    line says rccl_ranks == 8.  The strong-scaling reading (global batch 8 -> 1 per rank) runs the same way."""
+    import json
+    import subprocess
+    env = dict(os.environ, HS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra, per_gpu, scaling in ((["--batch", "1"], 1, "weak"), (["--batch", "8", "--strong-scaling"], 1, "strong")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+               "--workload", "tiny", "--comm-dtype", "bf16"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 8 and out["value"] > 0 and out["scaling"] == scaling
+        assert out["config"]["parallelism"] == "dp8" and out["config"]["batch_per_gpu"] == per_gpu and out["config"]["global_batch"] == 8
+        rc = out["rccl"]
+        assert rc["rccl_ranks"] == 8 and len(rc["step_ms_per_rank"]) == 8 and len(rc["allreduce_ms_per_step_standalone_per_rank"]) == 8
+        assert rc["buckets"] >= 1 and rc["allreduce_bytes_per_step"] > 0 and "bf16" in rc["exchange"]
+        assert rc["gemm_policy"] is not None and set(rc["gemm_policy"]["trial_ms_per_step"]) == {"own", "per_shape_with_library"}
+        tl = rc["bucket_timeline_rank0"]
+        assert isinstance(tl, list) and len(tl) >= rc["buckets"] and all("ms" in e and "launched_from" in e for e in tl), tl
