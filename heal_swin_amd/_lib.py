@@ -107,7 +107,7 @@ _SIGNATURES = {
     "hs_window_attn_module_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_i64,
                                   c_int, c_int, c_int, c_uint, c_int, c_ptr],
     "hs_window_attn_module_fwd_train": [c_ptr] * 17 + [c_i64] + [c_ptr] * 6 + [c_int, c_i64, c_int, c_int, c_int, c_uint, c_int, c_ptr],
-    "hs_window_attn_module_bwd": [c_ptr] * 14 + [c_i64] + [c_ptr] * 11 + [c_int, c_int, c_i64, c_int, c_int, c_int, c_uint, c_int, c_ptr],
+    "hs_window_attn_module_bwd_chain": [c_ptr] * 14 + [c_i64] + [c_ptr] * 11 + [c_int, c_int, c_i64, c_int, c_int, c_int, c_uint, c_int, c_ptr],
     "hs_layernorm_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_ptr],
     "hs_patch_merge_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr],
     "hs_patch_merge_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64,
@@ -131,7 +131,7 @@ _OTHER = {
     "hs_linear_wgrad_workspace": ([c_i64, c_int, c_int], c_i64),
     "hs_window_attn_bwd_workspace": ([c_int, c_i64, c_int, c_int, c_int, c_int], c_i64),
     "hs_patch_merge_bwd_workspace": ([c_i64, c_int, c_int], c_i64),
-    "hs_window_attn_module_bwd_workspace": ([c_int, c_i64, c_int, c_int, c_int], c_i64),
+    "hs_window_attn_module_bwd_chain_workspace": ([c_int, c_i64, c_int, c_int, c_int], c_i64),
     "hs_patch_expand_bwd_workspace": ([c_i64, c_int, c_int, c_int], c_i64),
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_OTHER))

@@ -19,7 +19,7 @@ extern "C" {
 
 /* floats: three bf16 activation buffers (dO [M, C], dqkv [M, 3C], dxn [M, C]: 5 M C / 2 floats) followed by the largest of the
  * chained kernels' own workspaces */
-int64_t hs_window_attn_module_bwd_workspace(int batch, int64_t n_tokens, int channels, int num_heads, int window_size) {
+int64_t hs_window_attn_module_bwd_chain_workspace(int batch, int64_t n_tokens, int channels, int num_heads, int window_size) {
     const int64_t rows = (int64_t)batch * n_tokens;
     int64_t ws = hs_window_attn_bwd_workspace(batch, n_tokens, channels, num_heads, window_size, HS_BF16);
     ws = max64(ws, hs_linear_wgrad_workspace(rows, 3 * channels, channels));
@@ -28,7 +28,7 @@ int64_t hs_window_attn_module_bwd_workspace(int batch, int64_t n_tokens, int cha
     return round4(rows * channels * 5 / 2 + 4) + ws;
 }
 
-int hs_window_attn_module_bwd(const void* dout, const void* x, const void* xn, const float* mean, const float* rstd, const void* qkv,
+int hs_window_attn_module_bwd_chain(const void* dout, const void* x, const void* xn, const float* mean, const float* rstd, const void* qkv,
                               const void* attn_out, const float* lse, const void* qkv_w_t, const void* proj_w_t, const float* ln_gamma,
                               const float* bias, const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels,
                               void* dx, float* dqkv_w, float* dqkv_b, float* dproj_w, float* dproj_b, float* dln_gamma, float* dln_beta,
@@ -36,12 +36,12 @@ int hs_window_attn_module_bwd(const void* dout, const void* x, const void* xn, c
                               int num_heads, int window_size, unsigned flags, int dtype, void* stream) {
     using namespace hs;
     HS_CHECK_ARG(dout && qkv && attn_out && lse && qkv_w_t && proj_w_t && head_scale && dx && dqkv_w && dproj_w && dhead_scale && workspace,
-                 "hs_window_attn_module_bwd: null operand");
+                 "hs_window_attn_module_bwd_chain: null operand");
     HS_CHECK_ARG((ln_gamma != nullptr) == (x && xn && mean && rstd && dln_gamma && dln_beta),
-                 "hs_window_attn_module_bwd: with a LayerNorm in front pass x, xn, mean, rstd, dln_gamma, dln_beta; without it none of them");
-    HS_CHECK_ARG((bias == nullptr) == (dbias == nullptr), "hs_window_attn_module_bwd: bias and dbias go together");
+                 "hs_window_attn_module_bwd_chain: with a LayerNorm in front pass x, xn, mean, rstd, dln_gamma, dln_beta; without it none of them");
+    HS_CHECK_ARG((bias == nullptr) == (dbias == nullptr), "hs_window_attn_module_bwd_chain: bias and dbias go together");
     if (!hs_window_attn_module_supported(channels, num_heads, window_size, dtype))
-        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_bwd: bf16, window 64, head_dim 32 and C = 96 or 128 only");
+        return fail(HS_ERR_UNSUPPORTED, "hs_window_attn_module_bwd_chain: bf16, window 64, head_dim 32 and C = 96 or 128 only");
     const int C = channels;
     const int64_t rows = (int64_t)batch * n_tokens;
     // activation scratch in front of the kernels' workspace
@@ -61,7 +61,7 @@ int hs_window_attn_module_bwd(const void* dout, const void* x, const void* xn, c
         return st;
     // ---- qkv (:136); its input is LayerNorm(x) (v1 placement) or x itself
     const void* qkv_in = v1 ? xn : x;
-    if (!v1 && !x) return fail(HS_ERR_INVALID_ARG, "hs_window_attn_module_bwd: x (the qkv Linear's input) is needed for its weight gradient");
+    if (!v1 && !x) return fail(HS_ERR_INVALID_ARG, "hs_window_attn_module_bwd_chain: x (the qkv Linear's input) is needed for its weight gradient");
     if (int st = hs_linear_wgrad(dqkv, qkv_in, dqkv_w, dqkv_b, ws, rows, 3 * C, C, accumulate, dtype, stream)) return st;
     if (!v1)  // dx = dqkv W_q: the caller adds the block's own residual path (v2 placement: x + norm(branch))
         return hs_gemm_nt(dqkv, 3 * C, qkv_w_t, 3 * C, 3 * C, nullptr, 0, nullptr, 0, 0, nullptr, dx, nullptr, rows, C, HS_EPI_BIAS, 0.f, 0, dtype,

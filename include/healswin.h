@@ -470,10 +470,10 @@ int hs_window_attn_module_fwd_train(const void* x, void* out, void* xn_out, floa
  *   ln_gamma NULL (v2 placement): x is the qkv Linear's input, xn / mean / rstd / dln_* are NULL, dx = dqkv W_q only
  *   dx [dev] bf16 [batch, n_tokens, C]; dqkv_w f32 [3C, C], dqkv_b f32 [3C] or NULL, dproj_w f32 [C, C], dproj_b f32 [C] or NULL,
  *   dln_gamma / dln_beta f32 [C], dbias f32 [nH, Ws, Ws] (NULL iff bias is), dhead_scale f32 [nH]: overwritten, or added to when
- *   accumulate != 0;  workspace [dev] f32 [hs_window_attn_module_bwd_workspace(...)]
+ *   accumulate != 0;  workspace [dev] f32 [hs_window_attn_module_bwd_chain_workspace(...)]
  *   flags: HS_ATTN_COSINE, HS_ATTN_RESIDUAL as in the forward call. */
-int64_t hs_window_attn_module_bwd_workspace(int batch, int64_t n_tokens, int channels, int num_heads, int window_size);
-int hs_window_attn_module_bwd(const void* dout, const void* x, const void* xn, const float* mean, const float* rstd, const void* qkv,
+int64_t hs_window_attn_module_bwd_chain_workspace(int batch, int64_t n_tokens, int channels, int num_heads, int window_size);
+int hs_window_attn_module_bwd_chain(const void* dout, const void* x, const void* xn, const float* mean, const float* rstd, const void* qkv,
                               const void* attn_out, const float* lse, const void* qkv_w_t, const void* proj_w_t, const float* ln_gamma,
                               const float* bias, const float* head_scale, const int32_t* idx, int64_t roll, const uint8_t* labels,
                               void* dx, float* dqkv_w, float* dqkv_b, float* dproj_w, float* dproj_b, float* dln_gamma, float* dln_beta,

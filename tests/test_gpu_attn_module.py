@@ -355,7 +355,7 @@ def test_model_training_step_uses_the_train_form_and_matches_the_composition():
 
 @pytest.mark.parametrize("v1,cosine,strategy", [(True, False, "nest_roll"), (True, True, "ring_shift"), (False, True, "nest_grid_shift")])
 def test_module_bwd_entry_point_equals_the_autograd_path(v1, cosine, strategy):
-    """C ABI: hs_window_attn_module_fwd_train followed by hs_window_attn_module_bwd (one call each way) gives the gradients the
+    """C ABI: hs_window_attn_module_fwd_train followed by hs_window_attn_module_bwd_chain (one call each way) gives the gradients the
     Python mirror's recorded autograd nodes give (ops.window_attn_module_train) -- same kernels, chained by the library."""
     from heal_swin_amd import ops, _lib
     from heal_swin_amd._lib import check, lib, ptr
@@ -393,11 +393,11 @@ def test_module_bwd_entry_point_equals_the_autograd_path(v1, cosine, strategy):
                                               ptr(P["lg"]) if v1 else None, ptr(P["lb"]) if v1 else None, ptr(P["bias"]), ptr(P["hs"]),
                                               ptr(idx), roll, ptr(labels), None, None, None, None, None, B, N, C, nH, 64, flags, _lib.HS_BF16, None), "fwd_train")
     assert torch.equal(out, y.detach())
-    ws = torch.empty(int(lib.hs_window_attn_module_bwd_workspace(B, N, C, nH, 64)), device=DEV)
+    ws = torch.empty(int(lib.hs_window_attn_module_bwd_chain_workspace(B, N, C, nH, 64)), device=DEV)
     dx = torch.empty_like(x)
     G = dict(wq=torch.empty(3 * C, C, device=DEV), bq=torch.empty(3 * C, device=DEV), wp=torch.empty(C, C, device=DEV), bp=torch.empty(C, device=DEV),
              lg=torch.empty(C, device=DEV), lb=torch.empty(C, device=DEV), bias=torch.empty(nH, 64, 64, device=DEV), hs=torch.empty(nH, device=DEV))
-    check(lib.hs_window_attn_module_bwd(ptr(dout), ptr(x), ptr(xn) if v1 else None, ptr(mean) if v1 else None, ptr(rstd) if v1 else None, ptr(qkv),
+    check(lib.hs_window_attn_module_bwd_chain(ptr(dout), ptr(x), ptr(xn) if v1 else None, ptr(mean) if v1 else None, ptr(rstd) if v1 else None, ptr(qkv),
                                         ptr(o), ptr(lse), ptr(wq16.t().contiguous()), ptr(wp16.t().contiguous()), ptr(P["lg"]) if v1 else None,
                                         ptr(P["bias"]), ptr(P["hs"]), ptr(idx), roll, ptr(labels), ptr(dx), ptr(G["wq"]), ptr(G["bq"]),
                                         ptr(G["wp"]), ptr(G["bp"]), ptr(G["lg"]) if v1 else None, ptr(G["lb"]) if v1 else None, ptr(G["bias"]),
