@@ -16,6 +16,7 @@ TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
 GRAD_TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2}
 
 REPORT = []  # (what, scale_err, rms_err, elem_err, scale) of every comparison made; printed at the end of the session
+SLOPES = []  # (what, slope - 1, cosine, n) of every assert_unbiased call
 
 
 def _np(a):
@@ -80,3 +81,29 @@ def worst(prefix=""):
     if not rows:
         return 0.0, 0.0, 0.0
     return max(r[1] for r in rows), max(r[2] for r in rows), max(r[3] for r in rows)
+
+
+def assert_unbiased(a, b, what="", slope_tol=0.05, cos_min=None, min_elems=256):
+    """A SYSTEMATIC error shows in the least-squares slope of a against the reference b,  s = <a, b> / <b, b>,  however noisy the
+    elements are: zero-mean rounding noise of relative rms r moves s by ~ r / sqrt(n), a dropped product / a wrong factor / a missed
+    accumulation of 10 % moves it by 0.1.  This is what lets the bf16 GRADIENT tests -- whose element bounds must admit the
+    rounding noise of cancelling sums (up to 0.2-0.5 of a tensor's scale on its worst element) -- still catch a 10 % error:
+    |s - 1| <= slope_tol on every tensor with >= min_elems elements (smaller ones are left to their element bound).
+    cos_min: optional bound on the cosine between a and b."""
+    if torch.is_tensor(a):
+        a = a.detach().to(torch.float64).flatten()
+        b = (b if torch.is_tensor(b) else torch.from_numpy(np.ascontiguousarray(b))).detach().to(a.device).to(torch.float64).flatten()
+        bb, ab, aa = float(b @ b), float(a @ b), float(a @ a)
+    else:
+        a, b = _np(a).ravel(), _np(b).ravel()
+        bb, ab, aa = float(b @ b), float(a @ b), float(a @ a)
+    n = int(b.shape[0])
+    if n < min_elems or bb == 0.0:
+        return None
+    slope = ab / bb
+    cos = ab / max((aa * bb) ** 0.5, 1e-300)
+    SLOPES.append((what, slope - 1.0, cos, n))
+    assert abs(slope - 1.0) <= slope_tol, f"{what}: slope of the result against the reference = {slope:.4f} (|s - 1| > {slope_tol}; cosine {cos:.4f}, {n} elements)"
+    if cos_min is not None:
+        assert cos >= cos_min, f"{what}: cosine with the reference {cos:.4f} < {cos_min}"
+    return slope

@@ -67,6 +67,12 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     tr.section("observed parity errors")
     for line in NOTES:
         tr.write_line(line)
+    import _util
+    if _util.SLOPES:
+        sl = sorted(_util.SLOPES, key=lambda r: -abs(r[1]))
+        tr.write_line(f"{len(sl)} gradient tensors checked for a systematic error (least-squares slope against the reference); the 8 largest |slope - 1|:")
+        for what, ds, cos, n in sl[:8]:
+            tr.write_line(f"  slope - 1 = {ds:+.2e}  cosine {cos:.5f}  ({n} elements)  {what}")
     worst = sorted(_PER_TEST.items(), key=lambda kv: -kv[1][1])
     tr.write_line(f"{len(_PER_TEST)} tests compared tensors; the 25 largest max|a-b|/max|b| (scale / rms / elem99.9, #comparisons):")
     for nodeid, (n, s, r, e) in worst[:25]:

@@ -18,7 +18,7 @@ import pytest
 import torch
 
 import conftest
-from _util import assert_close, errors
+from _util import assert_close, errors, assert_unbiased
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -128,6 +128,7 @@ def test_baseline_architecture_fwd_bwd_vs_oracle(name, dtype):
             ls_pairs.append((k, got.float().cpu().reshape(-1), g.reshape(-1)))
             continue
         assert_close(got, g, tol, f"{tag} grad {k}", floor=floor + (1e-7 if dtype == torch.bfloat16 else 1e-9))
+        assert_unbiased(got, g, f"{tag} grad {k}")  # (a systematic 10 % error, whatever the element bound above admits)
     if ls_pairs:
         a = torch.cat([p_[1] for p_ in ls_pairs]).double()
         b = torch.cat([p_[2] for p_ in ls_pairs]).double()
@@ -307,6 +308,7 @@ def test_headline_config_full_size_gradients_vs_oracle():
     report = []
     for dtype, tol_scale, tol_rms in ((torch.float32, 2e-4, 2e-4), (torch.bfloat16, 8e-2, 6e-2)):  # observed 4.2e-5 / 3.2e-5 and 4.6e-2 / 3.9e-2  # (bf16: the rel-pos tables of the deep stages)
         model.compute_dtype = dtype
+        tag_ = "fp32" if dtype == torch.float32 else "bf16"
         model.zero_grad(set_to_none=True)
         loss = seg_loss(model(xg), yg)
         loss.backward()
@@ -314,6 +316,7 @@ def test_headline_config_full_size_gradients_vs_oracle():
         for n, p_ in model.named_parameters():
             assert p_.grad is not None, n
             e = errors(p_.grad.float().cpu(), ref[n])
+            assert_unbiased(p_.grad.float().cpu(), ref[n], f"configs2_B_FULL {tag_} grad {n}")
             rms_all.append(e["rms_err"])
             if e["scale_err"] > worst_s[1]:
                 worst_s = (n, e["scale_err"])
@@ -402,6 +405,7 @@ def test_paper_config_full_size_gradients_vs_oracle():
         for n, p_ in model.named_parameters():
             assert p_.grad is not None, n
             e = errors(p_.grad.float().cpu(), ref[n])
+            assert_unbiased(p_.grad.float().cpu(), ref[n], f"paper_T_FULL {'fp32' if dtype == torch.float32 else 'bf16'} grad {n}")
             rms_all.append(e["rms_err"])
             if n.endswith("logit_scale"):
                 if e["scale_err"] > worst_ls[1]:
@@ -577,6 +581,7 @@ def test_full_size_backward_is_the_derivative_of_the_forward(name, strict_fp32_g
         # (observed up to 4.9e-2 of the table's scale on the headline model; every other tensor <= 3e-2)
         tol = max(bf16_tol, 8e-2) if n.endswith("relative_position_bias_table") else bf16_tol
         assert_close(g16[n], g, tol, f"{name} full-size bf16 grad vs fp32 grad {n}", floor=floor + 1e-7)
+        assert_unbiased(g16[n], g, f"{name} full-size bf16 grad vs fp32 grad {n}")
     if ls:
         a16 = torch.cat([t[0] for t in ls]).double()
         b32 = torch.cat([t[1] for t in ls]).double()
