@@ -467,7 +467,8 @@ def main():
                                     "torch.optim.Adam(fused=True)" if args.torch_adam else "heal_swin_amd.optim.FlatAdam (torch.optim.Adam arithmetic on flat buffers)",
                        "launch": "hip graph replay" if args.graph else "eager",
                        "params_M": res.params_m, "final_loss": res.loss, "peak_device_memory_GB": res.peak_gb,
-                       "library_gemm_selection": gemm_selection},
+                       "library_gemm_selection": gemm_selection,
+                       "own_or_library_gemm": _gemm_tuner_record()},
         }
         # whole-step model FLOPs (analytic forward count == FlopCounterMode; backward = 2x) against the dense bf16 peak
         if wl.get("fwd_gflop_per_image"):
@@ -755,6 +756,15 @@ def fold_gemm_tags(agg):
         o[2] += a[2]
         o[3] += a[3]
     return out
+
+
+def _gemm_tuner_record():
+    """What decided hs_gemm_nt-or-library for the bias / residual products of this process (ops.GemmTuner: first-call trials)."""
+    from heal_swin_amd import ops
+    t = ops.GEMM_TUNER
+    return {"mode": ops.GEMM_TUNE, "rule": "GELU / GELU' epilogues: hs_gemm_nt; bias / residual products: measured table, then a first-call trial "
+                                          "of both on synthetic operands per (rows bucket, n, k), then the class rule",
+            "trials_us_own_vs_library": {f"m~2^{k[0]} n={k[1]} k={k[2]}": list(v) + ["own" if t.picks[k] else "library"] for k, v in sorted(t.trials.items())}}
 
 
 class _NoSink:

@@ -538,7 +538,7 @@ int hs_sample_mask_u8(const void* mask, int batch, int height, int width, const 
  *             dy [dev] bf16[rows, C] = LayerNorm input gradient; dprime [dev] bf16[rows, 16] = dlogits * rstd;
  *             partials [dev] f32[hs_ln_head_partials(rows), 32]: per-wave sums u[k] = sum dlogits (0..15) and
  *             t[k] = sum dprime * mean (16..31).  With X = hs_linear_wgrad(dprime, y) - t:  dW = gamma X + beta u,
- *             dgamma_c = sum_k W X, dbeta_c = sum_k W u   (heal_swin_amd/ops.py:LnHeadFn).
+ *             dgamma_c = sum_k W X, dbeta_c = sum_k W u   (heal_swin_amd/ops/tail.py:LnHeadFn).
  *   logits_dtype: HS_BF16 (32-byte rows) or HS_F32 (64-byte rows: the logits keep their fp32 accumulator value and xhat enters the
  *             head product as hi + lo; dlogits is then read as fp32 too) -- the decoder tail's roundings are not averaged by
  *             anything downstream and dominate the bf16 logit error, see csrc/ln_head.hip.
@@ -592,7 +592,7 @@ int hs_expand_ln_head_fwd(const void* xn, const void* xn_lo, const void* wexp, c
  *   loss_partials [dev] f32[4 * hs_expand_ln_head_blocks(tokens), 2]: sums of w (lse - logit_label) and of w per wavefront:
  *                 loss = sum(col 0) / sum(col 1)  (the reference's weighted mean);
  *   backward: scale [dev] f32[1] = dloss / sum(col 1); wfold [dev] bf16[64, C] and bvec [dev] f32[32] as for the forward but with row
- *             blocks 4..7 and 8..11 EXCHANGED (heal_swin_amd/ops.py:_fold_head_ce; csrc/ln_head.hip says why); afold, dy, dprime,
+ *             blocks 4..7 and 8..11 EXCHANGED (heal_swin_amd/ops/tail.py:_fold_head_ce; csrc/ln_head.hip says why); afold, dy, dprime,
  *             partials as for hs_ln_head_bwd.  bf16, C in {64, 96, 128}. */
 int64_t hs_expand_ln_head_blocks(int64_t tokens);
 int hs_expand_ln_head_ce_fwd(const void* xn, const void* xn_lo, const void* wexp, const void* wfold, const float* bvec, const uint8_t* labels,

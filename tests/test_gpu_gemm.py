@@ -179,3 +179,40 @@ def test_linear_and_concat_linear_own_kernel_vs_library():
         ops.OWN_GEMM = prev
     for a, bb, nm in zip(res["1"], res["0"], ("z", "dx", "dskip", "dw", "db", "dwc", "dbc")):
         assert_close(a, bb, 2e-2, "own vs library " + nm)
+
+
+def test_gemm_tuner_measures_once_and_the_model_follows_its_pick():
+    """ops.GemmTuner: the first request of a new (rows bucket, n, k) class times hs_gemm_nt and the library on synthetic operands and
+    remembers the faster; later requests (and neighbouring row counts of the same power of two) are dictionary hits; own_gemm_ok
+    returns the pick for bias products outside the measured table; either pick gives the same Linear result to bf16 rounding."""
+    from heal_swin_amd import _lib, ops
+    from heal_swin_amd.ops import gemm as G
+    tuner = G.GemmTuner()
+    m, n, k = 40000, 640, 320  # not a shape of any benchmark workload
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pick = tuner.pick(m, n, k, dev)
+    assert pick in (True, False) and len(tuner.trials) == 1
+    own_us, lib_us = tuner.trials[tuner.key(m, n, k)]
+    assert own_us > 0 and lib_us > 0 and pick == (own_us <= lib_us)
+    assert tuner.pick(m + 1000, n, k, dev) == pick and len(tuner.trials) == 1  # same power-of-two bucket: no second trial
+    assert tuner.pick(64, 64, 64, dev) is None and len(tuner.trials) == 1     # too small to matter: the class rule answers
+    prev_tuner, prev_mode = G.GEMM_TUNER, ops.GEMM_TUNE
+    try:
+        G.GEMM_TUNER = tuner
+        ops.GEMM_TUNE = "all"
+        assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, n, k, torch.bfloat16, m=m) == pick
+        g = torch.Generator(device=DEV).manual_seed(0)
+        x = torch.randn((m, k), generator=g, device=DEV).to(torch.bfloat16)
+        w = torch.randn((n, k), generator=g, device=DEV) * k ** -0.5
+        b = torch.randn(n, generator=g, device=DEV)
+        ys = {}
+        for forced in (True, False):
+            tuner.picks[tuner.key(m, n, k)] = forced
+            ys[forced] = ops.linear(x, w, b).float()
+        ref = x.float() @ w.t() + b
+        for forced, y in ys.items():
+            assert_close(y, ref, 6e-3, f"linear through {'hs_gemm_nt' if forced else 'the library'}")
+        ops.GEMM_TUNE = "off"
+        assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, n, k, torch.bfloat16, m=m) == (k <= 128 or n <= 128 or (n <= 256 and k <= 256))
+    finally:
+        G.GEMM_TUNER, ops.GEMM_TUNE = prev_tuner, prev_mode
