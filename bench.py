@@ -762,8 +762,8 @@ def _gemm_tuner_record():
     """What decided hs_gemm_nt-or-library for the bias / residual products of this process (ops.GemmTuner: first-call trials)."""
     from heal_swin_amd import ops
     t = ops.GEMM_TUNER
-    return {"mode": ops.GEMM_TUNE, "rule": "GELU / GELU' epilogues: hs_gemm_nt; bias / residual products: measured table, then a first-call trial "
-                                          "of both on synthetic operands per (rows bucket, n, k), then the class rule",
+    return {"tuner": bool(ops.GEMM_TUNE), "rule": "GELU / GELU' epilogues: hs_gemm_nt; bias / residual products: a first-call trial of both on "
+                                                  "synthetic operands per (rows bucket, n, k), the class rule where no trial ran",
             "trials_us_own_vs_library": {f"m~2^{k[0]} n={k[1]} k={k[2]}": list(v) + ["own" if t.picks[k] else "library"] for k, v in sorted(t.trials.items())}}
 
 

@@ -20,11 +20,6 @@ OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice bel
 # Costs ~3 ms per step on an idle chip (HS_OWN_GEMM=1 measurement of round 3), saves ~27 ms under contention (r04_cu_contention.json).
 OWN_GELU_MAX_K = 4096
 OWN_DGELU_MAX_K = 1024
-# (n, k) -> bool: measured exceptions to the class rule of own_gemm_ok for the bias / residual products, in situ against the TunableOp
-# picks (profiles/r05_gemm_shape_table_ab.txt, us per launch lib -> own): T stage-1 qkv 146 -> 122, T stage-2 qkv 103 -> 76, T stage-2
-# proj 39 / 43 -> 33, B stage-1 qkv 259 -> 217.  The long reductions of the same stages stay with the library (T fc2 141 vs 160, 101 vs 113).
-OWN_SHAPE_TABLE = {(576, 192): True, (1152, 384): True, (384, 384): True, (768, 256): True}
-OWN_SHAPE_TABLE_MIN_M = 49152  # measured at m = 65536 ... 393216 rows only
 OWN_BIAS_MAX_K = 0  # (> 0 would send every bias / residual product with k <= this to hs_gemm_nt: measured, slower -- profiles/r03_gemm_policy_ab.txt)
 
 
@@ -34,8 +29,9 @@ class GemmTuner:
     nobody measured.  The first time a product of a new (rows bucket, n, k) class is asked for, both implementations run on
     synthetic operands of that shape (two operand sets in rotation, 1 + 3 launches each, interleaved, best time counts) and the
     faster one is remembered for the process; ~1-2 ms per new shape, during the first (warm-up) step.  Never inside a stream capture
-    (the class rule answers there) and only for products large enough for the choice to matter.  `GEMM_TUNE` = "new" (default): shapes
-    the table does not cover; "all": every shape (the table is ignored); "off": class rule + table only."""
+    (the class rule answers there) and only for products large enough for the choice to matter.  It replaces the per-shape table of
+    rounds 4-5 (four (n, k) pairs measured by hand in situ): on the bench's shapes it takes the same decisions and the step is the same
+    to +-0.5 ms (profiles/r06_gemm_tuner_ab.txt).  `GEMM_TUNE = False` (an attribute, for tests and A/B runs): class rule only."""
     MIN_FLOP = 1 << 33  # below ~8 GFLOP a product is a few microseconds either way
 
     def __init__(self):
@@ -79,7 +75,7 @@ class GemmTuner:
         return self.picks[key]
 
 
-GEMM_TUNE = os.environ.get("HS_OWN_GEMM_TUNE", "new")
+GEMM_TUNE = True
 GEMM_TUNER = GemmTuner()
 
 
@@ -103,11 +99,7 @@ def own_gemm_ok(epi, n, k, dtype, k2=0, m=None):
         return kk <= OWN_GELU_MAX_K
     if OWN_BIAS_MAX_K > 0:
         return kk <= OWN_BIAS_MAX_K
-    if GEMM_TUNE != "all" and (m is None or m >= OWN_SHAPE_TABLE_MIN_M):
-        pick = OWN_SHAPE_TABLE.get((n, kk))
-        if pick is not None:
-            return pick
-    if GEMM_TUNE != "off" and m is not None and k2 == 0 and torch.cuda.is_available():
+    if GEMM_TUNE and m is not None and k2 == 0 and torch.cuda.is_available():
         pick = GEMM_TUNER.pick(int(m), n, kk, torch.device("cuda", torch.cuda.current_device()))
         if pick is not None:
             return pick

@@ -184,7 +184,7 @@ def test_linear_and_concat_linear_own_kernel_vs_library():
 def test_gemm_tuner_measures_once_and_the_model_follows_its_pick():
     """ops.GemmTuner: the first request of a new (rows bucket, n, k) class times hs_gemm_nt and the library on synthetic operands and
     remembers the faster; later requests (and neighbouring row counts of the same power of two) are dictionary hits; own_gemm_ok
-    returns the pick for bias products outside the measured table; either pick gives the same Linear result to bf16 rounding."""
+    returns the pick for bias products; either pick gives the same Linear result to bf16 rounding."""
     from heal_swin_amd import _lib, ops
     from heal_swin_amd.ops import gemm as G
     tuner = G.GemmTuner()
@@ -199,7 +199,7 @@ def test_gemm_tuner_measures_once_and_the_model_follows_its_pick():
     prev_tuner, prev_mode = G.GEMM_TUNER, ops.GEMM_TUNE
     try:
         G.GEMM_TUNER = tuner
-        ops.GEMM_TUNE = "all"
+        ops.GEMM_TUNE = True
         assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, n, k, torch.bfloat16, m=m) == pick
         g = torch.Generator(device=DEV).manual_seed(0)
         x = torch.randn((m, k), generator=g, device=DEV).to(torch.bfloat16)
@@ -212,7 +212,7 @@ def test_gemm_tuner_measures_once_and_the_model_follows_its_pick():
         ref = x.float() @ w.t() + b
         for forced, y in ys.items():
             assert_close(y, ref, 6e-3, f"linear through {'hs_gemm_nt' if forced else 'the library'}")
-        ops.GEMM_TUNE = "off"
+        ops.GEMM_TUNE = False
         assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, n, k, torch.bfloat16, m=m) == (k <= 128 or n <= 128 or (n <= 256 and k <= 256))
     finally:
         G.GEMM_TUNER, ops.GEMM_TUNE = prev_tuner, prev_mode

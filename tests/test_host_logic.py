@@ -147,24 +147,37 @@ def test_bf16x3_policy_and_legality_helpers():
     assert not ops.own_gemm_legal(128, 512, torch.float32)
 
 
-def test_own_gemm_policy_class_rule_and_measured_exceptions(monkeypatch):
-    """ops.own_gemm_ok: the class rule (HBM-bound shapes, GELU epilogues) plus the table of measured per-shape exceptions, which applies
-    from OWN_SHAPE_TABLE_MIN_M rows up (it was measured on the large workloads only) and never overrides HS_OWN_GEMM = 0 / 1."""
+def test_own_gemm_policy_class_rule_tuner_picks_and_overrides(monkeypatch):
+    """ops.own_gemm_ok: GELU / GELU' epilogues by their K limits; bias / residual products by the first-call tuner's pick where one
+    exists (ops.GemmTuner; its trials need a GPU -- here its dictionary is filled by hand), else the class rule (HBM-bound shapes:
+    narrow or short); HS_OWN_GEMM = 0 / 1 and the data-parallel preference override everything."""
     import torch
     from heal_swin_amd import _lib, ops
+    from heal_swin_amd.ops import gemm as G
     bf = torch.bfloat16
     monkeypatch.setattr(ops, "OWN_GEMM", "auto")
     monkeypatch.setattr(ops.RT, "prefer_own_gemm", False)
-    monkeypatch.setattr(ops, "OWN_SHAPE_TABLE", {(1152, 384): True, (128, 128): False})
     assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 384, 96, bf) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 512, bf)  # class rule: narrow / short
     assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 512, 2048, bf) and not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1536, 512, bf)
-    assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=65536)  # table entry
-    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=ops.OWN_SHAPE_TABLE_MIN_M - 32)  # below the measured range: class rule
-    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1 << 20) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1024)
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=65536)  # (no GPU here: no trial, the class rule answers)
     assert ops.own_gemm_ok(_lib.HS_EPI_GELU, 2048, 512, bf) and ops.own_gemm_ok(_lib.HS_EPI_DGELU, 2048, 512, bf)  # epilogue products: own
     assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, torch.float32) and not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1150, 384, bf)
+    # a remembered pick is keyed by (power-of-two bucket of the rows, n, k) and decides for every row count of that bucket
+    tuner = G.GemmTuner()
+    tuner.picks[tuner.key(65536, 1152, 384)] = True
+    tuner.picks[tuner.key(1 << 20, 128, 128)] = False
+    monkeypatch.setattr(G, "GEMM_TUNER", tuner)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    assert tuner.key(65536, 1152, 384) == tuner.key(100000, 1152, 384) != tuner.key(32768, 1152, 384)
+    assert tuner.pick(100000, 1152, 384, None) is True and tuner.pick(64, 64, 64, None) is None  # hit / too small for a trial
+    assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=100000) and not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1 << 20)
+    assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1024)  # another bucket, below the trial size: class rule
+    monkeypatch.setattr(ops, "GEMM_TUNE", False)
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=100000) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1 << 20)
+    monkeypatch.setattr(ops, "GEMM_TUNE", True)
     monkeypatch.setattr(ops, "OWN_GEMM", "0")
-    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf) and not ops.own_gemm_ok(_lib.HS_EPI_GELU, 2048, 512, bf)
+    assert not ops.own_gemm_ok(_lib.HS_EPI_BIAS, 1152, 384, bf, m=100000) and not ops.own_gemm_ok(_lib.HS_EPI_GELU, 2048, 512, bf)
     monkeypatch.setattr(ops, "OWN_GEMM", "1")
     assert ops.own_gemm_ok(_lib.HS_EPI_BIAS, 128, 128, bf, m=1 << 20) and ops.own_gemm_ok(_lib.HS_EPI_BIAS, 512, 2048, bf)
 
