@@ -377,7 +377,7 @@ def main():
                 os.environ["NCCL_DEBUG"] = "VERSION"
                 os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         # RCCL's ring kernels are long-lived workgroups that share the chip with the backward.  A kernel that fills all 256 CUs
-        # loses 45-65 % when even 8 of them hold a foreign 128-VGPR workgroup (profiles/r03_cu_contention.json), so the exchange
+        # loses 45-65 % when even 8 of them hold a foreign 128-VGPR workgroup (profiles/archive_r01_r04/r03_cu_contention.json), so the exchange
         # gets a bounded number of channels and the library leaves that many CUs free (GradBucketAllReduce(reserved_cus=...)).
         # 596 MB of gradients per 160 ms step need < 10 GB/s: 16 channels are ample.  Both can be overridden from the environment.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
@@ -683,7 +683,7 @@ def roofline_of(timings, elapsed, detail=False, traffic_records=None):
                                    "frac": (tot_b + (fused[1] if fused else 0)) / (tot_t + (fused[0] if fused else 0)) / 1e9 / HBM_PEAK_GBS},
         "algorithmic_bytes_per_launch": tot_b / launches,
         # what a pure read stream reaches on this chip (tools/microbench/fill_rate.hip, 1 GB working set, every CU
-        # streaming: profiles/r02_microbench_fill_rate.txt) -- the vendor figure above is the contract's denominator
+        # streaming: profiles/archive_r01_r04/r02_microbench_fill_rate.txt) -- the vendor figure above is the contract's denominator
         "measured_read_ceiling_GBs": 6300.0, "frac_of_measured_ceiling": gbs / 6300.0,
         "mfma": {"achieved": tf_8d, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_8d / MFMA_PEAK_TFLOPS,
                  "flop_count": "SURVEY 8d: attention-core flops, fwd + bwd = 3 x forward",
@@ -874,7 +874,7 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
     gemm_policy = None
     if world > 1 and dtype_name == "bf16" and not args.graph and not drop_in:
         # With CUs reserved for RCCL the sink routes every bf16 Linear to hs_gemm_nt (whose grids honour the reservation), which costs
-        # ~4 % on an idle chip and saves 16 % if the exchange's kernels do stay resident (profiles/r04_cu_contention.json).  Which of the
+        # ~4 % on an idle chip and saves 16 % if the exchange's kernels do stay resident (profiles/archive_r01_r04/r04_cu_contention.json).  Which of the
         # two this node's exchange looks like is MEASURED here instead of assumed: three steps under each policy (max over ranks), the
         # faster one runs the timed region.  Every rank takes the same decision (the times are all-reduced).
         trial = {}

@@ -5,7 +5,7 @@
 // heal_swin_amd.optim.FlatAdam lays parameters and moments out the same way, so a step is ONE elementwise launch per bucket that
 // also writes the bf16 copy of the updated parameters the next forward's GEMMs read (ops.ParamCastCache): 16 B read + 14 B written
 // per parameter instead of a multi-tensor Adam (28 B) plus a separate multi-tensor cast (6 B) plus their ~40 launches -- on the
-// launch-heavy HEAL-SWIN-T / nside 128 step the two were 0.86 + 0.4 ms of 16.7 ms (profiles/r04_k_T128_summary.txt).
+// launch-heavy HEAL-SWIN-T / nside 128 step the two were 0.86 + 0.4 ms of 16.7 ms (profiles/archive_r01_r04/r04_k_T128_summary.txt).
 //
 // Arithmetic = torch.optim.Adam (amsgrad = False, maximize = False), single-tensor form:
 //   g += wd * p (Adam)   |   p *= 1 - lr * wd (AdamW, `decoupled`)

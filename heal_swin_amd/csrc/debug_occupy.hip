@@ -1,7 +1,7 @@
 // Diagnostic: occupy a chosen number of compute units for a chosen time on a stream of the caller's choice, the way a
 // communication library's ring kernels do during the backward of a data-parallel step (RCCL all-reduce: a few dozen long-lived
 // workgroups of 256-512 threads).  Used by tools/cu_contention.py to measure what such co-resident kernels cost the
-// one-resident-round grids of this library, and what hs_set_reserved_cus() buys back (profiles/r03_cu_contention.json).
+// one-resident-round grids of this library, and what hs_set_reserved_cus() buys back (profiles/archive_r01_r04/r03_cu_contention.json).
 #include "hs_device.h"
 
 namespace hs {

@@ -51,7 +51,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 #endif
 // HS_GEMM_EXP (measurement builds only, tools/gemm_overlap_premise.sh): bit 1 = the second half of the waves stores one output
 // tile's worth of bytes (into `aux`, which the bias epilogue does not use) from INSIDE the k-steps, a 1-KB instruction per wave and
-// 16-deep sub-step: the skeleton of an epilogue whose stores ride under the next tile's MFMAs (profiles/r03_gemm_overlap_premise.txt:
+// 16-deep sub-step: the skeleton of an epilogue whose stores ride under the next tile's MFMAs (profiles/archive_r01_r04/r03_gemm_overlap_premise.txt:
 // it costs 65-75 % of what the same bytes cost in a serial epilogue)
 #ifndef HS_GEMM_EXP
 #define HS_GEMM_EXP 0
@@ -105,7 +105,7 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
 // inside the stage buffer that was just consumed (one extra barrier per tile) instead of in LDS of their own
 // FAST (k and k2 multiples of 64: no K tail): the operand DMA of a k-step is issued by the FIRST HALF of the waves alone (twice the
 // pieces each, their k offset in the scalar operand), the other half runs MFMAs and fragment reads only -- 8-16 % on the 256 x 256
-// tile at every shape (profiles/r03_gemm_role_split.txt); the addressing form alone changes nothing
+// tile at every shape (profiles/archive_r01_r04/r03_gemm_role_split.txt); the addressing form alone changes nothing
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIAS, int EPI, bool DROP, bool FAST>
 __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
     // slots by tile parity behind the stages) and the epilogue reads them with ds_read_b128.  A global load at the top of the
     // epilogue is the youngest entry of the wave's in-order vmcnt queue: on the DMA-issuing waves it waited for the whole first
     // k-step of the NEXT tile (64 KB from L2 / HBM) before row block 0 could start -- 3700 cycles per tile on the waves every
-    // barrier then waits for (profiles/r03_gemm_pass_overlap.txt: row block 0 8582 cycles on wave 0, 4878 on wave 7).
+    // barrier then waits for (profiles/archive_r01_r04/r03_gemm_pass_overlap.txt: row block 0 8582 cycles on wave 0, 4878 on wave 7).
     // (Not on the 128 x 128 tile: its two workgroups per CU use all 160 KB already.)
     constexpr bool LBIAS = ALIAS && EPI != EPI_DGELU;
     constexpr int BIAS_OFF = NSTAGE * STAGE + (ALIAS ? 0 : NW * 4096), BIAS_LDS = LBIAS ? 2048 : 0;
@@ -797,7 +797,7 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
 #endif
     // Tile variants: 1 = 128x128 x 2 stages, own epilogue patches, two 4-wave workgroups per CU; 2 = 256x128 x 3 stages and
     // 3 = 256x256 x 2 stages: one 8-wave workgroup per CU, patches inside the consumed stage buffer.  Measured choice
-    // (tools/bench_gemm_nt.py, profiles/r02_gemm_nt_vs_library.*): 256x128 x 3 is the all-round shape; 256x256 halves the
+    // (tools/bench_gemm_nt.py, profiles/archive_r01_r04/r02_gemm_nt_vs_library.*): 256x128 x 3 is the all-round shape; 256x256 halves the
     // L2 -> LDS fill per flop and wins wide outputs with k >= 512 and every GELU / GELU' epilogue with n >= 512 (fewer,
     // larger tiles: the VALU-bound epilogue is paid per output element, the barrier / drain around it per tile);
     // 128x128 when the launch would not fill the chip otherwise.  (hs_gemm_nt_set_tile forces a variant for A/B runs.)
@@ -819,7 +819,7 @@ int hs_gemm_nt(const void* a, int64_t lda, const void* b, int64_t ldb, int k, co
     // (the 256 x 256 kernels take an epilogue input through the DMA ring, which moves whole 16-byte chunks)
     if (variant == 3 && (epilogue == EPI_DGELU || epilogue == EPI_RESID) && n % 8) variant = 2;
     hipStream_t st = (hipStream_t)stream;
-    // role-separated DMA issue (FAST) wherever there is no K tail (8-16 % on the 256 x 256 tile, profiles/r03_gemm_role_split.txt)
+    // role-separated DMA issue (FAST) wherever there is no K tail (8-16 % on the 256 x 256 tile, profiles/archive_r01_r04/r03_gemm_role_split.txt)
     const bool fast = k % 64 == 0 && k2 % 64 == 0;
     switch (variant) {
         case 2: return fast ? launch_tile<256, 128, 4, 2, 3, true, true>(p, epilogue, 1, st) : launch_tile<256, 128, 4, 2, 3, true, false>(p, epilogue, 1, st);

@@ -26,7 +26,7 @@ inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 // the attention kernels, the module kernel) leave the reserved CUs free for kernels of OTHER streams that must make progress
 // at the same time -- RCCL's all-reduce kernels during the backward of a data-parallel run: a persistent grid that fills
 // every CU either delays them to its end (no overlap) or, if they were resident first, runs its last workgroups as a second
-// round (profiles/r03_cu_contention.json).
+// round (profiles/archive_r01_r04/r03_cu_contention.json).
 int reserved_cus();
 inline int usable_cus_per_xcd() { return 32 - reserved_cus() / 8; }
 inline int usable_cus() { return 8 * usable_cus_per_xcd(); }

@@ -11,7 +11,7 @@
 // (tests/test_gpu_kernels.py::test_gelu_matches_erf_gelu bounds the shipped kernels at 2e-6) -- three orders of magnitude below
 // a bf16 rounding of the result.  Rounds 1-3 used Abramowitz & Stegun 7.1.26 (1.5e-7: one v_rcp_f32 + one v_exp_f32 + 7
 // multiply-adds per element); this form costs 12 instead of 18 VALU issue slots per element PAIR in the packed forward
-// epilogue and half the transcendentals (profiles/r03_gemm_trace_role_split.txt: that epilogue is VALU-bound).
+// epilogue and half the transcendentals (profiles/archive_r01_r04/r03_gemm_trace_role_split.txt: that epilogue is VALU-bound).
 #pragma once
 #include "hs_device.h"
 

@@ -68,7 +68,7 @@ struct vec_io<bf16_t, 8> {
     }
 };
 // (non-temporal stores for the residual-stream sum were measured here: +1-3 % on the kernel, nothing on the step --
-// profiles/r03_ln_store_ab.txt; the plain store stays)
+// profiles/archive_r01_r04/r03_ln_store_ab.txt; the plain store stays)
 template <typename T, int VEC>
 __device__ __forceinline__ void store_stream(void* p, int64_t i, const float* v) {
     vec_io<T, VEC>::store(p, i, v);

@@ -76,7 +76,7 @@ inline Geometry geometry_for(int64_t rows, int n_out, int k_in, int tile_k, int 
     g.dma = g.rows_per_slice * (int64_t)(n_out > k_in ? n_out : k_in) * elt < ((int64_t)1 << 31);
     // stage schedule of the LDS-DMA kernels: 3 = next stage's DMA issued behind the fragment reads + the second wave group half a
     // stage out of phase (8-wave tile).  (0 = DMA before the reads, 1 = behind them, 2 = behind the first MFMA group: the schedules
-    // round 2 measured against it, profiles/r02_wgrad_schedule_ab.txt)
+    // round 2 measured against it, profiles/archive_r01_r04/r02_wgrad_schedule_ab.txt)
     g.reads_first = 3;
     return g;
 }

@@ -3,7 +3,7 @@
 // Every split-K weight-gradient launch (csrc/linear_wgrad.hip) and every LayerNorm backward (csrc/layernorm.hip) ends in a
 // tiny "sum the per-workgroup partial records into the parameter's fp32 gradient" launch: 239 + 100 of them per HEAL-SWIN-B step,
 // 147 + 52 per HEAL-SWIN-T step -- each 5-11 us of GPU time that is launch ramp and a serial walk over the slices, 6 % + 1.7 % of
-// the T@128 step (profiles/r04_k_T128_summary.txt).  Nothing on the backward's critical path reads a parameter gradient, so
+// the T@128 step (profiles/archive_r01_r04/r04_k_T128_summary.txt).  Nothing on the backward's critical path reads a parameter gradient, so
 // callers that deposit into gradient buffers may pass HS_ACC_DEFER in `accumulate`: the producing kernel runs as before, the
 // reduction is QUEUED (host side, per thread) and hs_reduce_flush folds all queued jobs in ONE launch -- before the gradient
 // exchange of a bucket, at the end of the backward pass, or when the queue is full.  The partial records must stay alive (and

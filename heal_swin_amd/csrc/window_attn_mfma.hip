@@ -93,9 +93,9 @@ __device__ __forceinline__ bf16x8 join(s16x4 a, s16x4 b) {
 // The head's bias gradient is accumulated in registers over all windows of the launch (same layout as the bias) and
 // written once per workgroup to a partial buffer that a second tiny kernel reduces -- no atomics, deterministic.
 //
-// Arrangement (round 4; the round-3 kernel was issue / barrier bound -- profiles/r03_attn_bwd_ablation.txt: 34.5 VALU
+// Arrangement (round 4; the round-3 kernel was issue / barrier bound -- profiles/archive_r01_r04/r03_attn_bwd_ablation.txt: 34.5 VALU
 // instructions per MFMA, 5 barriers per window, 72 % of its time left with all global traffic removed; this one: 23.0, 3
-// barriers, stage 0 of HEAL-SWIN-B 680 -> 555-570 us, profiles/r04_attn_v2_ab.txt, r04_attn_pmc_*.json):
+// barriers, stage 0 of HEAL-SWIN-B 680 -> 555-570 us, profiles/archive_r01_r04/r04_attn_v2_ab.txt, r04_attn_pmc_*.json):
 //  * TRANSPOSED output products.  dQ^T = K^^T dS'^T, dK^^T = Q^T dS', dV^T = dO^T P are the same MFMAs with the A and B operands
 //    exchanged; the accumulator then has lane = token, registers = 4 consecutive features x 4 groups.  bf16 packing gives 8-byte
 //    pieces, one v_permlane32_swap per dword pairs them into 16 contiguous bytes, and each lane stores its token's row piece
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         {
         // (Measured, not kept: the same arithmetic on register PAIRS with v_pk_fma / v_pk_mul / v_pk_add -- 17 instead of 23 VALU
         // instructions per MFMA -- is 4-5 % SLOWER at every stage (stage 0: 584-591 us against 555-570, stage 2: 171 against
-        // 163-166; profiles/r04_attn_v2_ab.txt): a packed fp32 op occupies the SIMD for two passes, so it frees issue slots but no
+        // 163-166; profiles/archive_r01_r04/r04_attn_v2_ab.txt): a packed fp32 op occupies the SIMD for two passes, so it frees issue slots but no
         // ALU time, and it lengthens every dependent chain.)
         // pass 1: P and the (dropout-masked) dP in place; D = sum_k P dP over this lane's 32 keys
         auto pass1 = [&](auto masked_tag) {
@@ -1037,7 +1037,7 @@ int fwd_slots(const AttnParams& p, int hg) { return persistent_slots(p, p.nH / h
 // Heads per workgroup.  Forward (one wave per head): 4 where the head count allows (round 2: 2 / 1 heads per workgroup 3-7 % / 20 %
 // slower).  Backward (two waves per head): round 2 measured pairs ahead of four heads on the 5-barrier kernel (8-wave barriers);
 // with the 3-barrier kernel of round 4 FOUR heads per workgroup (8 waves, 137 KB of LDS, one workgroup per CU, 256-byte row
-// segments) win at every stage of HEAL-SWIN-B (profiles/r04_attn_bwd_hg4_ab.txt, same box: 570 -> 515, 290 -> 260, 163 -> 150,
+// segments) win at every stage of HEAL-SWIN-B (profiles/archive_r01_r04/r04_attn_bwd_hg4_ab.txt, same box: 570 -> 515, 290 -> 260, 163 -> 150,
 // 96 -> 93 us).
 int pick_head_group_bwd(const AttnParams& p) {
     const int nH = p.nH;
@@ -1047,7 +1047,7 @@ int pick_head_group_bwd(const AttnParams& p) {
     if (nH % 4 == 0 && (int64_t)p.B * p.N * p.C * 2 >= (64ll << 20)) return 4;
     // 33 KB of LDS per head.  Three heads (stage 0 of the T model: 192-byte rows) go together -- whole rows per workgroup instead of
     // 64-byte slices whose line neighbours come from L2 (PMC: 1.24 x the algorithmic traffic with one head per workgroup,
-    // profiles/r05_attn_pmc_T256_vs_D256.txt): T @ 128 stage 0 122 -> 92 us, T @ 256 462 -> 450 (profiles/r04_attn_hg_T.txt; six
+    // profiles/r05_attn_pmc_T256_vs_D256.txt): T @ 128 stage 0 122 -> 92 us, T @ 256 462 -> 450 (profiles/archive_r01_r04/r04_attn_hg_T.txt; six
     // heads stay in pairs: 214 vs 238 us in threes)
     if (nH == 3) return 3;
     return nH % 2 == 0 ? 2 : 1;
@@ -1083,7 +1083,7 @@ int launch_bwd(const AttnParams& p, float* workspace, hipStream_t stream) {
 int pick_head_group(const AttnParams& p) {
     const int nH = p.nH;
     // eight heads per workgroup (512-byte row segments, one workgroup of 8 waves per CU) on the large launches: with the
-    // 2-barrier kernel of round 4 stages 1 / 2 of HEAL-SWIN-B run 177 -> 166 / 107 -> 99 us (profiles/r04_attn_fwd_hg8_ab.txt;
+    // 2-barrier kernel of round 4 stages 1 / 2 of HEAL-SWIN-B run 177 -> 166 / 107 -> 99 us (profiles/archive_r01_r04/r04_attn_fwd_hg8_ab.txt;
     // round 3 had measured the opposite on the 3-barrier kernel); the small stage 3 (50 MB) loses 10 %
     if (nH % 8 == 0 && (int64_t)p.B * p.N * p.C * 2 >= (64ll << 20)) return 8;
     if (nH % 4 == 0) return 4;

@@ -895,7 +895,7 @@ int module_fwd_impl(const char* who, const void* x, void* out, const TrainOut& t
         p.proj_w = (const uint16_t*)proj_w; p.proj_b = proj_b; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.bias = bias;
         p.head_scale = head_scale; p.idx = idx; p.roll = idx ? 0 : roll; p.labels = labels; p.B = std::min(chunk, batch - b0);
         p.N = n_tokens; p.flags = flags;
-        p.dma_mode = 0;  // (1 / 2: the measured-and-rejected placements under the qkv product, profiles/r04_attn_module_train.txt)
+        p.dma_mode = 0;  // (1 / 2: the measured-and-rejected placements under the qkv product, profiles/archive_r01_r04/r04_attn_module_train.txt)
 #ifdef HS_MOD_TRACE
         p.trace = g_mod_trace;
 #endif

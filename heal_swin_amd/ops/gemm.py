@@ -16,11 +16,11 @@ OWN_GEMM = os.environ.get("HS_OWN_GEMM", "auto")  # "auto": per-shape choice bel
 
 # Set by parallel.GradBucketAllReduce while compute units are reserved for a co-resident gradient exchange (world > 1): every
 # bf16 Linear product then runs on hs_gemm_nt, whose persistent grids honour hs_set_reserved_cus.  The library GEMMs fill all
-# 256 CUs and cannot be masked: with 8 foreign workgroups resident they lose 64 % (256 -> 420 us, profiles/r03_cu_contention.json).
+# 256 CUs and cannot be masked: with 8 foreign workgroups resident they lose 64 % (256 -> 420 us, profiles/archive_r01_r04/r03_cu_contention.json).
 # Costs ~3 ms per step on an idle chip (HS_OWN_GEMM=1 measurement of round 3), saves ~27 ms under contention (r04_cu_contention.json).
 OWN_GELU_MAX_K = 4096
 OWN_DGELU_MAX_K = 1024
-OWN_BIAS_MAX_K = 0  # (> 0 would send every bias / residual product with k <= this to hs_gemm_nt: measured, slower -- profiles/r03_gemm_policy_ab.txt)
+OWN_BIAS_MAX_K = 0  # (> 0 would send every bias / residual product with k <= this to hs_gemm_nt: measured, slower -- profiles/archive_r01_r04/r03_gemm_policy_ab.txt)
 
 
 class GemmTuner:
@@ -82,7 +82,7 @@ GEMM_TUNER = GemmTuner()
 def own_gemm_ok(epi, n, k, dtype, k2=0, m=None):
     """Whether `hs_gemm_nt` should run this product (else the library GEMM + the standalone elementwise kernel).
     Measured on MI355X against hipBLASLt on the B / nside 256 / batch 8 shapes (tools/bench_gemm_nt.py,
-    profiles/r02_gemm_nt_vs_library.*): the own kernel wins where the product is HBM-bound (short reductions, narrow outputs:
+    profiles/archive_r01_r04/r02_gemm_nt_vs_library.*): the own kernel wins where the product is HBM-bound (short reductions, narrow outputs:
     stages 0-1), ties the untuned hipBLASLt on the K = 512 shapes (and loses to the TunableOp-selected solutions bench.py
     loads) and loses the long reductions (K >= 1024: 0.96-1.06 vs 1.26 PFLOP/s).  A GELU forward epilogue pays while the
     product is HBM-bound (it has to write h AND gelu(h): at K = 512 the 256x256 tile needs 355-368 us against 197 us tuned

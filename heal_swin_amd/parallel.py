@@ -41,7 +41,7 @@ class GradBucketAllReduce:
         cross-rank sum are bf16, as with DDP's bf16 compression hook.
         reserved_cus: compute units the library's chip-filling launches leave free for RCCL's kernels while this exchange is
         active ("auto": 16 when more than one rank exchanges, else 0; see include/healswin.h:hs_set_reserved_cus and
-        profiles/r03_cu_contention.json)."""
+        profiles/archive_r01_r04/r03_cu_contention.json)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.async_wgrad = None

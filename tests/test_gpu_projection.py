@@ -68,7 +68,7 @@ def test_batched_full_size_projection_matches_the_oracle():
         OP.sample_bilinear(imgs[0], v, u).astype(np.uint8)
         OP.sample_mask(masks[0], v, u, 7)
     conftest.NOTES.append(f"projection: numpy oracle {1e3 * (time.perf_counter() - t0):.0f} ms per 966x1280 frame at nside 256 "
-                          "(GPU kernels: tools/bench_projection.py, profiles/r02_projection_sampling.json)")
+                          "(GPU kernels: tools/bench_projection.py, profiles/archive_r01_r04/r02_projection_sampling.json)")
     with np.errstate(invalid="ignore"):
         for b in range(3):
             assert np.array_equal(hp_img[b].cpu().numpy(), OP.sample_bilinear(imgs[b], v, u).astype(np.uint8))

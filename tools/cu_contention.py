@@ -6,7 +6,7 @@ to exactly one resident round of all 256 CUs, and what does hs_set_reserved_cus(
 A stand-in (`hs_debug_occupy_cus`: k workgroups of 256 threads, 128 VGPRs, 16 KB LDS, resident for the whole measurement on a side
 stream) plays the communication kernels.  Measured: (1) the chip-filling kernels one by one at the HEAL-SWIN-B stage-2 shapes,
 (2) the whole B / nside 256 / batch 8 training step.  Round 4: a duty-cycled occupier shaped like the real exchange beside the always-resident one, and the step with every GEMM on
-hs_gemm_nt (ops.RT.prefer_own_gemm).  Writes JSON to stdout (-> profiles/r04_cu_contention.json)."""
+hs_gemm_nt (ops.RT.prefer_own_gemm).  Writes JSON to stdout (-> profiles/archive_r01_r04/r04_cu_contention.json)."""
 import json
 import os
 import sys

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds: heal_swin_amd/lib/libhealswin_expN.so = the library with csrc/gemm_nt.hip compiled with -DHS_GEMM_EXP=N
 # (hipcc ... -DHS_GEMM_EXP=N -c csrc/gemm_nt.hip, linked with the other objects of heal_swin_amd/build/).  When the experiment ran
-# (profiles/r03_gemm_overlap_premise.txt) bit 0 was the role-separated DMA issue, which has since become the shipped kernel (FAST);
+# (profiles/archive_r01_r04/r03_gemm_overlap_premise.txt) bit 0 was the role-separated DMA issue, which has since become the shipped kernel (FAST);
 # what remains behind the switch is bit 1 (N = 2): the store stream under the k-steps.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 L=heal_swin_amd/lib

@@ -30,13 +30,23 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--json", default="")
+    ap.add_argument("--no-tuned-gemm", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda")
+    # the library GEMMs with the solution picks the bench loads (PyTorch TunableOp results for these shapes), not the default heuristic
+    tuned = os.path.join(ROOT, "heal_swin_amd", "tuning", f"tunableop_gfx950_{args.model}256_bs{args.batch}_bf16.csv")
+    library = "default heuristic"
+    if os.path.exists(tuned) and not args.no_tuned_gemm:
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(False)
+        torch.cuda.tunable.set_filename(tuned, insert_device_ordinal=False)
+        if torch.cuda.tunable.read_file(tuned):
+            library = f"TunableOp picks ({os.path.basename(tuned)})"
     embed, heads0, bp = (128, 4, 12) if args.model == "B" else (96, 3, 8)
     depths = [2, 2, 18, 2] if args.model == "B" else [2, 2, 6, 2]
     rows = []
     tot = dict(flops=0.0, t=0.0, core=0.0)
-    print(f"HEAL-SWIN-{args.model} nside 256, {bp} base pixels, batch {args.batch}, bf16: WindowAttention module, forward + backward")
+    print(f"HEAL-SWIN-{args.model} nside 256, {bp} base pixels, batch {args.batch}, bf16: WindowAttention module, forward + backward; library GEMMs: {library}")
     print(f"{'stage':>5} {'C':>5} {'tokens':>8} {'blocks':>6} | {'module us':>10} {'TF/s':>6} {'of 2.5PF':>8} | {'core us':>8} {'GEMM us':>8} "
           f"{'GEMM TF/s':>9} | {'core-free bound':>15}")
     for s in range(4):
