@@ -335,6 +335,9 @@ def main():
     ap.add_argument("--async-wgrad", action="store_true", help="run the Linear weight-gradient kernels on a side stream")
     ap.add_argument("--torch-adam", action="store_true",
                     help="step torch.optim.Adam(fused=True) instead of heal_swin_amd.optim.FlatAdam (same arithmetic; A/B runs)")
+    ap.add_argument("--use-checkpoint", action="store_true",
+                    help="SwinHPTransformerConfig.use_checkpoint = True (swin_hp_transformer.py:541-542: every block's forward recomputed in the "
+                         "backward): the activation-memory policy of the reference, with its price")
     ap.add_argument("--strong-scaling", action="store_true",
                     help="--batch is the GLOBAL batch, split over the ranks (BASELINE's 'batch=8 at 1/2/4/8' read as a fixed total; SURVEY 8d "
                          "asks for both readings).  Default: --batch per GPU (weak scaling, the reference's per-process batch, train.py:34-41)")
@@ -447,6 +450,8 @@ def main():
     if args.paper_drop_rates:
         wl = dict(wl, cfg=dict(wl["cfg"], drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1),
                   name=wl["name"] + " drop 0.1/0.1/0.1")
+    if args.use_checkpoint:
+        wl = dict(wl, cfg=dict(wl["cfg"], use_checkpoint=True), name=wl["name"] + " use_checkpoint")
     ctx = types.SimpleNamespace(args=args, wl=wl, dev=dev, world=world, rank=rank, shared_gpu=shared_gpu)
     res = run_workload(ctx, args.dtype, args.steps, args.warmup, timing=not args.no_kernel_timing)
     elapsed = res.elapsed
@@ -547,6 +552,26 @@ def main():
         except Exception as e:  # noqa: BLE001
             out.setdefault('drop_in', {})
             out['drop_in'] = {**(out['drop_in'] if isinstance(out['drop_in'], dict) else {}), "error": f"{type(e).__name__}: {str(e)[:300]}"}
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+    # the reference's activation-memory policy (use_checkpoint: every block recomputed in the backward) on the same workload: what the
+    # 110 GB (bf16) / 260 GB (fp32) of the lines above shrink to, and what the recomputation costs
+    if world == 1 and args.dtype == "bf16" and not args.use_checkpoint and not args.drop_in and not args.no_companions and not args.graph and not args.tune_gemm:
+        try:  # (a companion line must never cost the headline line: its failure is recorded under its key)
+            wck = dict(wl, cfg=dict(wl["cfg"], use_checkpoint=True), name=wl["name"] + " use_checkpoint")
+            kctx = types.SimpleNamespace(**{**vars(ctx), "wl": wck})
+            out["use_checkpoint"] = {"workload": wck["name"], "batch_per_gpu": args.batch, "unit": "images/s",
+                                     "what": "SwinHPTransformerConfig.use_checkpoint=True (swin_hp_transformer.py:541-542), everything else as the headline / fp32 lines"}
+            for tag, dt, k in (("bf16", "bf16", 5), ("fp32", "fp32", 3)):
+                if tag == "fp32" and args.no_fp32_companion:
+                    continue
+                rck = run_workload(kctx, dt, k, 2, timing=False)
+                out["use_checkpoint"][tag] = {"value": args.batch * k / rck.elapsed, "ms_per_step": 1e3 * rck.elapsed / k, "steps": k, "warmup": 2,
+                                              "final_loss": rck.loss, "peak_device_memory_GB": rck.peak_gb}
+        except Exception as e:  # noqa: BLE001
+            out.setdefault('use_checkpoint', {})
+            out['use_checkpoint'] = {**(out['use_checkpoint'] if isinstance(out['use_checkpoint'], dict) else {}), "error": f"{type(e).__name__}: {str(e)[:300]}"}
             import gc
             gc.collect()
             torch.cuda.empty_cache()
