@@ -663,6 +663,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         }
     }
     int buf = 0, buf_free = AHEAD;  // buffer being computed; buffer the next issue goes to
+#if HS_GEMM_EXP & 32
+    // measurement build: static priority for the second-dispatched half of the waves (the SIMD partners of the DMA-issuing half): at equal
+    // priority the older wave wins every arbitration and the younger one sets the pace of the k-step (tools/gemm_trace.py: 2900 vs 2600 cycles)
+    if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+#if HS_GEMM_EXP & 64
+    if (NW == 8 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);  // (the opposite assignment, for the A/B)
+#endif
     bool drained = false;  // an epilogue's stores are in the queue: the counted wait below would be wrong
     TR(0);
     while (true) {
