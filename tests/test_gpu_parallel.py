@@ -266,3 +266,21 @@ def test_bench_script_eight_ranks_on_one_gpu():
         assert rc["gemm_policy"] is not None and set(rc["gemm_policy"]["trial_ms_per_step"]) == {"own", "per_shape_with_library"}
         tl = rc["bucket_timeline_rank0"]
         assert isinstance(tl, list) and len(tl) >= rc["buckets"] and all("ms" in e and "launched_from" in e for e in tl), tl
+
+
+def test_bench_script_drop_in_two_ranks_on_one_gpu():
+    """`bench.py --drop-in --gpus 2`: the level-1 integration as a multi-rank run -- torch's DistributedDataParallel around the module, no gradient
+    sink -- through the same launcher path as the driver's runs (two ranks sharing the GPU over gloo)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "tiny", "--drop-in"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "drop-in" in out["config"]["step"] and "DistributedDataParallel" in out["config"]["step"]
+    assert out["rccl"]["rccl_ranks"] == 2 and "DistributedDataParallel" in out["rccl"]["exchange"] and out["rccl"]["gemm_policy"] is None
