@@ -671,7 +671,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
 #if HS_GEMM_EXP & 64
     if (NW == 8 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);  // (the opposite assignment, for the A/B)
 #endif
-    bool drained = false;  // an epilogue's stores are in the queue: the counted wait below would be wrong
+    bool drained = false;  // an epilogue's stores are in the queue behind the operand pieces
+    constexpr int kEpiOps = TM * (TN / 2 > 0 ? TN / 2 : 1) * 4;  // vector-memory operations of the SMALLEST epilogue (four row-segment stores per row block)
+    static_assert((AHEAD - 1) * PIECES_ALL + kEpiOps <= 63, "vmcnt immediate");
     TR(0);
     while (true) {
         TR(3);
@@ -681,6 +683,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
             // an epilogue waits for its own input loads itself)
         } else if (AHEAD > 1 && issued == AHEAD && !drained)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PIECES_ALL) : "memory");
+        else if (drained && issued == AHEAD)
+            // behind an epilogue the queue holds, youngest last: [this step's pieces] [the later steps' pieces] [the epilogue's stores and
+            // input requests].  Waiting for the STORES' acknowledgements (vmcnt(0)) cost the issuing waves -- the ones every barrier waits
+            // for -- ~700 cycles per tile (tools/gemm_trace.py: "epilogue end -> next step"); the pieces are covered once no more than the
+            // later steps' pieces and kEpiOps epilogue operations remain (kEpiOps = the fewest an epilogue issues: one output's stores)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PIECES_ALL + kEpiOps) : "memory");
+        else if (drained && issued == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEpiOps) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         drained = false;
