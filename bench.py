@@ -897,7 +897,7 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
         step()
     sync()
     gemm_policy = None
-    if world > 1 and dtype_name == "bf16" and not args.graph and not drop_in:
+    if world > 1 and dtype_name == "bf16" and not drop_in:
         # With CUs reserved for RCCL the sink routes every bf16 Linear to hs_gemm_nt (whose grids honour the reservation), which costs
         # ~4 % on an idle chip and saves 16 % if the exchange's kernels do stay resident (profiles/archive_r01_r04/r04_cu_contention.json).  Which of the
         # two this node's exchange looks like is MEASURED here instead of assumed: three steps under each policy (max over ranks), the
@@ -921,9 +921,35 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
     if args.tune_gemm:
         torch.cuda.tunable.tuning_enable(False)  # every shape was met during the warm-up; PyTorch writes the file at exit
     epoch = None
-    if args.graph:
-        if world > 1:
-            raise SystemExit("--graph supports single-GPU runs (collectives are not captured)")
+    if args.graph and world > 1:
+        # collectives are not captured: two graphs around the sink's eager exchange (heal_swin_amd.graphs.GraphedTrainStep does the same)
+        if args.paper_drop_rates or drop_in:
+            raise SystemExit("--graph with --gpus > 1: no dropout replay counter / drop-in wiring on this path")
+
+        def fwd_bwd_local():
+            with dp.no_sync():
+                dp.zero_grad()
+                loss = model.forward_seg_loss(imgs.float(), labels) if fused_loss else loss_fn(model(imgs.float()), labels)
+                loss.backward()
+                dp.finish()
+            return loss
+        graph, graph_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = fwd_bwd_local()
+        dp.finish()
+        with torch.cuda.graph(graph_opt):
+            opt.step()
+
+        def step():  # noqa: F811
+            graph.replay()
+            dp.finish()
+            graph_opt.replay()
+            return static_loss
+
+        eager_step = None
+        step()
+        sync()
+    elif args.graph:
         eager_step = step
         if args.paper_drop_rates:
             # the kernels' host-drawn dropout seeds are frozen into the graph; the library's replay counter is not (hs_set_seed_epoch:
@@ -1021,6 +1047,8 @@ def _run_workload(ctx, dtype_name, steps, warmup, timing, undo):
     del model, dp, opt, imgs, labels, loss, step, net, ddp
     if args.graph:
         del graph, static_loss, eager_step
+        if world > 1:
+            del graph_opt
     del epoch  # (its registration with the library is withdrawn by run_workload's `undo`, which still holds the tensor)
     gc.collect()
     torch.cuda.empty_cache()

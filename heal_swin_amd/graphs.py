@@ -11,8 +11,13 @@ what the reference would have needed a tracing compiler for.
     for images, labels in loader:
         loss = step(images, labels)          # copies the batch into the graph's static buffers and replays
 
-Constraints (checked): single process (collectives are not captured -- under DP use the eager step), a `capturable=True` optimizer,
-fixed shapes.  Dropout / DropPath: the kernels' seeds are drawn on the host per call and are frozen into the graph; a model with
+Constraints (checked): a `capturable=True` optimizer, fixed shapes.  Data parallelism (world > 1, round 6): collectives are not captured, so
+the step becomes TWO graphs around an eager exchange -- graph 1: zero_grad -> forward -> loss -> backward with the gradients accumulated
+locally in the sink's flat buckets (`GradBucketAllReduce.no_sync()`: the hooks launch nothing); eager: `sink.finish()` all-reduces every
+bucket; graph 2: the optimizer step.  That gives up the overlap of the exchange with the backward (all buckets leave after the backward) for
+the host launch rate: it pays on the launch-bound workloads (HEAL-SWIN-T at nside <= 128: 18-19 ms eager, 15 ms replayed, ~1-2 ms of
+exposed exchange for 165 MB of gradients), not on the GPU-bound ones.  Needs the package's gradient sink (`grad_sink=`); torch's
+DistributedDataParallel launches its collectives from autograd hooks inside the backward and cannot be split this way.  Dropout / DropPath: the kernels' seeds are drawn on the host per call and are frozen into the graph; a model with
 drop rates > 0 is replayed with a device-side step counter registered with the library (`hs_set_seed_epoch`): every mask generator
 adds counter x odd constant to its frozen seed, the captured step ends with counter += 1, so every replay draws fresh masks and the
 forward and backward of a step agree.  DropPath's per-sample factors come from torch's CUDA generator, which is graph-safe by itself.
@@ -33,8 +38,10 @@ class GraphedTrainStep:
         cfg = getattr(model, "config", None)
         stochastic = model.training and cfg is not None and any(getattr(cfg, n, 0.0) for n in ("drop_rate", "attn_drop_rate", "drop_path_rate"))
         self._epoch = None
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            raise ValueError("GraphedTrainStep: gradient all-reduce is not captured; use the eager step under data parallelism")
+        self._dp = bool(torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)
+        if self._dp and (grad_sink is None or getattr(grad_sink, "world", 1) <= 1):
+            raise ValueError("GraphedTrainStep under data parallelism needs grad_sink=GradBucketAllReduce(...): the step is replayed as two "
+                             "graphs around the sink's eager exchange (torch DDP's in-backward collectives cannot be captured)")
         for group in optimizer.param_groups:
             if not group.get("capturable", False):
                 raise ValueError("GraphedTrainStep: the optimizer must be constructed with capturable=True")
@@ -70,8 +77,17 @@ class GraphedTrainStep:
         torch.cuda.synchronize(self.inputs.device)
 
         self.graph = torch.cuda.CUDAGraph()
+        if not self._dp:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager()
+            return
+        # data parallel: [graph 1: zero_grad, forward, loss, backward into the local buckets] -> eager exchange -> [graph 2: optimizer]
+        self.graph_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = self._eager()
+            self.loss = self._fwd_bwd_local()
+        self.grad_sink.finish()  # (an exchange between the two captures keeps every rank's collective sequence aligned with the replays')
+        with torch.cuda.graph(self.graph_opt):
+            self._opt_step()
 
     def _eager(self):
         if self.grad_sink is not None:
@@ -87,6 +103,20 @@ class GraphedTrainStep:
         if self._epoch is not None:
             self._epoch.add_(1)  # the next step (replay) draws new masks
         return loss.detach()
+
+    def _fwd_bwd_local(self):
+        with self.grad_sink.no_sync():  # gradients accumulate in the flat buckets; no hook launches a collective
+            self.grad_sink.zero_grad()
+            x = self.inputs if self.pre_forward is None else self.pre_forward(self.inputs)
+            loss = self.loss_fn(self.model(x), self.targets)
+            loss.backward()
+            self.grad_sink.finish()  # (local: queued parameter-gradient sums land, nothing is exchanged)
+        return loss.detach()
+
+    def _opt_step(self):
+        self.optimizer.step()
+        if self._epoch is not None:
+            self._epoch.add_(1)
 
     def close(self):
         """Unregister the replay counter (stochastic models); the graph must not be replayed afterwards."""
@@ -106,6 +136,9 @@ class GraphedTrainStep:
         self.inputs.copy_(inputs, non_blocking=True)
         self.targets.copy_(targets, non_blocking=True)
         self.graph.replay()
+        if self._dp:
+            self.grad_sink.finish()   # eager: every bucket all-reduced (averaged) and waited for on the current stream
+            self.graph_opt.replay()
         # The replay updated the parameters on the device without touching their Python-side version counters, which is what
         # ops.ParamCastCache keys its bf16 copies on: an EAGER forward after this replay (validation, the no-grad fused path)
         # must re-make them.  (The replayed step itself refreshes its copies inside the graph.)  Host-only, no launch.

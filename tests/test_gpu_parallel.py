@@ -284,3 +284,89 @@ def test_bench_script_drop_in_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and "drop-in" in out["config"]["step"] and "DistributedDataParallel" in out["config"]["step"]
     assert out["rccl"]["rccl_ranks"] == 2 and "DistributedDataParallel" in out["rccl"]["exchange"] and out["rccl"]["gemm_policy"] is None
+
+
+def _graphed_dp_worker(rank, world, port, graphed, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from heal_swin_amd.graphs import GraphedTrainStep
+    from heal_swin_amd.losses import seg_loss
+    from heal_swin_amd.optim import FlatAdam
+    from heal_swin_amd.parallel import GradBucketAllReduce
+    model = _build().train()
+    x, y = _data()
+    xs, ys = x.chunk(world)[rank], y.chunk(world)[rank]
+    dp = GradBucketAllReduce(model.parameters(), bucket_bytes=256 << 10)
+    opt = FlatAdam(model.parameters(), dp, lr=1e-3, model=model)
+    losses = []
+    if graphed:
+        step = GraphedTrainStep(model, lambda out, t: seg_loss(out, t), opt, xs, ys, warmup=2, grad_sink=dp)
+        for _ in range(3):
+            losses.append(float(step(xs, ys)))
+    else:
+        for _ in range(2 + 3):  # the graphed run's two warm-up steps are real training steps too
+            dp.zero_grad()
+            loss = seg_loss(model(xs), ys)
+            loss.backward()
+            dp.finish()
+            opt.step()
+            losses.append(float(loss.detach()))
+        losses = losses[2:]
+    torch.cuda.synchronize()
+    q.put((rank, losses, [p.detach().float().cpu().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_train_step_under_data_parallelism_equals_the_eager_dp_step():
+    """GraphedTrainStep with world > 1: [graph: zero_grad, forward, loss, backward into the local buckets] -> eager bucket exchange ->
+    [graph: FlatAdam].  Two ranks on one GPU over gloo: same losses and bit-identical parameters as the eager data-parallel step (the
+    exchange sums the same buckets in the same order; only its timing relative to the backward differs), replicas identical."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    res = {}
+    for graphed in (False, True):
+        world, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_graphed_dp_worker, args=(r, world, port, graphed, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        res[graphed] = {r: (l, ps) for r, l, ps in got}
+    for graphed in (False, True):
+        for a, b in zip(res[graphed][0][1], res[graphed][1][1]):
+            assert np.array_equal(a, b), "replicas diverged"
+    for r in (0, 1):
+        assert res[True][r][0] == res[False][r][0], (res[True][r][0], res[False][r][0])
+    for a, b in zip(res[True][0][1], res[False][0][1]):
+        assert np.array_equal(a, b)
+
+
+def test_bench_script_graph_replay_with_two_ranks_on_one_gpu():
+    """`bench.py --graph --gpus 2`: the step as two HIP graphs around the eager bucket exchange, through the driver's launcher path (two
+    ranks sharing the GPU over gloo); the line says so and the loss is the eager run's."""
+    import json
+    import subprocess
+    env = dict(os.environ, HS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for extra in ([], ["--graph"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--workload", "tiny"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        outs[bool(extra)] = json.loads(lines[0])
+    g, e = outs[True], outs[False]
+    assert g["config"]["launch"] == "hip graph replay" and e["config"]["launch"] == "eager" and g["n_gpus"] == 2
+    assert g["rccl"]["rccl_ranks"] == 2 and g["rccl"]["gemm_policy"] is not None
+    # the graphed run takes 1 (graph warm-up) step more before its timed region than the eager one: compare loosely
+    assert abs(g["config"]["final_loss"] - e["config"]["final_loss"]) < 0.05 * abs(e["config"]["final_loss"]), (g["config"]["final_loss"], e["config"]["final_loss"])
