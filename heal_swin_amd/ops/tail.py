@@ -155,14 +155,19 @@ class ExpandLnHeadFn(torch.autograd.Function):
         return dxn, dwexp, dgamma, dbeta, dw, None
 
 
+_CE_PERM = {}
+
+
 def _fold_head_ce(gamma, beta, weight, C, device):
     """The folded head weight for `hs_ln_head_ce_bwd`: as _fold_head, but with row blocks 4..7 and 8..11 exchanged, so that the
     kernel's accumulator register r < 8 of lane half h is class 8 h + r (csrc/ln_head.hip:ln_head_ce_bwd_kernel)."""
     wfold, bvec = _fold_head(gamma, beta, weight, C, device)
-    perm = torch.arange(32, device=device)
-    perm[4:8], perm[8:12] = torch.arange(8, 12, device=device), torch.arange(4, 8, device=device)
-    perm64 = torch.cat([perm, perm + 32])
-    return wfold[perm64].contiguous(), bvec[perm].contiguous()
+    key = str(device)
+    if key not in _CE_PERM:  # (built once per device: six tiny launches per step otherwise)
+        perm = list(range(4)) + list(range(8, 12)) + list(range(4, 8)) + list(range(12, 32))
+        _CE_PERM[key] = (torch.tensor(perm + [i + 32 for i in perm], device=device), torch.tensor(perm, device=device))
+    perm64, perm = _CE_PERM[key]
+    return wfold[perm64], bvec[perm]  # (advanced indexing: fresh contiguous tensors)
 
 
 class ExpandLnHeadCeFn(torch.autograd.Function):
