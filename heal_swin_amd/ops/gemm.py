@@ -44,11 +44,17 @@ class GemmTuner:
 
     def pick(self, m, n, k, device):
         key = self.key(m, n, k)
-        hit = self.picks.get(key)
-        if hit is not None:
-            return hit
+        if key in self.picks:
+            return self.picks[key]  # (None: a trial that failed -- the class rule answers from then on)
         if 2 * m * n * k < self.MIN_FLOP or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
             return None
+        try:
+            return self._trial(key, m, n, k, device)
+        except Exception:  # noqa: BLE001  (out of memory beside a large model, a library error: never the caller's problem)
+            self.picks[key] = None
+            return None
+
+    def _trial(self, key, m, n, k, device):
         with torch.no_grad():
             g = torch.Generator(device=device).manual_seed(1)
             sets = [(torch.randn((m, k), generator=g, device=device).to(torch.bfloat16),
