@@ -382,6 +382,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
         const uint32_t patch_off = ALIAS ? buf_done * STAGE : NSTAGE * STAGE;  // byte offset of the patch area inside smem
         TR(10);
         if (ALIAS) __builtin_amdgcn_s_barrier();  // every wave is done reading the stage buffer the patches live in
+#ifdef HS_GEMM_WAVE_STAGGER
+        // measurement build: the waves enter the epilogue HS_GEMM_WAVE_STAGGER x 64 cycles apart, so that their VALU / LDS-write / store phases
+        // (which they otherwise all run at the same moment on CU-wide resources) interleave
+        for (int w = 0; w < wave; ++w) __builtin_amdgcn_s_sleep(HS_GEMM_WAVE_STAGGER);
+#endif
         TR(11);
         const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
         const int64_t m0 = (int64_t)tm * BM;
