@@ -53,6 +53,19 @@ typedef __attribute__((address_space(3))) void lds_void;
 // tile's worth of bytes (into `aux`, which the bias epilogue does not use) from INSIDE the k-steps, a 1-KB instruction per wave and
 // 16-deep sub-step: the skeleton of an epilogue whose stores ride under the next tile's MFMAs (profiles/archive_r01_r04/r03_gemm_overlap_premise.txt:
 // it costs 65-75 % of what the same bytes cost in a serial epilogue)
+// HS_GEMM_STORE_AUX: cache policy of the epilogue's row-segment stores (gfx950: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).  Default 2 = NON-TEMPORAL:
+// an output tile is written once and read by another kernel; stored with the default policy its lines are allocated in the XCD's L2
+// (4 MB for 32 CUs x 128-256 KB of output per tile) and push out the A panel / weight lines the neighbouring workgroups re-read.  Same box,
+// s2 fc1 (us): bias 239.7 / 238.7 -> 225.1 / 228.4, + GELU 302.7 / 306.0 -> 289.2 / 289.5, GELU' 318.0 / 317.1 -> 315.8 / 311.7; whole step
+// 147.2 -> 144.6 ms (HEAL-SWIN-B), 45.9 -> 44.7 ms (paper T @ 256); sc1 (write-through) alone: nothing (profiles/r06_gemm_store_policy.txt)
+#ifndef HS_GEMM_STORE_AUX
+#define HS_GEMM_STORE_AUX 2
+#endif
+// HS_GEMM_IN_AUX: cache policy of the epilogue's INPUT rows (h for GELU', the residual), read once through the DMA ring.  Default 2 = non-temporal,
+// for the reason above: GELU' s2 292.0 / 293.5 -> 282.8 / 286.4 us, s1 426 / 423 -> 414 / 415 (profiles/r06_gemm_store_policy.txt)
+#ifndef HS_GEMM_IN_AUX
+#define HS_GEMM_IN_AUX 2
+#endif
 #ifndef HS_GEMM_EXP
 #define HS_GEMM_EXP 0
 #endif
@@ -443,7 +456,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
             unsigned char* base = smem + patch_off + (i & 1) * (NW * 4096) + wave * 4096;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + t * 1024), 16, in_voff, row_soff(i, t), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + t * 1024), 16, in_voff, row_soff(i, t), 0, HS_GEMM_IN_AUX);
         };
         if constexpr (RING) {
             request_in(0);
@@ -598,7 +611,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
                     TR(22);  // patch round trip done
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rws[t]), rs, rl_voff, row_soff(i, t), 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rws[t]), rs, rl_voff, row_soff(i, t), HS_GEMM_STORE_AUX);
                     // the data registers stay live across one wait state behind the last store (see above)
                     asm volatile("s_nop 0" ::"v"(rws[0]), "v"(rws[1]), "v"(rws[2]), "v"(rws[3]));
                 } else {
@@ -607,7 +620,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_nt_kernel(GemmParams p) 
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int n = ncol0 + j * 32 + 4 * half + 8 * g;
-                            __builtin_amdgcn_raw_buffer_store_b64(o[j][g], rs, n < p.n ? (uint32_t)(ml * n2 + n * 2) : kOob, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(o[j][g], rs, n < p.n ? (uint32_t)(ml * n2 + n * 2) : kOob, 0, HS_GEMM_STORE_AUX);
                         }
                 }
             };

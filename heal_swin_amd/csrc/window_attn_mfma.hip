@@ -27,6 +27,21 @@
 // per-lane factor applied to the fp32 scores.
 #include "window_attn.h"
 
+// HS_ATTN_STORE_AUX (measurement builds): cache policy of the row stores of O / dQ / dK / dV (gfx950: bit 1 = nt); see csrc/gemm_nt.hip
+#ifndef HS_ATTN_STORE_AUX
+#define HS_ATTN_STORE_AUX 0
+#endif
+// HS_ATTN_LOAD_AUX: cache policy of the q / k / v / dO row loads (every row is read once per head group)
+#ifndef HS_ATTN_LOAD_AUX
+#define HS_ATTN_LOAD_AUX 0
+#endif
+#ifndef HS_ATTN_LOAD_AUX_FWD
+#define HS_ATTN_LOAD_AUX_FWD HS_ATTN_LOAD_AUX
+#endif
+#ifndef HS_ATTN_LOAD_AUX_BWD
+#define HS_ATTN_LOAD_AUX_BWD HS_ATTN_LOAD_AUX
+#endif
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -256,10 +271,10 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const uint32_t vo = (uint32_t)tok_ld[rb] * c3b + colb;
-            ldq[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, 0);
-            ldk[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, cb, 0);
-            ldv[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 2 * cb, 0);
-            lddo[rb] = __builtin_amdgcn_raw_buffer_load_b128(rd, (uint32_t)tok_ld[rb] * cb + colb, 0, 0);
+            ldq[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, HS_ATTN_LOAD_AUX_BWD);
+            ldk[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, cb, HS_ATTN_LOAD_AUX_BWD);
+            ldv[rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 2 * cb, HS_ATTN_LOAD_AUX_BWD);
+            lddo[rb] = __builtin_amdgcn_raw_buffer_load_b128(rd, (uint32_t)tok_ld[rb] * cb + colb, 0, HS_ATTN_LOAD_AUX_BWD);
         }
         lse_next = p.lse[((int64_t)b_l * nH + h) * N + j_l + qq];
         if (p.labels && wv == 0) lab_next = p.labels[j_l + lane];
@@ -557,8 +572,8 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
             }
             u32x4 p0, p1;
             pack_rows_t(x, p0, p1);
-            __builtin_amdgcn_raw_buffer_store_b128(p0, rdq, vst, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(p1, rdq, vst + 32u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p0, rdq, vst, 0, HS_ATTN_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, rdq, vst + 32u, 0, HS_ATTN_STORE_AUX);
         }
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();  // B: both scratches complete
@@ -612,10 +627,10 @@ __global__ void __launch_bounds__(128 * HG, 2) attn_bwd_mfma_kernel(AttnParams p
         // counts loads and stores together and the two complete out of order, so a wait for the rows at the top of the next
         // window would also wait for these stores' round trip.
         if constexpr (!NOPIPE) claim();
-        __builtin_amdgcn_raw_buffer_store_b128(k0, rdq, vst, cb, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(k1, rdq, vst + 32u, cb, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(v0, rdq, vst, 2 * cb, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(v1, rdq, vst + 32u, 2 * cb, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(k0, rdq, vst, cb, HS_ATTN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(k1, rdq, vst + 32u, cb, HS_ATTN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v0, rdq, vst, 2 * cb, HS_ATTN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v1, rdq, vst + 32u, 2 * cb, HS_ATTN_STORE_AUX);
         lds_barrier();  // C: every wave is done with the tiles and the scratches
     }
 
@@ -744,9 +759,9 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const uint32_t vo = (uint32_t)tok_ld[rb] * c3b + colb;
-            ld[0][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, 0);
-            ld[1][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, cb, 0);
-            ld[2][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 2 * cb, 0);
+            ld[0][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, HS_ATTN_LOAD_AUX_FWD);
+            ld[1][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, cb, HS_ATTN_LOAD_AUX_FWD);
+            ld[2][rb] = __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 2 * cb, HS_ATTN_LOAD_AUX_FWD);
         }
         if (p.labels && g == 0) lab_next = p.labels[j_l + lane];
     };
@@ -967,10 +982,10 @@ __global__ void __launch_bounds__(64 * HG, 2) attn_fwd_mfma_kernel(AttnParams p,
         claim();
         const __amdgpu_buffer_rsrc_t ro = image_rsrc(p.out, img_out, b);
         const uint32_t hb = (uint32_t)(h * kHd) * 2u + 16u * half;
-        __builtin_amdgcn_raw_buffer_store_b128(o00, ro, (uint32_t)tq0 * cb + hb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o01, ro, (uint32_t)tq0 * cb + hb + 32u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o10, ro, (uint32_t)tq1 * cb + hb, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o11, ro, (uint32_t)tq1 * cb + hb + 32u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o00, ro, (uint32_t)tq0 * cb + hb, 0, HS_ATTN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(o01, ro, (uint32_t)tq0 * cb + hb + 32u, 0, HS_ATTN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(o10, ro, (uint32_t)tq1 * cb + hb, 0, HS_ATTN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(o11, ro, (uint32_t)tq1 * cb + hb + 32u, 0, HS_ATTN_STORE_AUX);
         lds_barrier();  // B: every wave is done with the tiles
     }
 }
